@@ -1,0 +1,164 @@
+/* libvaegslm_hip -- C ABI of the MI355X (gfx950) VAE-GSLM training hot path.
+ *
+ * The reference (b04901014/vae-gslm) has no native layer: its hot path is a
+ * chain of ATen calls inside Python nn.Modules.  Each entry point below
+ * replaces one such call site (cited as reference file:line); the Python
+ * binding a maintainer adds is shown in INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; the message is
+ *    retrievable with vg_last_error() (thread-local); nothing throws;
+ *  - all pointers are DEVICE pointers owned by the caller unless noted;
+ *    no function allocates, frees or synchronises -> safe under stream
+ *    capture (hipGraph);
+ *  - `stream` is the hipStream_t the work is enqueued on;
+ *  - sequences are right-padded: frame (b, t) is valid iff t < lengths[b]
+ *    (utils/tensormask.py:45-54).  `lengths` may be NULL (= all valid).
+ *    Rows are frames in (b, t) order: row m = b * T + t;
+ *  - dtype selects the STORAGE type of activations: VG_F32 runs the
+ *    exact-f32 MFMA path (parity), VG_BF16 the bf16 MFMA path (speed);
+ *    accumulation, softmax statistics, norms and losses are always fp32.
+ */
+#ifndef VAEGSLM_HIP_H
+#define VAEGSLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vg_stream_t; /* == hipStream_t */
+
+enum { VG_F32 = 0, VG_BF16 = 1 };
+enum { VG_ACT_NONE = 0, VG_ACT_RELU = 1, VG_ACT_GELU = 2 };
+
+int vg_version(void);
+/* copies the calling thread's last error message (NUL terminated) */
+int vg_last_error(char* buf, int buflen);
+
+/* ---------------------------------------------------------------- GEMM
+ * C[M,N] = epi( alpha * sum_k A(m,k) B(k,n) )
+ * Replaces nn.Linear forward/backward at modules/attention/attention.py:52,79
+ * (in_proj/out_proj), modules/transformer/layers.py:82 (FFN linear1/2 with
+ * GELU, modules/activations.py:11), :151-154 (stack input projection) and
+ * modules/linear/layers.py:192-193 (Linear heads, +ReLU), :87-109 (Gaussian
+ * head mean/logstd projections).
+ *   a_tr = 0: A stored [M][lda] (k contiguous);  a_tr = 1: A stored [K][lda] (m contiguous)
+ *   b_tr = 0: B stored [N][ldb] (k contiguous);  b_tr = 1: B stored [K][ldb] (n contiguous)
+ * Epilogue order: +bias[n] -> (aux_out = value) -> act -> *dact'(aux_in) ->
+ * +residual -> row mask (zero rows t >= lengths[b]) -> store.
+ * split_k > 1: fp32 C must be pre-zeroed; partial sums are added atomically
+ * and the epilogue is skipped (used for weight gradients only).
+ */
+typedef struct vg_gemm_desc {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int a_tr, b_tr;
+  int dtype;            /* storage type of A, B, residual, aux_*, and of C unless out_f32 */
+  const float* bias;    /* [N] fp32 or NULL */
+  const void* residual; /* [M][ldc] or NULL */
+  const void* aux_in;   /* [M][ldc] input of the activation derivative (dact) */
+  void* aux_out;        /* [M][ldc] receives the pre-activation value or NULL */
+  const int32_t* lengths;
+  int T;
+  int act, dact;
+  int out_f32;
+  int accumulate;       /* C += (fp32 C, split_k == 1) */
+  int split_k;
+  float alpha;
+} vg_gemm_desc;
+int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
+
+/* ---------------------------------------------------------------- RMSNorm
+ * modules/norm.py:28-32 fused with the re-mask of
+ * modules/transformer/layers.py:52-54:  y = mask ? scale * x * rsqrt(mean(x^2)+eps) : 0
+ * x, y: [M][C] (dtype); scale: fp32 [C]; rstd: fp32 [M] (saved for backward).
+ */
+int vg_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, int M, int C, float eps,
+                   const int32_t* lengths, int T, int dtype, vg_stream_t stream);
+/* dx = (dx_add ? dx_add : 0) + d(rmsnorm)/dx . dy ; dscale_partial: fp32 [nblocks][C]
+ * (nblocks = vg_rmsnorm_bwd_blocks(M)); reduce with vg_colsum_f32. */
+int vg_rmsnorm_bwd_blocks(int M);
+int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rstd, const void* dx_add,
+                   void* dx, float* dscale_partial, int M, int C, const int32_t* lengths, int T, int dtype,
+                   vg_stream_t stream);
+
+/* ---------------------------------------------------------------- attention
+ * Causal multi-head self-attention with in-kernel ALiBi, replacing the mask
+ * materialisation + F.scaled_dot_product_attention at
+ * modules/attention/attention.py:60-77 and modules/position/alibi.py:9-33.
+ * qkv: [B*T][3*H*64] = in_proj output (q | k | v, head h = columns 64h..64h+63,
+ * attention.py:12-18,52); out: [B*T][H*64] (heads merged, :78); rows
+ * t >= lengths[b] of `out` are written as zeros.  head_dim must be 64.
+ * slopes: fp32 [H] (positive; bias = -slope * (i - j)).  lse: fp32 [B][H][T].
+ */
+int vg_attn_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int T, int H,
+                const int32_t* lengths, int dtype, vg_stream_t stream);
+/* dqkv: [B*T][3*H*64]; delta: fp32 workspace [B][H][T]. */
+int vg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
+                void* dqkv, float* delta, int B, int T, int H, const int32_t* lengths, int dtype,
+                vg_stream_t stream);
+/* Single-query decode step against a pre-allocated KV cache (attention.py:56-73
+ * with past_kv).  q: [B][H*64]; kcache/vcache: [B][Tmax][H*64]; pos[b] = number
+ * of valid cache rows INCLUDING the current one; out: [B][H*64]. */
+int vg_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const float* slopes,
+                   const int32_t* pos, int B, int Tmax, int H, int dtype, vg_stream_t stream);
+
+/* ---------------------------------------------------------------- token cross-entropy
+ * training_lib/losses.py:30-41 (masked_ce_loss, reduction="sum", ignore -100).
+ * logits: [M][V] (dtype); targets: int64 [M]; loss_rows: fp32 [M] (0 on padded rows);
+ * lse: fp32 [M]; argmax: int32 [M].  bwd: dlogits = gscale * (softmax - onehot), 0 on padded rows.
+ */
+int vg_ce_fwd(const void* logits, const int64_t* targets, float* loss_rows, float* lse, int32_t* argmax, int M,
+              int V, int64_t ld, const int32_t* lengths, int T, int dtype, vg_stream_t stream);
+int vg_ce_bwd(const void* logits, const int64_t* targets, const float* lse, const float* gscale /*device scalar*/,
+              void* dlogits, int M, int V, int64_t ld, const int32_t* lengths, int T, int dtype,
+              vg_stream_t stream);
+
+/* ---------------------------------------------------------------- VAE terms
+ * Posterior reparameterisation (modules/linear/layers.py:110-128,
+ * models/speech/lvtr.py:157-160):
+ *   z = mask ? mu + eps * exp(logstd) * temperature : 0 ; log_q = mask ? -logstd - 0.5 - 0.5 ln 2pi : 0
+ * mu/logstd/eps/z/log_q: fp32 [M][D].
+ */
+int vg_reparam_fwd(const float* mu, const float* logstd, const float* eps, float* z, float* log_q, int M, int D,
+                   float temperature, const int32_t* lengths, int T, vg_stream_t stream);
+int vg_reparam_bwd(const float* dz, const float* dlog_q, const float* logstd, const float* eps, float* dmu,
+                   float* dlogstd, int M, int D, float temperature, const int32_t* lengths, int T,
+                   vg_stream_t stream);
+/* Prior log-density under the flow (models/speech/lvtr.py:182-191):
+ *   log_p[m,d] = mask ? logdet_sum[m]/D - ls - 0.5 ln 2pi - 0.5 exp(-2 ls) (u - mu)^2 : 0
+ * and the KL reduction (training_lib/losses.py:16-18,27 via trainers/speech/lvtr.py:122-124):
+ *   kl_rows[m] = mean_d(log_q - log_p)  (0 on padded rows)
+ * mu_ls: [M][ld_mu_ls] fp32 with mu in columns 0..D-1 and logstd in D..2D-1 (fused prior head). */
+int vg_prior_logp_fwd(const float* mu_ls, int64_t ld_mu_ls, const float* u, const float* logdet_sum,
+                      const float* log_q, float* log_p, float* kl_rows, int M, int D, const int32_t* lengths,
+                      int T, vg_stream_t stream);
+/* Backward of the pair (log_p, kl_rows): total dlog_p = dlog_p (may be NULL) - dkl_rows/D;
+ * outputs d(mu_ls) [M][2D], du [M][D], dlogdet_sum [M], dlog_q [M][D] (= +dkl_rows/D, may be NULL). */
+int vg_prior_logp_bwd(const float* dlog_p, const float* dkl_rows, const float* mu_ls, int64_t ld_mu_ls,
+                      const float* u, float* dmu_ls, float* du, float* dlogdet_sum, float* dlog_q, int M, int D,
+                      const int32_t* lengths, int T, vg_stream_t stream);
+
+/* ---------------------------------------------------------------- reductions / casts
+ * deterministic fp32 sum of n values -> out[0] (single block tree) */
+int vg_sum_f32(const float* x, int64_t n, float* out, vg_stream_t stream);
+/* column sums of a [M][N] matrix (dtype) -> fp32 [N]; bias gradients and the
+ * second stage of the RMSNorm scale gradient.  ws: fp32 [vg_colsum_blocks(M)][N]. */
+int vg_colsum_blocks(int M);
+int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, int dtype, vg_stream_t stream);
+/* dx = dy * act'(aux): ReLU takes aux = activation output, GELU (erf) takes aux = pre-activation
+ * (modules/activations.py:5-18 backward, for Linear+activation heads with several consumers). */
+int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, vg_stream_t stream);
+/* fp32 -> bf16 copy (weights shadow) */
+int vg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAEGSLM_HIP_H */

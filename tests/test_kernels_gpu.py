@@ -1,0 +1,285 @@
+"""Kernel-level parity tests (need an MI355X): every HIP kernel, forward and
+backward, fp32 (exact-f32 MFMA) and bf16, against plain torch math evaluated
+in fp64/fp32 on the same inputs.  Shapes include ragged lengths, sizes that are
+not tile multiples, and T = 1."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import hipvg
+    hipvg.lib()
+    from hipvg import functional
+    return functional
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dev()).to(dtype)
+
+
+def tol(dtype):
+    return dict(atol=2e-5, rtol=2e-5) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
+
+
+def lengths_for(B, T):
+    ls = [T] + [max(1, T - 37 * (i + 1)) for i in range(B - 1)]
+    return torch.tensor(ls[:B], dtype=torch.int32, device=dev())
+
+
+def row_mask(lengths, T):
+    return (torch.arange(T, device=dev())[None] < lengths[:, None]).reshape(-1)
+
+
+# ------------------------------------------------------------------ MFMA operand maps (exact integers)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm_exact_small_integers(F, dtype, mode):
+    """Asymmetric small-integer operands: any row/col or k-permutation error in
+    the fragment maps changes the (exactly representable) result."""
+    M, N, K = 200, 136, 192
+    g = torch.Generator().manual_seed(5)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    ref = A @ B.T
+    Ad, Bd = A.to(dev()).to(dtype), B.to(dev()).to(dtype)
+    if mode == "nt":
+        out = F.gemm(Ad, Bd, M, N, K)
+    elif mode == "nn":
+        out = F.gemm(Ad, Bd.T.contiguous(), M, N, K, b_tr=True)
+    else:
+        out = F.gemm(Ad.T.contiguous(), Bd.T.contiguous(), M, N, K, a_tr=True, b_tr=True, out_f32=True)
+    assert torch.equal(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(F, dtype):
+    B_, T = 2, 100
+    M, N, K = B_ * T, 320, 256
+    x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=K ** -0.5)
+    bias = rnd(N, scale=0.1)
+    res = rnd(M, N, dtype=dtype)
+    lens = lengths_for(B_, T)
+    mask = row_mask(lens, T)[:, None]
+    u_ref = x.double() @ w.double().T + bias.double()
+    aux = torch.empty(M, N, dtype=dtype, device=dev())
+    y = F.gemm(x, w, M, N, K, bias=bias, act=2, aux_out=aux, residual=res, lengths=lens, T=T)
+    ref = torch.where(mask, torch.nn.functional.gelu(u_ref) + res.double(), 0.0)
+    torch.testing.assert_close(y.double(), ref, **tol(dtype))
+    torch.testing.assert_close(aux.double(), u_ref, **tol(dtype))
+    # relu + fp32 output
+    y = F.gemm(x, w, M, N, K, bias=bias, act=1, out_f32=True)
+    assert y.dtype == torch.float32
+    torch.testing.assert_close(y.double(), torch.relu(u_ref), **tol(dtype))
+    # dgrad with fused GELU derivative
+    dy = rnd(M, N, dtype=dtype, seed=3)
+    wide = rnd(M, K, dtype=dtype, seed=4)     # plays the role of the pre-activation
+    dx = F.gemm(dy, w, M, K, N, b_tr=True, dact=2, aux_in=wide, lengths=lens, T=T)
+    a = wide.double()
+    gp = 0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+    ref = torch.where(mask, (dy.double() @ w.double()) * gp, 0.0)
+    torch.testing.assert_close(dx.double(), ref, **tol(dtype))
+    # wgrad, split-K (atomic) and single pass agree with the reference
+    for s in (1, 3):
+        dW = F.gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=s)
+        torch.testing.assert_close(dW.double(), dy.double().T @ x.double(),
+                                   atol=1e-4 if dtype == torch.float32 else 5e-2, rtol=1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_and_ffn_autograd(F, dtype):
+    B_, T, D, Fd = 2, 75, 256, 512
+    M = B_ * T
+    lens = lengths_for(B_, T)
+    mask = row_mask(lens, T)[:, None]
+    x = rnd(M, D, dtype=dtype).requires_grad_(True)
+    w1, b1 = rnd(Fd, D, scale=D ** -0.5).requires_grad_(True), rnd(Fd, scale=0.1).requires_grad_(True)
+    w2, b2 = rnd(D, Fd, scale=Fd ** -0.5).requires_grad_(True), rnd(D, scale=0.1).requires_grad_(True)
+    res = rnd(M, D, dtype=dtype, seed=9).requires_grad_(True)
+    y = F.ffn(x, w1, b1, w2, b2, residual=res, lengths=lens, T=T)
+    gy = torch.where(mask, rnd(M, D, seed=11), 0.0)
+    (y.float() * gy).sum().backward()
+    got = [t.grad.clone() for t in (x, w1, b1, w2, b2, res)]
+    xs = [t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2, res)]
+    x_, w1_, b1_, w2_, b2_, r_ = xs
+    if dtype == torch.bfloat16:   # the kernel consumes bf16-rounded weights
+        w1q, w2q = w1_.float().bfloat16().double(), w2_.float().bfloat16().double()
+        w1q, w2q = w1_ + (w1q - w1_).detach(), w2_ + (w2q - w2_).detach()
+    else:
+        w1q, w2q = w1_, w2_
+    h = torch.nn.functional.gelu(x_ @ w1q.T + b1_)
+    yr = torch.where(mask, r_ + h @ w2q.T + b2_, 0.0)
+    (yr * gy.double()).sum().backward()
+    torch.testing.assert_close(y.double(), yr.detach(), **tol(dtype))
+    for a, b, name in zip(got, xs, "x w1 b1 w2 b2 res".split()):
+        t = tol(dtype) if dtype == torch.float32 else dict(atol=0.15, rtol=5e-2)
+        if dtype == torch.float32:
+            t = dict(atol=2e-4, rtol=1e-4)
+        torch.testing.assert_close(a.double(), b.grad, msg=lambda m: f"{name}: {m}", **t)
+    # Linear + ReLU head with fp32 output
+    xx = rnd(M, D, dtype=dtype, seed=21).requires_grad_(True)
+    y = F.linear(xx, w1, b1, act="relu", out_f32=True)
+    y.sum().backward()
+    ref = torch.relu(xx.detach().double() @ w1.detach().double().T + b1.detach().double())
+    torch.testing.assert_close(y.double(), ref, **tol(dtype))
+
+
+# ------------------------------------------------------------------ RMSNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [256, 1024])
+def test_rmsnorm(F, dtype, C):
+    B_, T = 3, 67
+    M = B_ * T
+    lens = lengths_for(B_, T)
+    mask = row_mask(lens, T)[:, None]
+    x = rnd(M, C, dtype=dtype).requires_grad_(True)
+    sc = (1 + 0.1 * rnd(C)).requires_grad_(True)
+    y = F.rmsnorm(x, sc, 1e-6, lengths=lens, T=T)
+    gy = rnd(M, C, seed=2)
+    (y.float() * gy).sum().backward()
+    xr = x.detach().double().requires_grad_(True)
+    sr = sc.detach().double().requires_grad_(True)
+    yr = torch.where(mask, sr * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6), 0.0)
+    (yr * gy.double()).sum().backward()
+    torch.testing.assert_close(y.double(), yr.detach(), **tol(dtype))
+    t = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=5e-2)
+    torch.testing.assert_close(x.grad.double(), xr.grad, **t)
+    torch.testing.assert_close(sc.grad.double(), sr.grad, atol=1e-3 if dtype == torch.float32 else 0.5, rtol=2e-2)
+
+
+# ------------------------------------------------------------------ attention
+def attn_reference(qkv, B, T, H, lengths, slopes):
+    D = H * 64
+    q, k, v = qkv.double().reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    pos = torch.arange(T, device=qkv.device)
+    rel = (pos[:, None] - pos[None, :]).double()
+    bias = -slopes.double()[:, None, None] * rel.abs()
+    s = q @ k.transpose(-1, -2) / 8.0 + bias[None]
+    s = s.masked_fill(pos[None, :] > pos[:, None], float("-inf"))
+    o = torch.softmax(s, -1) @ v
+    o = o.permute(0, 2, 1, 3).reshape(B * T, D)
+    return torch.where(row_mask(lengths, T)[:, None], o, 0.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 200, 4), (1, 1, 4), (2, 130, 16), (1, 333, 12)])
+def test_attention_fwd_bwd(F, dtype, shape):
+    B_, T, H = shape
+    D = H * 64
+    lens = lengths_for(B_, T)
+    slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
+    qkv = rnd(B_ * T, 3 * D, dtype=dtype, seed=T).requires_grad_(True)
+    out = F.attention(qkv, slopes, B_, T, H, lens)
+    mask = row_mask(lens, T)[:, None]
+    go = torch.where(mask, rnd(B_ * T, D, seed=3), 0.0)
+    (out.float() * go).sum().backward()
+    qr = qkv.detach().double().requires_grad_(True)
+    ref = attn_reference(qr, B_, T, H, lens, slopes)
+    (ref * go.double()).sum().backward()
+    torch.testing.assert_close(out.double(), ref.detach(), **tol(dtype))
+    # reference grads on padded rows are exactly zero by the masking invariants
+    t = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=5e-2)
+    torch.testing.assert_close(qkv.grad.double(), qr.grad, **t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_softmax_rescale_branch(F, dtype):
+    """Force the running max to jump late in the sequence (spiked key) so the
+    online-softmax rescale path is exercised against a full fp64 reference."""
+    B_, T, H = 1, 256, 4
+    D = H * 64
+    slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
+    qkv = rnd(B_ * T, 3 * D, dtype=dtype, scale=0.5)
+    with torch.no_grad():
+        qkv[200, D:D + 64] = 6.0          # key 200 of head 0 spikes
+        qkv[201:, 0:64] = 1.5             # later queries align with it
+    out = F.attention(qkv, slopes, B_, T, H, None)
+    ref = attn_reference(qkv, B_, T, H, torch.tensor([T], device=dev()), slopes)
+    torch.testing.assert_close(out.double(), ref, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_decode(F, dtype):
+    B_, H, Tmax = 3, 4, 50
+    D = H * 64
+    slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
+    q, kc, vc = rnd(B_, D, dtype=dtype), rnd(B_, Tmax, D, dtype=dtype, seed=1), rnd(B_, Tmax, D, dtype=dtype, seed=2)
+    pos = torch.tensor([50, 17, 1], dtype=torch.int32, device=dev())
+    out = F.attention_decode(q, kc, vc, slopes, pos, H)
+    for b in range(B_):
+        n = int(pos[b])
+        qq = q[b].double().reshape(H, 1, 64)
+        kk = kc[b, :n].double().reshape(n, H, 64).permute(1, 0, 2)
+        vv = vc[b, :n].double().reshape(n, H, 64).permute(1, 0, 2)
+        dist = (n - 1 - torch.arange(n, device=dev())).double()
+        s = qq @ kk.transpose(-1, -2) / 8.0 - slopes.double()[:, None, None] * dist
+        ref = (torch.softmax(s, -1) @ vv).reshape(D)
+        torch.testing.assert_close(out[b].double(), ref, **tol(dtype))
+
+
+# ------------------------------------------------------------------ losses / VAE terms
+def test_cross_entropy(F):
+    B_, T, V = 2, 90, 200
+    M = B_ * T
+    lens = lengths_for(B_, T)
+    mask = row_mask(lens, T)
+    logits = rnd(M, V, scale=3.0).requires_grad_(True)
+    tgt = torch.randint(0, V, (M,), device=dev())
+    loss, amax = F.cross_entropy_sum(logits, tgt, lens, T)
+    (loss * 0.37).backward()
+    lr = logits.detach().double().requires_grad_(True)
+    tr = torch.where(mask, tgt, torch.full_like(tgt, -100))
+    ref = torch.nn.functional.cross_entropy(lr, tr, reduction="sum", ignore_index=-100)
+    (ref * 0.37).backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-6
+    torch.testing.assert_close(logits.grad.double(), lr.grad, atol=1e-6, rtol=1e-5)
+    assert torch.equal(amax.long(), logits.detach().argmax(-1))
+
+
+def test_vae_terms(F):
+    B_, T, Dl = 2, 77, 4
+    M = B_ * T
+    lens = lengths_for(B_, T)
+    mask = row_mask(lens, T)[:, None]
+    mu, ls, eps = (rnd(M, Dl, seed=s).requires_grad_(s < 2) for s in range(3))
+    z, lq = F.reparameterize(mu, ls, eps, 0.85, lens, T)
+    mu_ls = rnd(M, 2 * Dl, seed=5).requires_grad_(True)
+    u = rnd(M, Dl, seed=6).requires_grad_(True)
+    ldet = rnd(M, seed=7).requires_grad_(True)
+    log_p, kl = F.prior_logp_kl(mu_ls, u, ldet, lq, lens, T)
+    w = rnd(M, Dl, seed=8)
+    (kl * 0.04 + (z * w).sum() + (log_p * w).sum() * 0.1).backward()
+    got = [t.grad.clone() for t in (mu, ls, mu_ls, u, ldet)]
+    d = [t.detach().double().requires_grad_(True) for t in (mu, ls, mu_ls, u, ldet)]
+    mu_, ls_, ml_, u_, ld_ = d
+    c = 0.5 * math.log(2 * math.pi)
+    zr = torch.where(mask, mu_ + eps.double() * torch.exp(ls_) * 0.85, 0.0)
+    lqr = torch.where(mask, -ls_ - 0.5 - c, 0.0)
+    mp, lp_ = ml_[:, :Dl], ml_[:, Dl:]
+    lpr = ld_[:, None] / Dl - lp_ - c - 0.5 * torch.exp(-2 * lp_) * (u_ - mp) ** 2
+    lpr = torch.where(mask, lpr, 0.0)
+    klr = (lqr - lpr).mean(-1).sum()
+    (klr * 0.04 + (zr * w.double()).sum() + (lpr * w.double()).sum() * 0.1).backward()
+    torch.testing.assert_close(z.double(), zr.detach(), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(log_p.double(), lpr.detach(), atol=1e-5, rtol=1e-5)
+    assert abs(kl.item() - klr.item()) / abs(klr.item()) < 1e-5
+    for a, b in zip(got, d):
+        torch.testing.assert_close(a.double(), b.grad, atol=1e-5, rtol=1e-4)
+
+
+def test_small_reductions(F):
+    x = rnd(1000, 200, dtype=torch.bfloat16)
+    torch.testing.assert_close(F.colsum(x).double(), x.double().sum(0), atol=1e-2, rtol=1e-3)
+    y = rnd(12345)
+    assert abs(F.sum_f32(y).item() - y.double().sum().item()) < 1e-2
+    w = rnd(333, 77)
+    torch.testing.assert_close(F.shadow(torch.nn.Parameter(w), torch.bfloat16).float(), w.bfloat16().float())

@@ -1,0 +1,507 @@
+// Causal multi-head self-attention with in-kernel ALiBi (SURVEY.md K1 + K5),
+// head_dim = 64, for gfx950.  Replaces the (B,H,T,T) mask/bias materialisation
+// and F.scaled_dot_product_attention of modules/attention/attention.py:60-77.
+//
+// Orientation (all three kernels): the time index that softmax statistics
+// belong to sits on the MFMA *lane*, so row max / row sum / rescale are
+// lane-local (one cross-half shuffle) and the probability tile in the
+// accumulator registers is directly the B operand of the next product
+// (no LDS round trip for P):
+//   forward / dQ : S^T[key][query] = K Q^T ; O^T[d][query] = V^T P^T ; dQ^T = K^T dS^T
+//   dK/dV        : S[query][key]   = Q K^T ; dV^T[d][key] = dO^T P   ; dK^T = Q^T dS
+// K/V (or Q/dO) tiles are staged once per block through LDS in two images:
+// a K-contiguous RowTile (operand of the score products) and a TrTile read
+// with ds_read_b64_tr_b16 (operand of the products that sum over time).
+// Scores live in the log2 domain: s2 = (q.k / 8 - slope (i - j)) * log2(e).
+#include "vg_common.h"
+#include "../../include/vaegslm_hip.h"
+
+using namespace vg;
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int QB = 128;      // time rows owned by a block (4 waves x 32)
+constexpr int TB = 64;       // time rows staged per LDS tile
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float LN2 = 0.69314718055994530942f;
+constexpr float SCALE = 0.125f;   // 1 / sqrt(64)
+
+template <typename T> struct NVec { static constexpr int v = TB * DH / Traits<T>::VEC / 256; };  // 2 bf16 / 4 f32
+
+// ---- stage a [64 time][64 d] slab (one head) global -> registers -> LDS images
+template <typename T>
+VG_DEVICE void slab_load(uint4 (&r)[NVec<T>::v], const T* __restrict__ base, long row_stride, int t0, int t_lim,
+                         int tid) {
+  constexpr int VEC = Traits<T>::VEC, CPR = DH / VEC;
+#pragma unroll
+  for (int it = 0; it < NVec<T>::v; ++it) {
+    const int v = tid + 256 * it;
+    const int row = v / CPR, c16 = v % CPR;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (t0 + row < t_lim) val = *reinterpret_cast<const uint4*>(base + (long)(t0 + row) * row_stride + c16 * VEC);
+    r[it] = val;
+  }
+}
+template <typename T, bool ROW, bool TR>
+VG_DEVICE void slab_store(const uint4 (&r)[NVec<T>::v], char* row_img, char* tr_img, int tid) {
+  constexpr int VEC = Traits<T>::VEC, CPR = DH / VEC;
+#pragma unroll
+  for (int it = 0; it < NVec<T>::v; ++it) {
+    const int v = tid + 256 * it;
+    const int row = v / CPR, c16 = v % CPR;
+    if constexpr (ROW) RowTile<T, DH>::store_vec(row_img, row, c16, r[it]);
+    if constexpr (TR) TrTile<T, DH>::store_vec(tr_img, row, c16, r[it]);
+  }
+}
+
+// ---- per-lane operand fragments of one time row held in registers (B operand, k = d)
+template <typename T> struct RowRegs;
+template <> struct RowRegs<bf16_t> {
+  bf16x8 f[4];
+  VG_DEVICE void load(const bf16_t* __restrict__ row, int lane) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const bf16x8*>(row + 16 * s + 8 * (lane >> 5));
+  }
+};
+template <> struct RowRegs<float> {
+  float f[32];
+  VG_DEVICE void load(const float* __restrict__ row, int lane) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) f[s] = row[2 * s + (lane >> 5)];
+  }
+};
+
+template <typename T>
+VG_DEVICE f32x16 mma_row_regs(const char* row_img, int row, const RowRegs<T>& b, int lane, f32x16 acc) {
+  constexpr int STEPS = DH / Traits<T>::KSTEP;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc = Traits<T>::mfma(RowTile<T, DH>::frag(row_img, row, s, lane), b.f[s], acc);
+  return acc;
+}
+
+// acc[d-block db] += (tr image)^T[d][time k0..k0+31] . X[time][lane]
+template <typename T>
+VG_DEVICE f32x16 mma_tr_acc(const char* tr_img, int k0, int db, const f32x16& x, int lane, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < AccOperand<T>::STEPS; ++s)
+    acc = Traits<T>::mfma(TrTile<T, DH>::template frag<true>(tr_img, k0, db * 32, s, lane), AccOperand<T>::get(x, s),
+                          acc);
+  return acc;
+}
+
+// store a transposed accumulator pair O^T[2][d][time = lane] as rows [time][64 d] scaled by `mul`
+template <typename T>
+VG_DEVICE void store_rows_T(T* __restrict__ dst_row, const f32x16 (&o)[2], float mul, int lane) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = db * 32 + 8 * g + 4 * (lane >> 5);
+      if constexpr (sizeof(T) == 2) {
+        bf16x4 v = {(bf16_t)(o[db][4 * g] * mul), (bf16_t)(o[db][4 * g + 1] * mul), (bf16_t)(o[db][4 * g + 2] * mul),
+                    (bf16_t)(o[db][4 * g + 3] * mul)};
+        *reinterpret_cast<bf16x4*>(dst_row + d0) = v;
+      } else {
+        f32x4 v = {o[db][4 * g] * mul, o[db][4 * g + 1] * mul, o[db][4 * g + 2] * mul, o[db][4 * g + 3] * mul};
+        *reinterpret_cast<f32x4*>(dst_row + d0) = v;
+      }
+    }
+}
+
+VG_DEVICE float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+VG_DEVICE float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+template <typename T> struct LdsPlan {
+  static constexpr int ROW_BYTES = sizeof(T) == 2 ? TB * 128 : TB * (DH + 1) * 4;
+  static constexpr int TR_BYTES = sizeof(T) == 2 ? TB * 128 : TB * DH * 4;
+};
+
+// =====================================================================================
+// forward
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                       float* __restrict__ lse, const float* __restrict__ slopes,
+                                                       int Tn, int H, const int* __restrict__ lengths) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_row = smem;
+  char* v_tr = smem + LdsPlan<T>::ROW_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * DH;
+  const long rs = 3L * D;
+  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int q0 = qt * QB;
+  const int qw0 = q0 + wave * 32;
+  const int query = qw0 + (lane & 31);
+  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
+  T* __restrict__ obase = out + (long)b * Tn * D + h * DH;
+
+  if (q0 >= len) {   // fully padded tile: zero rows (attention.py:80 re-mask)
+    f32x16 z[2] = {zero16(), zero16()};
+    if (query < Tn) store_rows_T<T>(obase + (long)query * D, z, 0.f, lane);
+    return;
+  }
+  const int qend = min(q0 + QB, len);
+  const int nkt = (qend + TB - 1) / TB;
+
+  RowRegs<T> qf;
+  qf.load(base + (long)min(query, Tn - 1) * rs, lane);
+  const float slope2 = slopes[h] * LOG2E;
+  const float c2 = SCALE * LOG2E;
+
+  f32x16 o[2] = {zero16(), zero16()};
+  float m = -INFINITY, l = 0.f;
+
+  uint4 rk[NVec<T>::v], rv[NVec<T>::v];
+  slab_load<T>(rk, base + D, rs, 0, Tn, tid);
+  slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int kv0 = kt * TB;
+    __syncthreads();
+    slab_store<T, true, false>(rk, k_row, nullptr, tid);
+    slab_store<T, false, true>(rv, nullptr, v_tr, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
+      slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+    }
+    if (qw0 + 31 < kv0) continue;   // this wave's queries all precede the tile (causal)
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) s[kb] = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, zero16());
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kv0 + kb * 32 + acc_row(i, lane);
+        float v = s[kb][i] * c2 - slope2 * (float)(query - key);
+        v = key <= query ? v : -INFINITY;
+        s[kb][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f(m - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = exp2f(s[kb][i] - m_new);
+        s[kb][i] = p;
+        ps += p;
+      }
+    l = l * alpha + xhalf_sum(ps);
+    m = m_new;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) o[db] = mma_tr_acc<T>(v_tr, kb * 32, db, s[kb], lane, o[db]);
+    }
+  }
+  if (query < Tn) {
+    const bool valid = query < len;
+    store_rows_T<T>(obase + (long)query * D, o, valid ? 1.f / l : 0.f, lane);
+    if (valid && lane < 32) lse[((long)b * H + h) * Tn + query] = (m + log2f(l)) * LN2;
+  }
+}
+
+// =====================================================================================
+// backward: delta = rowsum(dO * O) per (b, h, t)
+// =====================================================================================
+template <typename T>
+__global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta,
+                                  int B, int Tn, int H) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid & 7;
+  const long mh = gid >> 3;
+  const int h = mh % H;
+  const long m = mh / H;
+  float acc = 0.f;
+  if (m < (long)B * Tn) {
+    const long off = m * (long)H * DH + h * DH + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += to_f32<T>(o[off + e]) * to_f32<T>(dout[off + e]);
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if (c == 0 && m < (long)B * Tn) {
+    const int b = m / Tn, t = m % Tn;
+    delta[((long)b * H + h) * Tn + t] = acc;
+  }
+}
+
+// =====================================================================================
+// backward: dQ  (block owns 128 queries, sweeps key tiles; no atomics)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ delta,
+                                                          const float* __restrict__ slopes, T* __restrict__ dqkv,
+                                                          int Tn, int H, const int* __restrict__ lengths) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_row = smem;
+  char* v_row = smem + LdsPlan<T>::ROW_BYTES;
+  char* k_tr = smem + 2 * LdsPlan<T>::ROW_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * DH;
+  const long rs = 3L * D;
+  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int q0 = qt * QB, qw0 = q0 + wave * 32, query = qw0 + (lane & 31);
+  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
+  T* __restrict__ dqbase = dqkv + (long)b * Tn * rs + h * DH;
+  if (q0 >= len) {
+    f32x16 z[2] = {zero16(), zero16()};
+    if (query < Tn) store_rows_T<T>(dqbase + (long)query * rs, z, 0.f, lane);
+    return;
+  }
+  const int qend = min(q0 + QB, len);
+  const int nkt = (qend + TB - 1) / TB;
+  const bool qvalid = query < len;
+  const int qc = min(query, Tn - 1);
+  RowRegs<T> qf, dof;
+  qf.load(base + (long)qc * rs, lane);
+  dof.load(dout + ((long)b * Tn + qc) * D + h * DH, lane);
+  const float lse2 = qvalid ? lse[((long)b * H + h) * Tn + query] * LOG2E : 0.f;
+  const float dl = qvalid ? delta[((long)b * H + h) * Tn + query] : 0.f;
+  const float slope2 = slopes[h] * LOG2E, c2 = SCALE * LOG2E;
+
+  f32x16 dq[2] = {zero16(), zero16()};
+  uint4 rk[NVec<T>::v], rv[NVec<T>::v];
+  slab_load<T>(rk, base + D, rs, 0, Tn, tid);
+  slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int kv0 = kt * TB;
+    __syncthreads();
+    slab_store<T, true, true>(rk, k_row, k_tr, tid);
+    slab_store<T, true, false>(rv, v_row, nullptr, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
+      slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+    }
+    if (qw0 + 31 < kv0) continue;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, zero16());
+      f32x16 dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, zero16());
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kv0 + kb * 32 + acc_row(i, lane);
+        const float p = (key <= query && qvalid) ? exp2f(s[i] * c2 - slope2 * (float)(query - key) - lse2) : 0.f;
+        s[i] = p * (dp[i] - dl) * SCALE;
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dq[db] = mma_tr_acc<T>(k_tr, kb * 32, db, s, lane, dq[db]);
+    }
+  }
+  if (query < Tn) store_rows_T<T>(dqbase + (long)query * rs, dq, 1.f, lane);
+}
+
+// =====================================================================================
+// backward: dK, dV (block owns 128 keys, sweeps query tiles; no atomics)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                           const float* __restrict__ lse,
+                                                           const float* __restrict__ delta,
+                                                           const float* __restrict__ slopes, T* __restrict__ dqkv,
+                                                           int Tn, int H, const int* __restrict__ lengths) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* q_row = smem;
+  char* do_row = smem + LdsPlan<T>::ROW_BYTES;
+  char* q_tr = smem + 2 * LdsPlan<T>::ROW_BYTES;
+  char* do_tr = q_tr + LdsPlan<T>::TR_BYTES;
+  float* st = reinterpret_cast<float*>(do_tr + LdsPlan<T>::TR_BYTES);   // [2][64]: lse2, delta
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ktile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * DH;
+  const long rs = 3L * D;
+  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int k0 = ktile * QB, kw0 = k0 + wave * 32, key = kw0 + (lane & 31);
+  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
+  const T* __restrict__ dobase = dout + (long)b * Tn * D + h * DH;
+  T* __restrict__ dkbase = dqkv + (long)b * Tn * rs + D + h * DH;
+  T* __restrict__ dvbase = dqkv + (long)b * Tn * rs + 2 * D + h * DH;
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+  if (k0 >= len) {
+    if (key < Tn) {
+      store_rows_T<T>(dkbase + (long)key * rs, dk, 0.f, lane);
+      store_rows_T<T>(dvbase + (long)key * rs, dv, 0.f, lane);
+    }
+    return;
+  }
+  const int kc = min(key, Tn - 1);
+  RowRegs<T> kf, vf;
+  kf.load(base + D + (long)kc * rs, lane);
+  vf.load(base + 2 * D + (long)kc * rs, lane);
+  const float slope2 = slopes[h] * LOG2E, c2 = SCALE * LOG2E;
+  const float* __restrict__ lse_bh = lse + ((long)b * H + h) * Tn;
+  const float* __restrict__ dl_bh = delta + ((long)b * H + h) * Tn;
+
+  const int qt_beg = k0 / TB, qt_end = (len + TB - 1) / TB;
+  uint4 rq[NVec<T>::v], rd[NVec<T>::v];
+  slab_load<T>(rq, base, rs, qt_beg * TB, Tn, tid);
+  slab_load<T>(rd, dobase, D, qt_beg * TB, Tn, tid);
+  for (int qt = qt_beg; qt < qt_end; ++qt) {
+    const int qs0 = qt * TB;
+    __syncthreads();
+    slab_store<T, true, true>(rq, q_row, q_tr, tid);
+    slab_store<T, true, true>(rd, do_row, do_tr, tid);
+    if (tid < 64) {
+      const int qq = qs0 + tid;
+      const bool ok = qq < len;
+      st[tid] = ok ? lse_bh[qq] * LOG2E : 0.f;
+      st[64 + tid] = ok ? dl_bh[qq] : 0.f;
+    }
+    __syncthreads();
+    if (qt + 1 < qt_end) {
+      slab_load<T>(rq, base, rs, qs0 + TB, Tn, tid);
+      slab_load<T>(rd, dobase, D, qs0 + TB, Tn, tid);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if (qs0 + qb * 32 + 31 < kw0) continue;   // all queries precede this wave's keys
+      f32x16 s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, zero16());
+      f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, zero16());
+      f32x16 ds;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ql = qb * 32 + acc_row(i, lane);
+        const int qq = qs0 + ql;
+        const float p = (key <= qq && qq < len) ? exp2f(s[i] * c2 - slope2 * (float)(qq - key) - st[ql]) : 0.f;
+        s[i] = p;
+        ds[i] = p * (dp[i] - st[64 + ql]) * SCALE;
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dv[db] = mma_tr_acc<T>(do_tr, qb * 32, db, s, lane, dv[db]);
+        dk[db] = mma_tr_acc<T>(q_tr, qb * 32, db, ds, lane, dk[db]);
+      }
+    }
+  }
+  if (key < Tn) {
+    store_rows_T<T>(dkbase + (long)key * rs, dk, 1.f, lane);
+    store_rows_T<T>(dvbase + (long)key * rs, dv, 1.f, lane);
+  }
+}
+
+// =====================================================================================
+// decode: one query row per (b, h) against a pre-allocated cache (HBM-bound)
+// one wave per (b, h); lanes stride over cache rows, 64-d dot per lane.
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(64) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                         const T* __restrict__ vc, T* __restrict__ out,
+                                                         const float* __restrict__ slopes,
+                                                         const int* __restrict__ pos, int Tmax, int H) {
+  __shared__ float red[64][DH + 1];
+  const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  const int D = H * DH;
+  const int n = pos[b];
+  float qv[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) qv[d] = to_f32<T>(q[(long)b * D + h * DH + d]);
+  const float slope = slopes[h];
+  float m = -INFINITY, l = 0.f, acc[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const T* kr = kc + ((long)b * Tmax + j) * D + h * DH;
+    const T* vr = vc + ((long)b * Tmax + j) * D + h * DH;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) s += qv[d] * to_f32<T>(kr[d]);
+    s = s * SCALE - slope * (float)(n - 1 - j);
+    const float mn = fmaxf(m, s);
+    const float a = expf(m - mn), p = expf(s - mn);
+    l = l * a + p;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = acc[d] * a + p * to_f32<T>(vr[d]);
+    m = mn;
+  }
+  const float mg = wave_max(m);
+  const float w = (m == -INFINITY) ? 0.f : expf(m - mg);
+  const float lg = wave_sum(l * w);
+#pragma unroll
+  for (int d = 0; d < DH; ++d) red[lane][d] = acc[d] * w;
+  __syncthreads();
+  float o = 0.f;
+  for (int r = 0; r < 64; ++r) o += red[r][lane];
+  out[(long)b * D + h * DH + lane] = from_f32<T>(o / lg);
+}
+
+template <typename T>
+int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tn, int H,
+               const int32_t* lengths, hipStream_t stream) {
+  const size_t lds = LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
+  dim3 grid((Tn + QB - 1) / QB, H, B);
+  hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
+                     lengths);
+  return vg_host::check_launch("vg_attn_fwd");
+}
+
+template <typename T>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
+               void* dqkv, float* delta, int B, int Tn, int H, const int32_t* lengths, hipStream_t stream) {
+  const long nthreads = (long)B * Tn * H * 8;
+  hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
+                     (const T*)out, (const T*)dout, delta, B, Tn, H);
+  dim3 grid((Tn + QB - 1) / QB, H, B);
+  const size_t lds_q = 3 * LdsPlan<T>::ROW_BYTES;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
+                     delta, slopes, (T*)dqkv, Tn, H, lengths);
+  const size_t lds_k = 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float);
+  static bool attr[2] = {false, false};
+  if (!attr[sizeof(T) == 2]) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+    attr[sizeof(T) == 2] = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, dim3(256), lds_k, stream, (const T*)qkv, (const T*)dout, lse,
+                     delta, slopes, (T*)dqkv, Tn, H, lengths);
+  return vg_host::check_launch("vg_attn_bwd");
+}
+
+}  // namespace
+
+extern "C" int vg_attn_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int T, int H,
+                           const int32_t* lengths, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && T > 0 && H > 0, "vg_attn_fwd: empty problem");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_fwd: bad dtype %d", dtype);
+  VG_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "vg_attn_fwd: unaligned");
+  if (dtype == VG_BF16) return launch_fwd<bf16_t>(qkv, out, lse, slopes, B, T, H, lengths, stream);
+  return launch_fwd<float>(qkv, out, lse, slopes, B, T, H, lengths, stream);
+}
+
+extern "C" int vg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                           const float* slopes, void* dqkv, float* delta, int B, int T, int H,
+                           const int32_t* lengths, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && T > 0 && H > 0, "vg_attn_bwd: empty problem");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_bwd: bad dtype %d", dtype);
+  if (dtype == VG_BF16)
+    return launch_bwd<bf16_t>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, stream);
+  return launch_bwd<float>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, stream);
+}
+
+extern "C" int vg_attn_decode(const void* q, const void* kcache, const void* vcache, void* out,
+                              const float* slopes, const int32_t* pos, int B, int Tmax, int H, int dtype,
+                              hipStream_t stream) {
+  VG_REQUIRE(B > 0 && Tmax > 0 && H > 0, "vg_attn_decode: empty problem");
+  dim3 grid(H, B);
+  if (dtype == VG_BF16)
+    hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, grid, dim3(64), 0, stream, (const bf16_t*)q,
+                       (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, slopes, pos, Tmax, H);
+  else
+    hipLaunchKernelGGL(attn_decode_kernel<float>, grid, dim3(64), 0, stream, (const float*)q, (const float*)kcache,
+                       (const float*)vcache, (float*)out, slopes, pos, Tmax, H);
+  return vg_host::check_launch("vg_attn_decode");
+}

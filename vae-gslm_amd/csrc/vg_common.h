@@ -1,0 +1,222 @@
+// Shared device-side building blocks for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Everything here is written for wave64 + the 32x32 MFMA family:
+//   * bf16 : v_mfma_f32_32x32x16_bf16  (8 bf16 per lane per operand, 16-deep k-step)
+//   * f32  : v_mfma_f32_32x32x2_f32    (1 f32 per lane per operand, 2-deep k-step,
+//            bit-exact fmaf chain -> used by the fp32 parity path)
+// Both share ONE accumulator layout (16 f32 registers per lane):
+//     col = lane & 31,  row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5),  i = 0..15
+// so every kernel body (epilogues, online softmax, masking) is written once and
+// templated on the storage type.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define VG_DEVICE __device__ __forceinline__
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+namespace vg {
+
+// ---------------------------------------------------------------- accumulator map
+VG_DEVICE int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+VG_DEVICE int acc_col(int lane) { return lane & 31; }
+
+VG_DEVICE f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// ---------------------------------------------------------------- scalar conversions
+template <typename T> VG_DEVICE float to_f32(T v);
+template <> VG_DEVICE float to_f32<float>(float v) { return v; }
+template <> VG_DEVICE float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> VG_DEVICE T from_f32(float v);
+template <> VG_DEVICE float from_f32<float>(float v) { return v; }
+template <> VG_DEVICE bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---------------------------------------------------------------- per-type traits
+template <typename T> struct Traits;
+
+template <> struct Traits<bf16_t> {
+  typedef bf16x8 Frag;                 // one MFMA operand fragment
+  static constexpr int KSTEP = 16;     // reduction depth of one MFMA
+  static constexpr int VEC = 8;        // elements per 16-byte vector
+  static VG_DEVICE f32x16 mfma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <> struct Traits<float> {
+  typedef float Frag;
+  static constexpr int KSTEP = 2;
+  static constexpr int VEC = 4;
+  static VG_DEVICE f32x16 mfma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// ---------------------------------------------------------------- LDS tile images
+//
+// RowTile<T, KD>: a [rows][KD] tile whose reduction index k is contiguous
+// ("K-contiguous": activations [M][K], nn.Linear weights [N][K], K/Q/V rows
+// [t][d]).  An MFMA operand fragment is 8 consecutive k (bf16) / one k (f32)
+// of one row.
+//   bf16: KD must be 64 -> 128-byte rows; the 16-byte chunk index is XORed
+//         with (row >> 1) & 7 so each ds_read_b128 lane group touches 16
+//         distinct 16-byte slots of the 256-byte bank row (conflict-free).
+//   f32 : pitch KD + 1 floats (odd pitch -> conflict-free ds_read_b32 column reads).
+template <typename T, int KD> struct RowTile;
+
+template <int KD> struct RowTile<bf16_t, KD> {
+  static_assert(KD == 64, "bf16 RowTile is specialised for 128-byte rows");
+  static VG_DEVICE int bytes(int rows) { return rows * 128; }
+  // byte offset of 16-byte chunk c16 (0..7) of `row`
+  static VG_DEVICE int chunk_off(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
+  // store 8 elements (one 16-byte vector) fetched from global
+  static VG_DEVICE void store_vec(char* base, int row, int c16, uint4 v) {
+    *reinterpret_cast<uint4*>(base + chunk_off(row, c16)) = v;
+  }
+  // fragment of k-step s (16 deep): this lane's row `row`, k = 16 s + 8 h + j
+  static VG_DEVICE bf16x8 frag(const char* base, int row, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(base + chunk_off(row, 2 * s + (lane >> 5)));
+  }
+};
+
+template <int KD> struct RowTile<float, KD> {
+  static constexpr int PITCH = KD + 1;
+  static VG_DEVICE int bytes(int rows) { return rows * PITCH * 4; }
+  static VG_DEVICE void store_vec(char* base, int row, int c16, uint4 v) {
+    float* p = reinterpret_cast<float*>(base) + row * PITCH + c16 * 4;
+    p[0] = __uint_as_float(v.x); p[1] = __uint_as_float(v.y);
+    p[2] = __uint_as_float(v.z); p[3] = __uint_as_float(v.w);
+  }
+  // fragment of k-step s (2 deep): k = 2 s + h
+  static VG_DEVICE float frag(const char* base, int row, int s, int lane) {
+    return reinterpret_cast<const float*>(base)[row * PITCH + 2 * s + (lane >> 5)];
+  }
+};
+
+// TrTile<T, COLS>: a [krows][COLS] tile whose reduction index k is the ROW
+// (the operand's own row/col index is contiguous): dY and X in the weight-
+// gradient GEMM, W [N][K] in the data-gradient GEMM, V (and K, Q, dO) in the
+// attention products that sum over time.  bf16 fragments are fetched with
+// ds_read_b64_tr_b16 (hardware transpose, 4 k x 16 columns per 16-lane group).
+//   bf16, COLS = 128: 256-byte rows, 64-byte granule index ^= (krow & 3)
+//   bf16, COLS =  64: 128-byte rows, 64-byte granule index ^= (krow >> 1) & 1
+//   -> the 4 consecutive k-rows x 64 bytes a 32-lane half reads tile one
+//      256-byte bank row exactly (conflict-free).
+//   f32: plain [krows][COLS] (lanes read 32 consecutive floats).
+template <typename T, int COLS> struct TrTile;
+
+template <int COLS> struct TrTile<bf16_t, COLS> {
+  static_assert(COLS == 128 || COLS == 64, "bf16 TrTile supports 128 or 64 columns");
+  static constexpr int PITCH = COLS * 2;
+  static VG_DEVICE int bytes(int krows) { return krows * PITCH; }
+  static VG_DEVICE int swz(int krow) { return COLS == 128 ? (krow & 3) : ((krow >> 1) & 1); }
+  // byte offset of element (krow, col); col multiple of 4 for vector access
+  static VG_DEVICE int off(int krow, int col) {
+    return krow * PITCH + ((((col >> 5) ^ swz(krow))) << 6) + ((col & 31) << 1);
+  }
+  static VG_DEVICE void store_vec(char* base, int krow, int c16, uint4 v) {
+    *reinterpret_cast<uint4*>(base + off(krow, c16 * 8)) = v;
+  }
+  // fragment for k-step s: element j <-> k = kperm(s, h, j), operand index = col0 + (lane & 31)
+  //   natural order  : k = 16 s + 8 h + j                    (PERM = false)
+  //   accumulator order: k = 16 s + 8 (j >> 2) + 4 h + (j & 3) (PERM = true; pairs with a
+  //                      32x32 accumulator tile used as the other operand)
+  template <bool PERM>
+  static VG_DEVICE bf16x8 frag(const char* base, int k0, int col0, int s, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+    const int col = col0 + 16 * (g & 1) + 4 * p;
+    const int ka = k0 + 16 * s + (PERM ? 4 * h : 8 * h) + q;
+    const int kb = ka + (PERM ? 8 : 4);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + off(ka, col)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + off(kb, col)));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+};
+
+template <int COLS> struct TrTile<float, COLS> {
+  static constexpr int PITCH = COLS;   // floats
+  static VG_DEVICE int bytes(int krows) { return krows * PITCH * 4; }
+  static VG_DEVICE void store_vec(char* base, int krow, int c16, uint4 v) {
+    *reinterpret_cast<uint4*>(base + (krow * PITCH + c16 * 4) * 4) = v;
+  }
+  // k-step s (2 deep).  natural: k = 2 s + h ; accumulator order: k = acc_row(s, lane)
+  template <bool PERM>
+  static VG_DEVICE float frag(const char* base, int k0, int col0, int s, int lane) {
+    const int k = k0 + (PERM ? acc_row(s, lane) : 2 * s + (lane >> 5));
+    return reinterpret_cast<const float*>(base)[k * PITCH + col0 + (lane & 31)];
+  }
+};
+
+// A 32x32 accumulator tile X (rows = reduction index) as the B operand of the
+// next product (Y = A . X).  bf16: registers 8s..8s+7 packed; f32: register s.
+template <typename T> struct AccOperand;
+template <> struct AccOperand<bf16_t> {
+  static constexpr int STEPS = 2;
+  static VG_DEVICE bf16x8 get(const f32x16& x, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s + j];
+    return r;
+  }
+};
+template <> struct AccOperand<float> {
+  static constexpr int STEPS = 16;
+  static VG_DEVICE float get(const f32x16& x, int s) { return x[s]; }
+};
+
+// ---------------------------------------------------------------- misc math
+VG_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+VG_DEVICE float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+VG_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+VG_DEVICE float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// row predicate: frame (b = m / T, t = m % T) is valid iff t < lengths[b]
+VG_DEVICE bool row_valid(const int* __restrict__ lengths, int T, int m) {
+  if (lengths == nullptr) return true;
+  const int b = m / T;
+  return (m - b * T) < lengths[b];
+}
+
+}  // namespace vg
+
+// ---------------------------------------------------------------- host-side error plumbing
+namespace vg_host {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace vg_host
+
+#define VG_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      vg_host::set_error(__VA_ARGS__);        \
+      return 1;                               \
+    }                                         \
+  } while (0)

@@ -1,0 +1,253 @@
+// MFMA GEMM family for the Transformer / head linears.
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(k,n) )
+//
+// Operand storage modes (no transposed copies are ever materialised):
+//   A_ROW : A stored [M][K]  (k contiguous)      activations, upstream grads
+//   A_TR  : A stored [K][M]  (m contiguous)      dY in the weight-gradient GEMM
+//   B_ROW : B stored [N][K]  (k contiguous)      nn.Linear weight in forward
+//   B_TR  : B stored [K][N]  (n contiguous)      nn.Linear weight in dgrad, X in wgrad
+//
+//   forward   y  = x  W^T       : A_ROW, B_ROW      (reference: modules/transformer/layers.py:82,
+//   dgrad     dx = dy W         : A_ROW, B_TR        modules/attention/attention.py:52,79,
+//   wgrad     dW = dy^T x       : A_TR,  B_TR        modules/linear/layers.py:192-193)
+//
+// Tiling: 128x128 block tile, 4 waves (2x2), each wave a 64x64 tile = 2x2
+// MFMA 32x32 tiles; BK = 64 (bf16) / 32 (f32) -> every LDS tile is 16 KiB;
+// two LDS stages, register-staged global loads issued one tile ahead of the
+// MFMAs that hide them (one barrier per K tile).
+#include "vg_common.h"
+#include "../../include/vaegslm_hip.h"
+
+using namespace vg;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int TILE_BYTES = 128 * 33 * 4;   // largest image (f32 RowTile 128 x (32+1))
+
+struct GemmParams {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  const float* bias;        // [N] fp32 or null
+  const void* residual;     // [M][ldc] (type T) or null
+  const void* aux_in;       // [M][ldc] (type T): input of the activation derivative
+  void* aux_out;            // [M][ldc] (type T): pre-activation copy
+  const int* lengths; int T;
+  int act;                  // VG_ACT_*
+  int dact;                 // VG_ACT_* derivative applied to the result (uses aux_in)
+  int out_f32;              // C is fp32 regardless of T
+  int accumulate;           // C += result (fp32 C only)
+  int k_per_split;          // K range handled by one blockIdx.z (multiple of BK)
+  float alpha;
+};
+
+template <typename T> struct BKOf;
+template <> struct BKOf<bf16_t> { static constexpr int v = 64; };
+template <> struct BKOf<float> { static constexpr int v = 32; };
+
+// ---- global -> register staging of one 16 KiB operand tile (4 x 16 B per thread)
+template <typename T, bool TR>
+VG_DEVICE void stage_load(uint4 (&r)[4], const T* __restrict__ src, long ld, int rc0, int rc_lim,
+                          int k0, int k_lim, int tid) {
+  constexpr int VEC = Traits<T>::VEC;
+  constexpr int BK = BKOf<T>::v;
+  if constexpr (!TR) {
+    // tile [128 rows][BK] : thread -> (row = it*32 + tid/8, chunk = tid%8)
+    const int c16 = tid & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = rc0 + it * 32 + (tid >> 3);
+      const int k = k0 + c16 * VEC;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < rc_lim && k < k_lim) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + k);
+      r[it] = v;
+    }
+  } else {
+    // tile [BK krows][128 cols] : 128 cols = 128/VEC chunks per krow
+    constexpr int CPR = 128 / VEC;            // chunks per krow (16 bf16 / 32 f32)
+    constexpr int RPI = NTHREADS / CPR;       // krows per iteration (16 / 8)
+    static_assert(RPI * 4 == BK, "tile shape");
+    const int c16 = tid % CPR;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int krow = k0 + it * RPI + tid / CPR;
+      const int col = rc0 + c16 * VEC;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (krow < k_lim && col < rc_lim) v = *reinterpret_cast<const uint4*>(src + (long)krow * ld + col);
+      r[it] = v;
+    }
+  }
+}
+
+template <typename T, bool TR>
+VG_DEVICE void stage_store(const uint4 (&r)[4], char* tile, int tid) {
+  constexpr int VEC = Traits<T>::VEC;
+  constexpr int BK = BKOf<T>::v;
+  if constexpr (!TR) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) RowTile<T, BK>::store_vec(tile, it * 32 + (tid >> 3), tid & 7, r[it]);
+  } else {
+    constexpr int CPR = 128 / VEC;
+    constexpr int RPI = NTHREADS / CPR;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) TrTile<T, 128>::store_vec(tile, it * RPI + tid / CPR, tid % CPR, r[it]);
+  }
+}
+
+template <typename T, bool A_TR, bool B_TR>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+  typedef Traits<T> Tr;
+  typedef typename Tr::Frag Frag;
+  constexpr int BK = BKOf<T>::v;
+  constexpr int KSTEPS = BK / Tr::KSTEP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // stage c: A image at smem + 2c * TILE_BYTES, B image right behind it
+  auto tileA = [&](int c) -> char* { return smem + (2 * c) * TILE_BYTES; };
+  auto tileB = [&](int c) -> char* { return smem + (2 * c + 1) * TILE_BYTES; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(p.B);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+
+  uint4 ra[4], rb[4];
+  stage_load<T, A_TR>(ra, A, p.lda, m0, p.M, kbeg, kend, tid);
+  stage_load<T, B_TR>(rb, B, p.ldb, n0, p.N, kbeg, kend, tid);
+  stage_store<T, A_TR>(ra, tileA(0), tid);
+  stage_store<T, B_TR>(rb, tileB(0), tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1) < nkt;
+    if (more) {
+      stage_load<T, A_TR>(ra, A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+      stage_load<T, B_TR>(rb, B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
+    }
+    const char* ta = tileA(cur);
+    const char* tb = tileB(cur);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      Frag fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if constexpr (A_TR) fa[i] = TrTile<T, 128>::template frag<false>(ta, 0, wm * 64 + i * 32, s, lane);
+        else fa[i] = RowTile<T, BK>::frag(ta, wm * 64 + i * 32 + (lane & 31), s, lane);
+        if constexpr (B_TR) fb[i] = TrTile<T, 128>::template frag<false>(tb, 0, wn * 64 + i * 32, s, lane);
+        else fb[i] = RowTile<T, BK>::frag(tb, wn * 64 + i * 32 + (lane & 31), s, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Tr::mfma(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) {
+      stage_store<T, A_TR>(ra, tileA(cur ^ 1), tid);
+      stage_store<T, B_TR>(rb, tileB(cur ^ 1), tid);
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------ epilogue
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  const T* __restrict__ auxi = reinterpret_cast<const T*>(p.aux_in);
+  T* __restrict__ auxo = reinterpret_cast<T*>(p.aux_out);
+  const bool split = gridDim.z > 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+      if (m >= p.M) continue;
+      const bool valid = row_valid(p.lengths, p.T, m);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + acc_col(lane);
+        if (n >= p.N) continue;
+        const long idx = (long)m * p.ldc + n;
+        float v = acc[i][j][r] * p.alpha;
+        if (split) {   // partial sums: raw fp32 accumulation, no epilogue
+          atomicAdd(reinterpret_cast<float*>(p.C) + idx, v);
+          continue;
+        }
+        if (p.bias) v += p.bias[n];
+        if (auxo) auxo[idx] = from_f32<T>(v);
+        if (p.act == VG_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == VG_ACT_GELU) v = gelu_erf(v);
+        if (p.dact == VG_ACT_RELU) v = (to_f32<T>(auxi[idx]) > 0.f) ? v : 0.f;
+        else if (p.dact == VG_ACT_GELU) v *= gelu_erf_grad(to_f32<T>(auxi[idx]));
+        if (res) v += to_f32<T>(res[idx]);
+        if (!valid) v = 0.f;
+        if (p.out_f32) {
+          float* c = reinterpret_cast<float*>(p.C) + idx;
+          *c = p.accumulate ? (*c + v) : v;
+        } else {
+          reinterpret_cast<T*>(p.C)[idx] = from_f32<T>(v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_t stream) {
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
+  dim3 block(NTHREADS);
+  const size_t lds = 4 * TILE_BYTES;
+  void (*k)(GemmParams) = nullptr;
+  if (!a_tr && !b_tr) k = gemm_kernel<T, false, false>;
+  else if (!a_tr && b_tr) k = gemm_kernel<T, false, true>;
+  else if (a_tr && b_tr) k = gemm_kernel<T, true, true>;
+  else k = gemm_kernel<T, true, false>;
+  static bool attr_done[2][4] = {};
+  const int ti = sizeof(T) == 4 ? 0 : 1, ki = a_tr * 2 + b_tr;
+  if (!attr_done[ti][ki]) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done[ti][ki] = true;
+  }
+  hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+  return vg_host::check_launch("vg_gemm");
+}
+
+}  // namespace
+
+extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
+  VG_REQUIRE(d != nullptr, "vg_gemm: null descriptor");
+  VG_REQUIRE(d->dtype == VG_F32 || d->dtype == VG_BF16, "vg_gemm: bad dtype %d", d->dtype);
+  VG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vg_gemm: empty problem %d %d %d", d->M, d->N, d->K);
+  const int vec = d->dtype == VG_BF16 ? 8 : 4;
+  const int bk = d->dtype == VG_BF16 ? 64 : 32;
+  VG_REQUIRE(d->lda % vec == 0 && d->ldb % vec == 0, "vg_gemm: lda/ldb must be multiples of %d", vec);
+  if (!d->a_tr || !d->b_tr) VG_REQUIRE(d->K % vec == 0, "vg_gemm: K must be a multiple of %d", vec);
+  if (d->a_tr) VG_REQUIRE(d->M % vec == 0, "vg_gemm: M must be a multiple of %d for a_tr", vec);
+  if (d->b_tr) VG_REQUIRE(d->N % vec == 0, "vg_gemm: N must be a multiple of %d for b_tr", vec);
+  VG_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "vg_gemm: A/B must be 16-byte aligned");
+  int splits = d->split_k > 0 ? d->split_k : 1;
+  VG_REQUIRE(splits == 1 || d->out_f32, "vg_gemm: split-K needs an fp32 (pre-zeroed) C");
+  GemmParams p;
+  p.A = d->A; p.B = d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.bias = d->bias; p.residual = d->residual; p.aux_in = d->aux_in; p.aux_out = d->aux_out;
+  p.lengths = d->lengths; p.T = d->T > 0 ? d->T : 1;
+  p.act = d->act; p.dact = d->dact; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
+  p.alpha = d->alpha;
+  int kps = (d->K + splits - 1) / splits;
+  kps = ((kps + bk - 1) / bk) * bk;
+  splits = (d->K + kps - 1) / kps;
+  p.k_per_split = kps;
+  if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, stream);
+  return launch<float>(p, d->a_tr, d->b_tr, splits, stream);
+}

@@ -1,0 +1,555 @@
+// Row-wise (HBM-bound) kernels: RMSNorm, token cross-entropy, the VAE
+// reparameterisation / prior log-density / KL terms, and the small
+// deterministic reductions that go with them.  One wave64 per frame for the
+// wide rows (coalesced 16-byte loads, shuffle reductions, fp32 math); one
+// thread per element/row for the 4-wide latent tensors.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vg_common.h"
+#include "../../include/vaegslm_hip.h"
+
+using namespace vg;
+
+// ------------------------------------------------------------------ host error plumbing
+namespace vg_host {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+}  // namespace vg_host
+
+extern "C" int vg_version(void) { return 100; }
+extern "C" int vg_last_error(char* buf, int buflen) {
+  if (buf == nullptr || buflen <= 0) return 1;
+  strncpy(buf, vg_host::g_err, buflen - 1);
+  buf[buflen - 1] = 0;
+  return 0;
+}
+
+namespace {
+
+constexpr int MAXV = 4;   // 16-byte vectors per lane per row (C <= 2048 bf16 / 1024 f32)
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  static VG_DEVICE void load(const float* p, float (&o)[8]) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  static VG_DEVICE void store(float* p, const float (&o)[8]) {
+    f32x4 v = {o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  static VG_DEVICE void load(const bf16_t* p, float (&o)[8]) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  static VG_DEVICE void store(bf16_t* p, const float (&o)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
+
+// ------------------------------------------------------------------ RMSNorm forward
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                          T* __restrict__ y, float* __restrict__ rstd, int M, int C,
+                                                          float eps, const int* __restrict__ lengths, int Tlen) {
+  constexpr int N = Vec<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = C / N;
+  const bool valid = row_valid(lengths, Tlen, row);
+  float v[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      Vec<T>::load(x + (long)row * C + c * N, v[i]);
+#pragma unroll
+      for (int e = 0; e < N; ++e) ss += v[i][e] * v[i][e];
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)C + eps);
+  if (lane == 0) rstd[row] = r;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] = valid ? scale[c * N + e] * (v[i][e] * r) : 0.f;
+      Vec<T>::store(y + (long)row * C + c * N, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RMSNorm backward
+// dx = dx_add + mask * rstd * (g - xhat * mean(g * xhat)),  g = dy * scale, xhat = x * rstd
+// dscale_partial[block][c] = sum over this block's valid rows of dy * xhat
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ rstd, const T* __restrict__ dx_add,
+                                                          T* __restrict__ dx, float* __restrict__ dscale_partial,
+                                                          int M, int C, const int* __restrict__ lengths, int Tlen) {
+  constexpr int N = Vec<T>::N;
+  __shared__ float red[4][64 * MAXV * 8 / 4];   // sized for the f32 case below (see static_assert)
+  static_assert(sizeof(red) >= 4 * 64 * MAXV * 2 * sizeof(float), "reduction scratch");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = C / N;
+  float ds[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ds[i][e] = 0.f;
+
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const bool valid = row_valid(lengths, Tlen, row);
+    const float r = rstd[row];
+    float g[MAXV][8], xh[MAXV][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        float a[8], b[8];
+        Vec<T>::load(dy + (long)row * C + c * N, a);
+        Vec<T>::load(x + (long)row * C + c * N, b);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          xh[i][e] = b[e] * r;
+          g[i][e] = a[e] * scale[c * N + e];
+          dot += g[i][e] * xh[i][e];
+          if (valid) ds[i][e] += a[e] * xh[i][e];
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        float o[8];
+        if (dx_add) Vec<T>::load(dx_add + (long)row * C + c * N, o);
+        else {
+#pragma unroll
+          for (int e = 0; e < N; ++e) o[e] = 0.f;
+        }
+        if (valid) {
+#pragma unroll
+          for (int e = 0; e < N; ++e) o[e] += r * (g[i][e] - xh[i][e] * dot);
+        }
+        Vec<T>::store(dx + (long)row * C + c * N, o);
+      }
+    }
+  }
+  // cross-wave reduction of the scale-gradient partials, MAXV passes of [4][64*N]
+  float* scratch = &red[0][0];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < N; ++e) scratch[(wave * 64 + lane) * N + e] = ds[i][e];
+    __syncthreads();
+    const int c = lane + 64 * i;
+    if (wave == 0 && c < nvec) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += scratch[(w * 64 + lane) * N + e];
+        dscale_partial[(long)blockIdx.x * C + c * N + e] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ column sums
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, int M, int N, long ld, float* __restrict__ out) {
+  __shared__ float red[4][64][4];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c0 = (blockIdx.x * 64 + tx) * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    for (int m = blockIdx.y * 4 + ty; m < M; m += gridDim.y * 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += to_f32<T>(x[(long)m * ld + c0 + e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[ty][tx][e] = s[e];
+  __syncthreads();
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      out[(long)blockIdx.y * N + c0 + e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
+  }
+}
+
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+    t = wave_sum(t);
+    if (threadIdx.x == 0) out[0] = t;
+  }
+}
+
+__global__ void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(src + i);
+      f32x4 b = *reinterpret_cast<const f32x4*>(src + i + 4);
+      bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3],
+                  (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+      *reinterpret_cast<bf16x8*>(dst + i) = o;
+    } else {
+      for (long j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ activation backward
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ aux, T* __restrict__ dx, long n,
+                               int act) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float g = to_f32<T>(dy[i]), a = to_f32<T>(aux[i]);
+    float r = g;
+    if (act == VG_ACT_RELU) r = a > 0.f ? g : 0.f;
+    else if (act == VG_ACT_GELU) r = g * gelu_erf_grad(a);
+    dx[i] = from_f32<T>(r);
+  }
+}
+
+// ------------------------------------------------------------------ token cross-entropy
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const long* __restrict__ targets,
+                                                     float* __restrict__ loss_rows, float* __restrict__ lse_out,
+                                                     int* __restrict__ argmax, int M, int V, long ld,
+                                                     const int* __restrict__ lengths, int Tlen) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* p = logits + (long)row * ld;
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) {
+    const float v = to_f32<T>(p[c]);
+    if (v > mx) { mx = v; mi = c; }
+  }
+  // wave arg-max (lowest index wins ties, like torch.argmax on CPU)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+  }
+  float se = 0.f;
+  for (int c = lane; c < V; c += 64) se += expf(to_f32<T>(p[c]) - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  if (lane == 0) {
+    const bool valid = row_valid(lengths, Tlen, row);
+    const long t = targets[row];
+    const bool use = valid && t >= 0 && t < V;
+    loss_rows[row] = use ? lse - to_f32<T>(p[t]) : 0.f;
+    lse_out[row] = lse;
+    argmax[row] = mi;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, const long* __restrict__ targets,
+                                                     const float* __restrict__ lse, const float* __restrict__ gscale,
+                                                     T* __restrict__ dlogits, int M, int V, long ld,
+                                                     const int* __restrict__ lengths, int Tlen) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bool valid = row_valid(lengths, Tlen, row);
+  const long t = targets[row];
+  const bool use = valid && t >= 0 && t < V;
+  const float g = gscale[0];
+  const float l = lse[row];
+  for (int c = lane; c < V; c += 64) {
+    float d = 0.f;
+    if (use) d = g * (expf(to_f32<T>(logits[(long)row * ld + c]) - l) - (c == t ? 1.f : 0.f));
+    dlogits[(long)row * ld + c] = from_f32<T>(d);
+  }
+}
+
+// ------------------------------------------------------------------ VAE terms
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ ls,
+                                   const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ log_q,
+                                   int M, int D, float temp, const int* __restrict__ lengths, int Tlen) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * D) return;
+  const bool valid = row_valid(lengths, Tlen, (int)(i / D));
+  const float s = ls[i];
+  z[i] = valid ? mu[i] + eps[i] * expf(s) * temp : 0.f;
+  log_q[i] = valid ? -s - 0.5f - HALF_LOG_2PI : 0.f;
+}
+
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ dlog_q,
+                                   const float* __restrict__ ls, const float* __restrict__ eps,
+                                   float* __restrict__ dmu, float* __restrict__ dls, int M, int D, float temp,
+                                   const int* __restrict__ lengths, int Tlen) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * D) return;
+  const bool valid = row_valid(lengths, Tlen, (int)(i / D));
+  const float gz = (valid && dz) ? dz[i] : 0.f;
+  const float gq = (valid && dlog_q) ? dlog_q[i] : 0.f;
+  dmu[i] = gz;
+  dls[i] = gz * eps[i] * expf(ls[i]) * temp - gq;
+}
+
+__global__ void prior_logp_fwd_kernel(const float* __restrict__ mu_ls, long ld, const float* __restrict__ u,
+                                      const float* __restrict__ logdet_sum, const float* __restrict__ log_q,
+                                      float* __restrict__ log_p, float* __restrict__ kl_rows, int M, int D,
+                                      const int* __restrict__ lengths, int Tlen) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const bool valid = row_valid(lengths, Tlen, m);
+  const float ld_term = logdet_sum[m] / (float)D;
+  float kl = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float mu = mu_ls[(long)m * ld + d], ls = mu_ls[(long)m * ld + D + d];
+    const float diff = u[(long)m * D + d] - mu;
+    float lp = ld_term - ls - HALF_LOG_2PI - 0.5f * (expf(-2.f * ls) * diff * diff);
+    lp = valid ? lp : 0.f;
+    log_p[(long)m * D + d] = lp;
+    kl += (valid ? log_q[(long)m * D + d] : 0.f) - lp;
+  }
+  kl_rows[m] = kl / (float)D;
+}
+
+// total dlog_p = dlog_p_in - dkl_rows / D ; dlog_q = + dkl_rows / D   (masked)
+__global__ void prior_logp_bwd_kernel(const float* __restrict__ dlog_p_in, const float* __restrict__ dkl_rows,
+                                      const float* __restrict__ mu_ls, long ld, const float* __restrict__ u,
+                                      float* __restrict__ dmu_ls, float* __restrict__ du,
+                                      float* __restrict__ dlogdet_sum, float* __restrict__ dlog_q, int M, int D,
+                                      const int* __restrict__ lengths, int Tlen) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const bool valid = row_valid(lengths, Tlen, m);
+  const float gk = (valid && dkl_rows) ? dkl_rows[m] / (float)D : 0.f;
+  float gsum = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float g = -gk;
+    if (valid && dlog_p_in) g += dlog_p_in[(long)m * D + d];
+    const float mu = mu_ls[(long)m * ld + d], ls = mu_ls[(long)m * ld + D + d];
+    const float diff = u[(long)m * D + d] - mu;
+    const float w = expf(-2.f * ls);
+    dmu_ls[(long)m * 2 * D + d] = g * w * diff;
+    dmu_ls[(long)m * 2 * D + D + d] = g * (-1.f + w * diff * diff);
+    du[(long)m * D + d] = -g * w * diff;
+    if (dlog_q) dlog_q[(long)m * D + d] = gk;
+    gsum += g;
+  }
+  dlogdet_sum[m] = gsum / (float)D;
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+namespace {
+
+int check_row_shape(const char* who, int M, int C, int dtype) {
+  const int n = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "%s: bad dtype %d", who, dtype);
+  VG_REQUIRE(M > 0 && C > 0, "%s: empty input", who);
+  VG_REQUIRE(C % n == 0 && C / n <= 64 * MAXV, "%s: C=%d unsupported (multiple of %d, <= %d)", who, C, n,
+             64 * MAXV * n);
+  return 0;
+}
+
+template <typename T>
+void run_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, int M, int C, float eps,
+                     const int32_t* lengths, int Tn, hipStream_t stream) {
+  rmsnorm_fwd_kernel<T><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const T*)x, scale, (T*)y, rstd, M, C, eps,
+                                                                     lengths, Tn);
+}
+template <typename T>
+void run_rmsnorm_bwd(int nb, const void* dy, const void* x, const float* scale, const float* rstd,
+                     const void* dx_add, void* dx, float* dsp, int M, int C, const int32_t* lengths, int Tn,
+                     hipStream_t stream) {
+  rmsnorm_bwd_kernel<T><<<dim3(nb), dim3(256), 0, stream>>>((const T*)dy, (const T*)x, scale, rstd,
+                                                            (const T*)dx_add, (T*)dx, dsp, M, C, lengths, Tn);
+}
+template <typename T>
+void run_colsum(dim3 grid, const void* x, int M, int N, long ld, float* out, hipStream_t stream) {
+  colsum_kernel<T><<<grid, dim3(64, 4), 0, stream>>>((const T*)x, M, N, ld, out);
+}
+template <typename T>
+void run_ce_fwd(const void* logits, const int64_t* targets, float* loss_rows, float* lse, int32_t* argmax, int M,
+                int V, long ld, const int32_t* lengths, int Tn, hipStream_t stream) {
+  ce_fwd_kernel<T><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const T*)logits, (const long*)targets, loss_rows,
+                                                                lse, argmax, M, V, ld, lengths, Tn);
+}
+template <typename T>
+void run_ce_bwd(const void* logits, const int64_t* targets, const float* lse, const float* gscale, void* dlogits,
+                int M, int V, long ld, const int32_t* lengths, int Tn, hipStream_t stream) {
+  ce_bwd_kernel<T><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const T*)logits, (const long*)targets, lse, gscale,
+                                                                (T*)dlogits, M, V, ld, lengths, Tn);
+}
+
+}  // namespace
+
+extern "C" int vg_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, int M, int C, float eps,
+                              const int32_t* lengths, int T, int dtype, hipStream_t stream) {
+  if (int e = check_row_shape("vg_rmsnorm_fwd", M, C, dtype)) return e;
+  const int Tn = T > 0 ? T : 1;
+  if (dtype == VG_BF16) run_rmsnorm_fwd<bf16_t>(x, scale, y, rstd, M, C, eps, lengths, Tn, stream);
+  else run_rmsnorm_fwd<float>(x, scale, y, rstd, M, C, eps, lengths, Tn, stream);
+  return vg_host::check_launch("vg_rmsnorm_fwd");
+}
+
+extern "C" int vg_rmsnorm_bwd_blocks(int M) {
+  const int b = (M + 3) / 4;
+  return b < 512 ? b : 512;
+}
+
+extern "C" int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rstd,
+                              const void* dx_add, void* dx, float* dscale_partial, int M, int C,
+                              const int32_t* lengths, int T, int dtype, hipStream_t stream) {
+  if (int e = check_row_shape("vg_rmsnorm_bwd", M, C, dtype)) return e;
+  const int nb = vg_rmsnorm_bwd_blocks(M), Tn = T > 0 ? T : 1;
+  if (dtype == VG_BF16)
+    run_rmsnorm_bwd<bf16_t>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, M, C, lengths, Tn, stream);
+  else
+    run_rmsnorm_bwd<float>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, M, C, lengths, Tn, stream);
+  return vg_host::check_launch("vg_rmsnorm_bwd");
+}
+
+extern "C" int vg_colsum_blocks(int M) {
+  const int b = (M + 31) / 32;
+  return b < 128 ? (b > 0 ? b : 1) : 128;
+}
+
+extern "C" int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, int dtype,
+                         hipStream_t stream) {
+  VG_REQUIRE(N % 4 == 0 && M > 0, "vg_colsum: N=%d must be a multiple of 4", N);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_colsum: bad dtype %d", dtype);
+  const int nb = vg_colsum_blocks(M);
+  dim3 grid1((N + 255) / 256, nb), grid2((N + 255) / 256, 1);
+  float* first = nb == 1 ? out : ws;
+  if (dtype == VG_BF16) run_colsum<bf16_t>(nb == 1 ? grid2 : grid1, x, M, N, (long)ld, first, stream);
+  else run_colsum<float>(nb == 1 ? grid2 : grid1, x, M, N, (long)ld, first, stream);
+  if (nb > 1) run_colsum<float>(grid2, ws, nb, N, (long)N, out, stream);
+  return vg_host::check_launch("vg_colsum");
+}
+
+extern "C" int vg_sum_f32(const float* x, int64_t n, float* out, hipStream_t stream) {
+  sum_kernel<<<dim3(1), dim3(1024), 0, stream>>>(x, (long)n, out);
+  return vg_host::check_launch("vg_sum_f32");
+}
+
+extern "C" int vg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
+  VG_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "vg_cast: unaligned");
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  cast_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(src, (bf16_t*)dst, (long)n);
+  return vg_host::check_launch("vg_cast_f32_to_bf16");
+}
+
+extern "C" int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype,
+                          hipStream_t stream) {
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_act_bwd: bad dtype %d", dtype);
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (dtype == VG_BF16)
+    act_bwd_kernel<bf16_t><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const bf16_t*)dy, (const bf16_t*)aux,
+                                                                             (bf16_t*)dx, (long)n, act);
+  else
+    act_bwd_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)dy, (const float*)aux,
+                                                                            (float*)dx, (long)n, act);
+  return vg_host::check_launch("vg_act_bwd");
+}
+
+extern "C" int vg_ce_fwd(const void* logits, const int64_t* targets, float* loss_rows, float* lse, int32_t* argmax,
+                         int M, int V, int64_t ld, const int32_t* lengths, int T, int dtype, hipStream_t stream) {
+  VG_REQUIRE(M > 0 && V > 0, "vg_ce_fwd: empty");
+  const int Tn = T > 0 ? T : 1;
+  if (dtype == VG_BF16) run_ce_fwd<bf16_t>(logits, targets, loss_rows, lse, argmax, M, V, (long)ld, lengths, Tn, stream);
+  else run_ce_fwd<float>(logits, targets, loss_rows, lse, argmax, M, V, (long)ld, lengths, Tn, stream);
+  return vg_host::check_launch("vg_ce_fwd");
+}
+
+extern "C" int vg_ce_bwd(const void* logits, const int64_t* targets, const float* lse, const float* gscale,
+                         void* dlogits, int M, int V, int64_t ld, const int32_t* lengths, int T, int dtype,
+                         hipStream_t stream) {
+  VG_REQUIRE(M > 0 && V > 0, "vg_ce_bwd: empty");
+  const int Tn = T > 0 ? T : 1;
+  if (dtype == VG_BF16) run_ce_bwd<bf16_t>(logits, targets, lse, gscale, dlogits, M, V, (long)ld, lengths, Tn, stream);
+  else run_ce_bwd<float>(logits, targets, lse, gscale, dlogits, M, V, (long)ld, lengths, Tn, stream);
+  return vg_host::check_launch("vg_ce_bwd");
+}
+
+extern "C" int vg_reparam_fwd(const float* mu, const float* logstd, const float* eps, float* z, float* log_q, int M,
+                              int D, float temperature, const int32_t* lengths, int T, hipStream_t stream) {
+  const long n = (long)M * D;
+  reparam_fwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(mu, logstd, eps, z, log_q, M, D,
+                                                                                  temperature, lengths, T > 0 ? T : 1);
+  return vg_host::check_launch("vg_reparam_fwd");
+}
+
+extern "C" int vg_reparam_bwd(const float* dz, const float* dlog_q, const float* logstd, const float* eps,
+                              float* dmu, float* dlogstd, int M, int D, float temperature, const int32_t* lengths,
+                              int T, hipStream_t stream) {
+  const long n = (long)M * D;
+  reparam_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
+      dz, dlog_q, logstd, eps, dmu, dlogstd, M, D, temperature, lengths, T > 0 ? T : 1);
+  return vg_host::check_launch("vg_reparam_bwd");
+}
+
+extern "C" int vg_prior_logp_fwd(const float* mu_ls, int64_t ld_mu_ls, const float* u, const float* logdet_sum,
+                                 const float* log_q, float* log_p, float* kl_rows, int M, int D,
+                                 const int32_t* lengths, int T, hipStream_t stream) {
+  prior_logp_fwd_kernel<<<dim3((M + 255) / 256), dim3(256), 0, stream>>>(mu_ls, (long)ld_mu_ls, u, logdet_sum, log_q,
+                                                                         log_p, kl_rows, M, D, lengths, T > 0 ? T : 1);
+  return vg_host::check_launch("vg_prior_logp_fwd");
+}
+
+extern "C" int vg_prior_logp_bwd(const float* dlog_p, const float* dkl_rows, const float* mu_ls, int64_t ld_mu_ls,
+                                 const float* u, float* dmu_ls, float* du, float* dlogdet_sum, float* dlog_q, int M,
+                                 int D, const int32_t* lengths, int T, hipStream_t stream) {
+  prior_logp_bwd_kernel<<<dim3((M + 255) / 256), dim3(256), 0, stream>>>(
+      dlog_p, dkl_rows, mu_ls, (long)ld_mu_ls, u, dmu_ls, du, dlogdet_sum, dlog_q, M, D, lengths, T > 0 ? T : 1);
+  return vg_host::check_launch("vg_prior_logp_bwd");
+}

@@ -1,0 +1,137 @@
+"""ctypes binding of ``libvaegslm_hip.so`` (C ABI: include/vaegslm_hip.h).
+
+PyTorch is used only as plumbing here: it owns device memory and streams;
+every compute call goes through the C ABI with raw device pointers.  There is
+NO CPU fallback: loading fails loudly when the library is missing, and every
+wrapper refuses non-GPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libvaegslm_hip.so")
+
+VG_F32, VG_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp),
+                ("M", _i), ("N", _i), ("K", _i),
+                ("lda", _i64), ("ldb", _i64), ("ldc", _i64),
+                ("a_tr", _i), ("b_tr", _i), ("dtype", _i),
+                ("bias", _vp), ("residual", _vp), ("aux_in", _vp), ("aux_out", _vp),
+                ("lengths", _vp), ("T", _i),
+                ("act", _i), ("dact", _i), ("out_f32", _i), ("accumulate", _i),
+                ("split_k", _i), ("alpha", _f)]
+
+
+# name -> argtypes (restype is always int); must list EVERY symbol of the header
+SIGNATURES = {
+    "vg_version": [],
+    "vg_last_error": [C.c_char_p, _i],
+    "vg_gemm": [C.POINTER(GemmDesc), _vp],
+    "vg_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp],
+    "vg_rmsnorm_bwd_blocks": [_i],
+    "vg_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "vg_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "vg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "vg_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vg_ce_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _i, _i, _vp],
+    "vg_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _i, _i, _vp],
+    "vg_reparam_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp],
+    "vg_reparam_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp],
+    "vg_prior_logp_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
+    "vg_prior_logp_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
+    "vg_sum_f32": [_vp, _i64, _vp, _vp],
+    "vg_colsum_blocks": [_i],
+    "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _vp],
+    "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: the MI355X HIP hot path has no fallback. "
+                        "Build it with `python vae-gslm_amd/hipvg/build.py` "
+                        "(or `__graft_entry__.build()`).")
+                handle = C.CDLL(LIB_PATH)
+                for name, argtypes in SIGNATURES.items():
+                    fn = getattr(handle, name)     # AttributeError if the ABI lost a symbol
+                    fn.argtypes = argtypes
+                    fn.restype = C.c_int
+                _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().vg_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def dtype_id(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return VG_F32
+    if t == torch.bfloat16:
+        return VG_BF16
+    raise TypeError(f"HIP hot path supports float32 / bfloat16 activations, got {t}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vae-gslm_amd HIP ops need tensors on an MI355X device "
+                           "(there is no CPU fallback); got a CPU tensor")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------- precision policy
+class _Policy(threading.local):
+    def __init__(self):
+        self.dtype = torch.bfloat16
+
+
+_policy = _Policy()
+
+
+def set_precision(p) -> None:
+    """'bf16' (fast path) or 'fp32' (exact-f32 MFMA parity path)."""
+    if isinstance(p, str):
+        p = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+             "fp32": torch.float32, "float32": torch.float32}[p]
+    assert p in (torch.bfloat16, torch.float32)
+    _policy.dtype = p
+
+
+def compute_dtype() -> torch.dtype:
+    return _policy.dtype

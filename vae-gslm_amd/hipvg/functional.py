@@ -1,0 +1,393 @@
+"""Autograd-aware wrappers over the C ABI (include/vaegslm_hip.h).
+
+Each ``torch.autograd.Function`` here owns a hand-written backward that calls
+the matching HIP kernels; none of them falls back to ATen math.  Conventions:
+
+* activations are 2-D ``[M, C]`` row-major with rows = frames in (b, t) order
+  (``M = B * T``), in the compute dtype (``hipvg.compute_dtype()``);
+* ``lengths`` is an int32 device tensor ``[B]`` (right-padded prefix masks,
+  utils/tensormask.py:45-54 of the reference) or ``None``;
+* parameters stay fp32 (master copy); bf16 shadows are cached per parameter
+  version, so they are re-cast once per optimizer step, not per micro-batch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import (ACT_GELU, ACT_IDS, ACT_NONE, ACT_RELU, GemmDesc, check, dtype_id, lib, ptr,
+               stream)
+
+Tensor = torch.Tensor
+
+# ---------------------------------------------------------------- weight shadows
+
+def shadow(weight: Tensor, dtype: torch.dtype) -> Tensor:
+    """fp32 master parameter -> tensor in the compute dtype (cached by version)."""
+    if weight.dtype == dtype:
+        return weight.detach()
+    ent = getattr(weight, "_vg_shadow", None)
+    ver = weight._version
+    if ent is not None and ent[0] == ver and ent[1].dtype == dtype:
+        return ent[1]
+    assert weight.dtype == torch.float32 and dtype == torch.bfloat16
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    out = torch.empty(w.shape, dtype=dtype, device=w.device)
+    check(lib().vg_cast_f32_to_bf16(ptr(w), ptr(out), w.numel(), stream()), "vg_cast_f32_to_bf16")
+    weight._vg_shadow = (ver, out)
+    return out
+
+
+# ---------------------------------------------------------------- raw ops
+def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False,
+         out: Optional[Tensor] = None, out_f32=False, bias: Optional[Tensor] = None,
+         residual: Optional[Tensor] = None, aux_in: Optional[Tensor] = None,
+         aux_out: Optional[Tensor] = None, lengths: Optional[Tensor] = None, T: int = 0,
+         act: int = ACT_NONE, dact: int = ACT_NONE, accumulate=False, split_k: int = 1,
+         alpha: float = 1.0) -> Tensor:
+    assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
+    assert A.dtype == B.dtype
+    if out is None:
+        odt = torch.float32 if out_f32 else A.dtype
+        out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=odt, device=A.device)
+    d = GemmDesc()
+    d.A, d.B, d.C = ptr(A), ptr(B), ptr(out)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), out.stride(0)
+    d.a_tr, d.b_tr, d.dtype = int(a_tr), int(b_tr), dtype_id(A.dtype)
+    d.bias, d.residual = ptr(bias), ptr(residual)
+    d.aux_in, d.aux_out = ptr(aux_in), ptr(aux_out)
+    d.lengths, d.T = ptr(lengths), int(T)
+    d.act, d.dact = act, dact
+    d.out_f32 = int(out.dtype == torch.float32)
+    d.accumulate, d.split_k, d.alpha = int(accumulate), int(split_k), float(alpha)
+    check(lib().vg_gemm(C.byref(d), stream()), "vg_gemm")
+    return out
+
+
+def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -> int:
+    """Split the reduction (frame) dimension of a weight-gradient GEMM so that
+    the grid fills 256 CUs x 2 blocks.  fp32 (parity) stays un-split so the
+    result is deterministic."""
+    if dtype == torch.float32:
+        return 1
+    tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
+    s = max(1, 512 // max(tiles, 1))
+    s = min(s, max(1, k_red // 256), 16)
+    return s
+
+
+def colsum(x: Tensor) -> Tensor:
+    M, N = x.shape
+    nb = lib().vg_colsum_blocks(M)
+    ws = torch.empty((nb, N), dtype=torch.float32, device=x.device)
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    check(lib().vg_colsum(ptr(x), M, N, x.stride(0), ptr(ws), ptr(out), dtype_id(x.dtype), stream()),
+          "vg_colsum")
+    return out
+
+
+def act_bwd(dy: Tensor, aux: Tensor, act: int) -> Tensor:
+    out = torch.empty_like(dy)
+    check(lib().vg_act_bwd(ptr(dy), ptr(aux), ptr(out), dy.numel(), act, dtype_id(dy.dtype), stream()),
+          "vg_act_bwd")
+    return out
+
+
+def sum_f32(x: Tensor) -> Tensor:
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(lib().vg_sum_f32(ptr(x), x.numel(), ptr(out), stream()), "vg_sum_f32")
+    return out
+
+
+def _as(x: Tensor, dtype: torch.dtype) -> Tensor:
+    x = x if x.dtype == dtype else x.to(dtype)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+# ---------------------------------------------------------------- Linear (+bias, act, residual, mask)
+class LinearFn(torch.autograd.Function):
+    """y = mask( act(x W^T + b) + residual )   (modules/linear/layers.py:192-193,
+    modules/attention/attention.py:52,79-80, modules/transformer/layers.py:151-154)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, lengths, T, act, out_f32):
+        M, K = x.shape
+        N = weight.shape[0]
+        w = shadow(weight, x.dtype)
+        b = None if bias is None else bias.detach().float()
+        aux = None
+        y_dtype_f32 = bool(out_f32)
+        if act == ACT_GELU:
+            aux = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        y = gemm(x, w, M, N, K, bias=b, residual=residual, lengths=lengths, T=T, act=act,
+                 aux_out=aux, out_f32=y_dtype_f32)
+        if act == ACT_RELU:
+            aux = y
+        ctx.save_for_backward(x, w, aux, lengths)
+        ctx.meta = (T, act, bias is not None, residual is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, aux, lengths = ctx.saved_tensors
+        T, act, has_bias, has_res, wshape = ctx.meta
+        M, K = x.shape
+        N = wshape[0]
+        dy = _as(dy, x.dtype)
+        du = dy
+        if act != ACT_NONE:
+            du = act_bwd(dy, _as(aux, x.dtype), act)
+        dx = dW = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(du, w, M, K, N, b_tr=True, lengths=lengths, T=T)
+        if ctx.needs_input_grad[1]:
+            s = wgrad_splits(N, K, M, x.dtype)
+            dW = gemm(du, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=s)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(du)
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dW, db, dres, None, None, None, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act=None,
+           residual: Optional[Tensor] = None, lengths: Optional[Tensor] = None, T: int = 0,
+           out_f32: bool = False) -> Tensor:
+    return LinearFn.apply(x, weight, bias, residual, lengths, T, ACT_IDS[act] if not isinstance(act, int) else act,
+                          out_f32)
+
+
+# ---------------------------------------------------------------- fused FFN
+class FFNFn(torch.autograd.Function):
+    """y = mask( residual + W2 gelu(W1 x + b1) + b2 )  (modules/transformer/layers.py:78-86)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, lengths, T):
+        M, K = x.shape
+        F_ = w1.shape[0]
+        s1, s2 = shadow(w1, x.dtype), shadow(w2, x.dtype)
+        u = torch.empty((M, F_), dtype=x.dtype, device=x.device)
+        h = gemm(x, s1, M, F_, K, bias=None if b1 is None else b1.detach(), act=ACT_GELU, aux_out=u)
+        y = gemm(h, s2, M, K, F_, bias=None if b2 is None else b2.detach(), residual=residual,
+                 lengths=lengths, T=T)
+        ctx.save_for_backward(x, s1, s2, u, h, lengths)
+        ctx.meta = (T, b1 is not None, b2 is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s1, s2, u, h, lengths = ctx.saved_tensors
+        T, hb1, hb2, has_res = ctx.meta
+        M, K = x.shape
+        F_ = s1.shape[0]
+        dy = _as(dy, x.dtype)
+        du = gemm(dy, s2, M, F_, K, b_tr=True, dact=ACT_GELU, aux_in=u)
+        dW2 = gemm(dy, h, K, F_, M, a_tr=True, b_tr=True, out_f32=True,
+                   split_k=wgrad_splits(K, F_, M, x.dtype)) if ctx.needs_input_grad[3] else None
+        db2 = colsum(dy) if (hb2 and ctx.needs_input_grad[4]) else None
+        dx = gemm(du, s1, M, K, F_, b_tr=True, lengths=lengths, T=T) if ctx.needs_input_grad[0] else None
+        dW1 = gemm(du, x, F_, K, M, a_tr=True, b_tr=True, out_f32=True,
+                   split_k=wgrad_splits(F_, K, M, x.dtype)) if ctx.needs_input_grad[1] else None
+        db1 = colsum(du) if (hb1 and ctx.needs_input_grad[2]) else None
+        dres = dy if (has_res and ctx.needs_input_grad[5]) else None
+        return dx, dW1, db1, dW2, db2, dres, None, None
+
+
+def ffn(x, w1, b1, w2, b2, *, residual=None, lengths=None, T=0):
+    return FFNFn.apply(x, w1, b1, w2, b2, residual, lengths, T)
+
+
+# ---------------------------------------------------------------- RMSNorm
+class RMSNormFn(torch.autograd.Function):
+    """modules/norm.py:28-32 (+ re-mask, modules/transformer/layers.py:52-54)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, eps, lengths, T):
+        M, Cc = x.shape
+        y = torch.empty_like(x)
+        rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+        sc = scale.detach().float().contiguous()
+        check(lib().vg_rmsnorm_fwd(ptr(x), ptr(sc), ptr(y), ptr(rstd), M, Cc, float(eps), ptr(lengths),
+                                   int(T), dtype_id(x.dtype), stream()), "vg_rmsnorm_fwd")
+        ctx.save_for_backward(x, sc, rstd, lengths)
+        ctx.T = T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sc, rstd, lengths = ctx.saved_tensors
+        M, Cc = x.shape
+        dy = _as(dy, x.dtype)
+        dx = torch.empty_like(x)
+        nb = lib().vg_rmsnorm_bwd_blocks(M)
+        part = torch.empty((nb, Cc), dtype=torch.float32, device=x.device)
+        check(lib().vg_rmsnorm_bwd(ptr(dy), ptr(x), ptr(sc), ptr(rstd), None, ptr(dx), ptr(part), M, Cc,
+                                   ptr(lengths), int(ctx.T), dtype_id(x.dtype), stream()), "vg_rmsnorm_bwd")
+        dscale = colsum(part) if ctx.needs_input_grad[1] else None
+        return dx, dscale, None, None, None
+
+
+def rmsnorm(x, scale, eps, *, lengths=None, T=0):
+    return RMSNormFn.apply(x, scale, eps, lengths, T)
+
+
+# ---------------------------------------------------------------- attention
+def alibi_slopes(nheads: int):
+    """modules/position/alibi.py:19-30 (positive slopes; the bias is -slope*|i-j|)."""
+    def pow2(n):
+        start = 2 ** (-2 ** -(math.log2(n) - 3))
+        return [start * start ** i for i in range(n)]
+    if math.log2(nheads).is_integer():
+        return pow2(nheads)
+    c = 2 ** math.floor(math.log2(nheads))
+    return pow2(c) + alibi_slopes(2 * c)[0::2][:nheads - c]
+
+
+class AttentionFn(torch.autograd.Function):
+    """Causal ALiBi attention over the packed in_proj output
+    (modules/attention/attention.py:52-78)."""
+
+    @staticmethod
+    def forward(ctx, qkv, slopes, B, T, H, lengths):
+        D = H * 64
+        assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
+        out = torch.empty((B * T, D), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+        check(lib().vg_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(slopes), B, T, H, ptr(lengths),
+                                dtype_id(qkv.dtype), stream()), "vg_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse, slopes, lengths)
+        ctx.dims = (B, T, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, slopes, lengths = ctx.saved_tensors
+        B, T, H = ctx.dims
+        dout = _as(dout, qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+        check(lib().vg_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
+                                B, T, H, ptr(lengths), dtype_id(qkv.dtype), stream()), "vg_attn_bwd")
+        return dqkv, None, None, None, None, None
+
+
+def attention(qkv, slopes, B, T, H, lengths=None):
+    return AttentionFn.apply(qkv, slopes, B, T, H, lengths)
+
+
+def attention_decode(q, kcache, vcache, slopes, pos, H):
+    B, D = q.shape
+    out = torch.empty_like(q)
+    check(lib().vg_attn_decode(ptr(q), ptr(kcache), ptr(vcache), ptr(out), ptr(slopes), ptr(pos), B,
+                               kcache.shape[1], H, dtype_id(q.dtype), stream()), "vg_attn_decode")
+    return out
+
+
+# ---------------------------------------------------------------- token cross-entropy
+class CrossEntropyFn(torch.autograd.Function):
+    """training_lib/losses.py:30-41: sum over valid frames of -log softmax(logits)[target]."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, lengths, T):
+        M, V = logits.shape
+        assert logits.is_contiguous()
+        rows = torch.empty((M,), dtype=torch.float32, device=logits.device)
+        lse = torch.empty((M,), dtype=torch.float32, device=logits.device)
+        amax = torch.empty((M,), dtype=torch.int32, device=logits.device)
+        tg = targets.reshape(-1).contiguous()
+        check(lib().vg_ce_fwd(ptr(logits), ptr(tg), ptr(rows), ptr(lse), ptr(amax), M, V, logits.stride(0),
+                              ptr(lengths), int(T), dtype_id(logits.dtype), stream()), "vg_ce_fwd")
+        ctx.save_for_backward(logits, tg, lse, lengths)
+        ctx.T = T
+        ctx.mark_non_differentiable(amax)
+        return sum_f32(rows), amax
+
+    @staticmethod
+    def backward(ctx, g, _):
+        logits, tg, lse, lengths = ctx.saved_tensors
+        M, V = logits.shape
+        gs = g.detach().float().reshape(1).contiguous()
+        dl = torch.empty_like(logits)
+        check(lib().vg_ce_bwd(ptr(logits), ptr(tg), ptr(lse), ptr(gs), ptr(dl), M, V, logits.stride(0),
+                              ptr(lengths), int(ctx.T), dtype_id(logits.dtype), stream()), "vg_ce_bwd")
+        return dl, None, None, None
+
+
+def cross_entropy_sum(logits, targets, lengths=None, T=0):
+    return CrossEntropyFn.apply(logits, targets, lengths, T)
+
+
+# ---------------------------------------------------------------- VAE terms
+class ReparamFn(torch.autograd.Function):
+    """z = mask(mu + eps * exp(logstd) * temperature), log_q = mask(-logstd - 0.5 - 0.5 ln 2pi)
+    (modules/linear/layers.py:110-128; models/speech/lvtr.py:157-160)."""
+
+    @staticmethod
+    def forward(ctx, mu, logstd, eps, temperature, lengths, T):
+        mu, logstd, eps = (_as(t, torch.float32) for t in (mu, logstd, eps))
+        M, D = mu.shape
+        z, lq = torch.empty_like(mu), torch.empty_like(mu)
+        check(lib().vg_reparam_fwd(ptr(mu), ptr(logstd), ptr(eps), ptr(z), ptr(lq), M, D, float(temperature),
+                                   ptr(lengths), int(T), stream()), "vg_reparam_fwd")
+        ctx.save_for_backward(logstd, eps, lengths)
+        ctx.meta = (float(temperature), T)
+        return z, lq
+
+    @staticmethod
+    def backward(ctx, dz, dlq):
+        logstd, eps, lengths = ctx.saved_tensors
+        temperature, T = ctx.meta
+        M, D = logstd.shape
+        dz = None if dz is None else _as(dz, torch.float32)
+        dlq = None if dlq is None else _as(dlq, torch.float32)
+        dmu, dls = torch.empty_like(logstd), torch.empty_like(logstd)
+        check(lib().vg_reparam_bwd(ptr(dz), ptr(dlq), ptr(logstd), ptr(eps), ptr(dmu), ptr(dls), M, D,
+                                   temperature, ptr(lengths), int(T), stream()), "vg_reparam_bwd")
+        return dmu, dls, None, None, None, None
+
+
+def reparameterize(mu, logstd, eps, temperature=1.0, lengths=None, T=0):
+    return ReparamFn.apply(mu, logstd, eps, temperature, lengths, T)
+
+
+class PriorKLFn(torch.autograd.Function):
+    """log_p under the conditional flow prior and the summed KL
+    (models/speech/lvtr.py:182-191; training_lib/losses.py:16-18,27)."""
+
+    @staticmethod
+    def forward(ctx, mu_ls, u, logdet_sum, log_q, lengths, T):
+        mu_ls, u, logdet_sum, log_q = (_as(t, torch.float32) for t in (mu_ls, u, logdet_sum, log_q))
+        M, D = u.shape
+        log_p = torch.empty_like(u)
+        rows = torch.empty((M,), dtype=torch.float32, device=u.device)
+        check(lib().vg_prior_logp_fwd(ptr(mu_ls), mu_ls.stride(0), ptr(u), ptr(logdet_sum), ptr(log_q),
+                                      ptr(log_p), ptr(rows), M, D, ptr(lengths), int(T), stream()),
+              "vg_prior_logp_fwd")
+        ctx.save_for_backward(mu_ls, u, lengths)
+        ctx.T = T
+        return log_p, sum_f32(rows)
+
+    @staticmethod
+    def backward(ctx, dlog_p, dkl):
+        mu_ls, u, lengths = ctx.saved_tensors
+        M, D = u.shape
+        dlp = None if dlog_p is None else _as(dlog_p, torch.float32)
+        dkr = None if dkl is None else dkl.detach().float().reshape(1).expand(M).contiguous()
+        dmu_ls = torch.empty((M, 2 * D), dtype=torch.float32, device=u.device)
+        du = torch.empty_like(u)
+        dld = torch.empty((M,), dtype=torch.float32, device=u.device)
+        dlq = torch.empty_like(u)
+        check(lib().vg_prior_logp_bwd(ptr(dlp), ptr(dkr), ptr(mu_ls), mu_ls.stride(0), ptr(u), ptr(dmu_ls),
+                                      ptr(du), ptr(dld), ptr(dlq), M, D, ptr(lengths), int(ctx.T), stream()),
+              "vg_prior_logp_bwd")
+        return dmu_ls, du, dld, dlq, None, None
+
+
+def prior_logp_kl(mu_ls, u, logdet_sum, log_q, lengths=None, T=0):
+    return PriorKLFn.apply(mu_ls, u, logdet_sum, log_q, lengths, T)
