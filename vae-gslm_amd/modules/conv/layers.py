@@ -1,0 +1,210 @@
+"""Convolutional stacks that run INSIDE the training step but outside the HIP
+hot path (SURVEY.md section 2, rows marked as stock PyTorch-ROCm): the
+posterior encoder / diffusion UNet body (``BottleNeckResNet``) and the
+utterance encoder (``CNNStack``).
+
+Only the state-dict layout is dictated by the reference
+(modules/conv/layers.py:70-135,231-295,386-652: ``linear``, ``layers.N.{norm,
+conv1,conv2,conv3,time_emb}``, ``skip_conv.N``, ``final_norm``, ``out_linear``;
+``layers.N.{conv,norm}`` for the CNN stack) so its checkpoints load with
+``strict=True``.  The implementation is a single configurable bottleneck block
+instead of the reference's four subclasses, and supports exactly what
+``vae-gslm.yaml`` instantiates: resample rate 1, "concat" conditioning,
+optional diffusion-time embedding, concat skip connections.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from hparams.hp import Hparams
+from modules.activations import get_activation
+from modules.norm import get_norm_fn
+from utils.helpers import get_padding
+from utils.tensormask import TensorMask
+
+
+class Conv1d(nn.Conv1d):
+    """Conv1d that accepts an asymmetric ``padding=(left, right)`` tuple."""
+
+    def __init__(self, *args, **kwargs):
+        pad = kwargs.get("padding", 0)
+        self.two_side_padding = None
+        if isinstance(pad, tuple):
+            assert len(pad) == 2
+            self.two_side_padding = pad
+            kwargs["padding"] = 0
+        super().__init__(*args, **kwargs)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.two_side_padding is not None:
+            x = F.pad(x, list(self.two_side_padding))
+        return super().forward(x)
+
+
+class BottleneckBlock(nn.Module):
+    """x + conv3(act(conv2([norm(dwconv(x) + t_emb) ; cond])))   on (B, C, T)."""
+
+    def __init__(self, channels: int, hidden: int, lhp: Hparams, cond_dim: int = 0,
+                 time_dim: Optional[int] = None):
+        super().__init__()
+        lhp.check_arg_in_hparams("kernel_size", "norm", "activation")
+        assert lhp.norm.identifier != "LayerNorm", "BCT format not supported"
+        if lhp.get("shortcut", False) or lhp.has("layer_scale") or lhp.get("dropout", 0.0):
+            raise NotImplementedError("shortcut / layer_scale / dropout variants are not used by vae-gslm.yaml")
+        pad = get_padding(lhp.kernel_size, causal=lhp.get("causal_padding", False),
+                          future=lhp.get("future_padding", False))
+        self.norm = get_norm_fn(channels, lhp.norm)
+        self.act = get_activation(lhp.activation)
+        self.conv1 = Conv1d(channels, channels, kernel_size=lhp.kernel_size, padding=pad, groups=channels)
+        self.conv2 = nn.Conv1d(channels + cond_dim, hidden, kernel_size=1)
+        self.conv3 = nn.Conv1d(hidden, channels, kernel_size=1)
+        if time_dim is not None:
+            self.time_emb = nn.Linear(time_dim, channels)
+        self.has_time, self.has_cond = time_dim is not None, cond_dim > 0
+
+    def forward(self, x: torch.Tensor, cond: Optional[torch.Tensor] = None,
+                temb: Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = self.conv1(x)
+        if self.has_time:
+            h = h + self.time_emb(self.act(temb)).unsqueeze(-1)
+        h = self.norm(h)
+        if self.has_cond:
+            h = torch.cat([h, cond.to(h.dtype)], 1)
+        return x + self.conv3(self.act(self.conv2(h)))
+
+
+class BottleNeckResNet(nn.Module):
+    def __init__(self, hp: Hparams, input_dim: Optional[int] = None,
+                 output_dim: Optional[int] = None) -> None:
+        super().__init__()
+        hp.check_arg_in_hparams("num_layers", "layer", "init_channel", "out_channels",
+                                "hidden_channels", "resample_rates", "resample_ksize")
+        self.hp = hp
+        L = hp.num_layers
+        for name in ("resample_rates", "resample_ksize", "out_channels", "hidden_channels"):
+            assert len(getattr(hp, name)) == L
+        if any(r not in (1, -1) for r in hp.resample_rates):
+            raise NotImplementedError("resampling BottleNeckResNet layers are not used by vae-gslm.yaml")
+        boundary = hp.upward_layer.boundary if hp.has("upward_layer") else L
+        assert boundary <= L
+        self.conditional: List[bool] = list(hp.get("conditional", [False] * L))
+        cond_dim = 0
+        if hp.has("conditional"):
+            hp.check_arg_in_hparams("condition_dim")
+            cond_dim = hp.condition_dim
+        self.time_dim = hp.get("time_dim", None)
+        self.skip_connection = list(hp.get("skip_connection", [None] * L))
+        self.skip_concat = hp.get("connection_type", None) == "concat"
+        widths = [hp.init_channel] + list(hp.out_channels)
+        blocks, skips = [], []
+        for i in range(L):
+            lhp = hp.layer if i < boundary else hp.upward_layer
+            assert widths[i] == widths[i + 1]
+            if self.conditional[i] and lhp.get("condition_type", "film") != "concat":
+                raise NotImplementedError("only condition_type='concat' is used by vae-gslm.yaml")
+            blocks.append(BottleneckBlock(widths[i], hp.hidden_channels[i], lhp,
+                                          cond_dim=cond_dim if self.conditional[i] else 0,
+                                          time_dim=self.time_dim))
+            fuse = self.skip_connection[i] is not None and self.skip_concat
+            skips.append(nn.Conv1d(2 * widths[i], widths[i], 1) if fuse else nn.Identity())
+        self.layers = nn.ModuleList(blocks)
+        self.skip_conv = nn.ModuleList(skips)
+        self.linear = nn.Linear(input_dim, hp.init_channel) if input_dim is not None else None
+        self.out_linear = nn.Linear(widths[-1], output_dim) if output_dim is not None else None
+        self.final_norm = get_norm_fn(widths[-1], hp.layer.norm) if hp.get("final_norm", False) else None
+        self.first_norm = get_norm_fn(widths[0], hp.layer.norm) if hp.get("first_norm", False) else None
+
+    def forward(self, x: TensorMask, c: Optional[TensorMask] = None,
+                t: Optional[torch.Tensor] = None) -> TensorMask:
+        """x: (B, T, C) TensorMask; c: (B, T, Cc) TensorMask; t: (B, time_dim)."""
+        mask = x.mask
+        h = x.value
+        if self.linear is not None:
+            h = TensorMask(self.linear(h), mask).apply_mask().value
+        h = h.transpose(1, 2)
+        if self.first_norm is not None:
+            h = self.first_norm(h)
+        cond = None if c is None else c.value.transpose(1, 2)
+        history = [h]
+        for i, block in enumerate(self.layers):
+            h = block(h, cond if self.conditional[i] else None, t if self.time_dim is not None else None)
+            src = self.skip_connection[i]
+            if src is not None:
+                if self.skip_concat:
+                    h = self.skip_conv[i](torch.cat([h, history[src].to(h.dtype)], 1))
+                else:
+                    h = h + history[src]
+            history.append(h)
+        if self.final_norm is not None:
+            h = self.final_norm(h)
+        h = h.transpose(1, 2)
+        if self.out_linear is not None:
+            h = self.out_linear(h)
+        return TensorMask(h, mask).apply_mask()
+
+    @property
+    def sample_ratio(self) -> float:
+        return 1.0
+
+
+class ConvNormAct(nn.Module):
+    """Strided conv -> per-frame channel norm -> activation on (B, C, T)."""
+
+    def __init__(self, cin: int, cout: int, kernel: int, rate: int, lhp: Hparams):
+        super().__init__()
+        if rate >= 1 and rate != 1:
+            raise NotImplementedError("up-sampling CNNStack layers are not used by vae-gslm.yaml")
+        self.factor = 1 if rate == 1 else -rate
+        self.conv = Conv1d(cin, cout, kernel_size=kernel, stride=self.factor,
+                           padding=get_padding(kernel, causal=lhp.get("causal_padding", False),
+                                               future=lhp.get("future_padding", False)))
+        self.norm = get_norm_fn(cout, lhp.norm)
+        self.act = get_activation(lhp.activation)
+
+    def forward(self, h: torch.Tensor, length: torch.Tensor):
+        h = self.act(self.norm(self.conv(h)))
+        if self.factor != 1:
+            # the reference multiplies (not divides) the lengths of down-sampling
+            # layers (modules/conv/layers.py:568,588-591); reproduced for parity
+            length = TensorMask.resize_length(length, float(self.factor))
+            length = torch.clamp(length, max=h.shape[-1])
+        return h, length
+
+
+class CNNStack(nn.Module):
+    def __init__(self, hp: Hparams, input_dim: Optional[int] = None,
+                 output_dim: Optional[int] = None) -> None:
+        super().__init__()
+        hp.check_arg_in_hparams("num_layers", "layer", "init_channel", "out_channels",
+                                "resample_rates", "resample_ksize")
+        self.hp = hp
+        widths = [hp.init_channel] + list(hp.out_channels)
+        assert len(hp.resample_rates) == len(hp.resample_ksize) == len(hp.out_channels) == hp.num_layers
+        self.layers = nn.ModuleList([
+            ConvNormAct(widths[i], widths[i + 1], hp.resample_ksize[i], hp.resample_rates[i], hp.layer)
+            for i in range(hp.num_layers)])
+        self.linear = nn.Linear(input_dim, hp.init_channel) if input_dim is not None else None
+        self.out_linear = nn.Linear(widths[-1], output_dim) if output_dim is not None else None
+
+    def forward(self, x: TensorMask) -> TensorMask:
+        h = x.value
+        if self.linear is not None:
+            h = TensorMask(self.linear(h), x.mask).apply_mask().value
+        h, length = h.transpose(1, 2), x.length
+        for layer in self.layers:
+            h, length = layer(h, length)
+        h = h.transpose(1, 2)
+        if self.out_linear is not None:
+            h = self.out_linear(h)
+        return TensorMask.fromlength(h, length).apply_mask()
+
+    @property
+    def sample_ratio(self) -> float:
+        r = 1.0
+        for rate in self.hp.resample_rates:
+            r = r * rate if rate > 0 else r / -rate
+        return r

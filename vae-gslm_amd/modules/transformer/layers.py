@@ -1,0 +1,176 @@
+"""Pre-LN Transformer layer and stack on the HIP kernels.
+
+Drop-in for the reference ``modules/transformer/layers.py`` (``TransformerLayer``
+:13-93, ``TransformerLayerStack`` :96-204): same constructors, parameter names
+(``self_attn.*``, ``linear1/2``, ``norm1/3.scale``, ``final_norm.scale``,
+``linear.weight``), ``forward`` / ``run`` signatures and result dicts.
+
+One layer is six kernel launches forward:
+    rmsnorm(+mask) -> QKV GEMM -> flash attention (causal + ALiBi in-kernel)
+    -> out-proj GEMM (+residual, +mask) -> rmsnorm -> FFN GEMM pair
+       (bias+GELU epilogue ; bias+residual+mask epilogue)
+The activations stay 2-D ``[B*T, C]`` in the compute dtype between kernels;
+``TensorMask`` objects are only created at the module boundary.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, List, Mapping, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+import hipvg
+from hipvg import functional as HF
+from hparams.hp import Hparams
+from modules.activations import get_activation, hip_act_id
+from modules.attention.attention import AlibiBias, CrossAttention, SelfAttention, _slopes_from
+from modules.norm import RMSNorm, get_norm_fn
+from modules.position.embedding import get_positional_encoding
+from utils.tensormask import TensorMask
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, hp: Hparams) -> None:
+        super().__init__()
+        hp.check_arg_in_hparams("ffd_size", "norm", "activation", "dim", "self_attn")
+        self.hp = hp
+        self.preln = hp.get("preln", True)
+        if hp.get("dropout", 0.0) or hp.has("cross_attn") or not self.preln:
+            raise NotImplementedError("HIP TransformerLayer: pre-LN, no dropout, no cross-attention")
+        self.self_attn = SelfAttention(hp.dim, hp.self_attn)
+        self.cross_attn = None
+        use_bias = hp.get("bias", True)
+        self.linear1 = nn.Linear(hp.dim, hp.ffd_size, bias=use_bias)
+        self.linear2 = nn.Linear(hp.ffd_size, hp.dim, bias=use_bias)
+        self.norm1 = get_norm_fn(hp.dim, hp.norm)
+        self.norm3 = get_norm_fn(hp.dim, hp.norm)
+        self.activation = get_activation(hp.activation)
+        if not isinstance(self.norm1, RMSNorm) or hip_act_id(self.activation) != "gelu":
+            raise NotImplementedError("HIP TransformerLayer implements RMSNorm + exact GELU "
+                                      "(the vae-gslm.yaml layer)")
+
+    # ---- the fused path used by training and by the stack: 2-D activations in, 2-D out
+    def forward_2d(self, x2: torch.Tensor, B: int, T: int, lens: Optional[torch.Tensor],
+                   slopes: torch.Tensor) -> torch.Tensor:
+        sa = self.self_attn
+        n1 = HF.rmsnorm(x2, self.norm1.scale, self.norm1.eps, lengths=lens, T=T)
+        qkv = HF.linear(n1, sa.in_proj.weight, sa.in_proj.bias)
+        ctx = HF.attention(qkv, slopes, B, T, sa.nheads, lens)
+        x1 = HF.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x2, lengths=lens, T=T)
+        n3 = HF.rmsnorm(x1, self.norm3.scale, self.norm3.eps, lengths=lens, T=T)
+        return HF.ffn(n3, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                      residual=x1, lengths=lens, T=T)
+
+    def forward(self, tgt: TensorMask, memory: Optional[TensorMask] = None,
+                rpe_pair: Optional[Tuple[str, Any]] = None, rpe_bias=None,
+                past_kv: Optional[Mapping] = None, return_attn: bool = False,
+                return_kv: bool = False) -> Mapping:
+        B, T, D = tgt.value.shape
+        dt = hipvg.compute_dtype()
+        output = dict()
+        x2 = tgt.value.reshape(B * T, D).to(dt).contiguous()
+        lens = tgt.lengths32
+        if past_kv is None and not return_attn and not return_kv:
+            bias_h = _slopes_from(rpe_pair, rpe_bias, x2.device)
+            if rpe_pair is not None and rpe_pair[0] == "ALiBi":
+                output["rpe_bias"] = bias_h
+            y = self.forward_2d(x2, B, T, lens, bias_h.slopes)
+            output["output"] = TensorMask(y.view(B, T, D), tgt.mask)
+            return output
+        # decode / debug path: same kernels, through the SelfAttention module
+        n1 = HF.rmsnorm(x2, self.norm1.scale, self.norm1.eps, lengths=lens, T=T)
+        sa = self.self_attn(TensorMask(n1.view(B, T, D), tgt.mask), past_kv=past_kv, rpe_pair=rpe_pair,
+                            rpe_bias=rpe_bias, return_attn=return_attn, return_kv=return_kv)
+        if "rpe_bias" in sa:
+            output["rpe_bias"] = sa["rpe_bias"]
+        x1 = x2 + sa["output"].value.reshape(B * T, D)
+        n3 = HF.rmsnorm(x1, self.norm3.scale, self.norm3.eps, lengths=lens, T=T)
+        y = HF.ffn(n3, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                   residual=x1, lengths=lens, T=T)
+        output["output"] = TensorMask(y.view(B, T, D), tgt.mask)
+        if return_attn:
+            output["self_attn"] = sa["attn"]
+        if return_kv:
+            output["kv"] = sa["kv"]
+        return output
+
+
+class TransformerLayerStack(nn.Module):
+    def __init__(self, hp: Hparams, input_dim: Optional[int] = None,
+                 output_dim: Optional[int] = None, memory_dim: Optional[int] = None) -> None:
+        super().__init__()
+        hp.check_arg_in_hparams("num_layers", "layer")
+        self.hp = hp
+        self.layers = nn.ModuleList([TransformerLayer(hp.layer) for _ in range(hp.num_layers)])
+        use_bias = hp.get("bias", True)
+        self.linear = nn.Linear(input_dim, hp.layer.dim, bias=use_bias) if input_dim is not None else None
+        self.out = nn.Linear(hp.layer.dim, output_dim, bias=use_bias) if output_dim is not None else None
+        self.memory_linear = None
+        self.is_cross_attn = False
+        self.final_norm = get_norm_fn(hp.layer.dim, hp.layer.norm) if hp.get("final_ln", True) else None
+        self.first_norm = get_norm_fn(hp.layer.dim, hp.layer.norm) if hp.get("first_ln", False) else None
+        self.rpe, self.rpe_id = None, None
+        if hp.get("rpe", False):
+            self.rpe_id = hp.rpe.identifier
+            self.rpe = get_positional_encoding(self.rpe_id, hp.rpe, hp.layer.dim,
+                                               hp.layer.self_attn.nheads)
+
+    def _norm2d(self, norm, x2, lens, T, masked):
+        return HF.rmsnorm(x2, norm.scale, norm.eps, lengths=lens if masked else None, T=T)
+
+    def run(self, tgt: TensorMask, memory: Optional[TensorMask] = None,
+            past_kv: Optional[List] = None, return_attn: bool = False,
+            return_kv: bool = False) -> Mapping[str, Any]:
+        B, T = tgt.value.shape[:2]
+        D = self.hp.layer.dim
+        dt = hipvg.compute_dtype()
+        mask, lens = tgt.mask, tgt.lengths32
+        outputs = {}
+        if return_attn:
+            outputs["self_attn"] = []
+        if return_kv:
+            outputs["kv"] = []
+        x2 = tgt.value.reshape(B * T, -1).to(dt).contiguous()
+        if self.linear is not None:
+            x2 = HF.linear(x2, self.linear.weight, self.linear.bias, lengths=lens, T=T)
+        if self.first_norm is not None:
+            x2 = self._norm2d(self.first_norm, x2, lens, T, masked=True)
+        fast = past_kv is None and not return_attn and not return_kv
+        layer_outs = []
+        if fast:
+            slopes = _slopes_from((self.rpe_id, self.rpe), None, x2.device).slopes
+            for layer in self.layers:
+                x2 = layer.forward_2d(x2, B, T, lens, slopes)
+                layer_outs.append(TensorMask(x2.view(B, T, D), mask))
+        else:
+            past = past_kv if past_kv is not None else [None] * len(self.layers)
+            rpe_pair, rpe_bias = (self.rpe_id, self.rpe), None
+            cur = TensorMask(x2.view(B, T, D), mask)
+            for layer, pkv in zip(self.layers, past):
+                res = layer(cur, memory, rpe_pair=rpe_pair, rpe_bias=rpe_bias, past_kv=pkv,
+                            return_attn=return_attn, return_kv=return_kv)
+                if "rpe_bias" in res:
+                    rpe_pair, rpe_bias = None, res["rpe_bias"]
+                if return_attn:
+                    outputs["self_attn"].append(res["self_attn"].detach())
+                if return_kv:
+                    outputs["kv"].append(res["kv"])
+                cur = res["output"]
+                layer_outs.append(cur)
+            x2 = cur.value.reshape(B * T, D)
+        if self.final_norm is not None:
+            # the reference does not re-mask here (:186-189); zero rows stay zero under RMSNorm
+            x2 = self._norm2d(self.final_norm, x2, lens, T, masked=True)
+            layer_outs.append(TensorMask(x2.view(B, T, D), mask))
+        if self.out is not None:
+            x2 = HF.linear(x2, self.out.weight, self.out.bias, lengths=lens, T=T)
+        outputs["output"] = TensorMask(x2.view(B, T, -1), mask)
+        outputs["layers"] = layer_outs
+        return outputs
+
+    def forward(self, tgt: TensorMask, memory: Optional[TensorMask] = None) -> TensorMask:
+        return self.run(tgt, memory=memory)["output"]
+
+    def custom_weight_init(self, init_std: float):
+        return None     # only T5RPE tables were initialised here in the reference (:201-204)
