@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the VAE-GSLM training step on MI355X (driver contract: see the
+task statement).  One "step" = one optimizer step of configs/train/speech/
+vae-gslm.yaml = `gradient_accumulation` (2) micro-batches of `batch_size` (8)
+sequences, each a full LVTR forward + backward (Transformer+VAE hot path on the
+HIP kernels, conv encoder / diffusion decoder on stock ops), the RCCL gradient
+all-reduce (N > 1) and the fused AdamW update.  seq_len = 1000 frames (BASELINE
+configs[1]); synthetic 50 Hz token + mel batches resident in HBM before timing.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line: tokens/s (whole job), plus
+  roofline     -- the bf16 MFMA GEMM kernel family (dominant kernel): algorithmic
+                  FLOPs / launch durations measured with HIP events on the launch
+                  stream during the timed region, against the 2.5 PFLOP/s dense peak;
+  cpu_baseline -- the CPU oracle (port of the reference's fp32 path) timed on this
+                  host's cores on a bounded sample of the same workload (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vae-gslm_amd"))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+CONFIG = os.path.join(ROOT, "vae-gslm_amd", "configs", "train", "speech", "vae-gslm.yaml")
+SEQ_LEN = 1000
+TRAIN_FLOP_PER_TOKEN = 1.3238e9      # BASELINE.md section 3 (hot path, causal-exact, 3 x forward)
+PEAK_BF16 = 2.5e15                   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def cpu_baseline(threads_note=True):
+    """Oracle (CPU port of the reference fp32 path): full config, B=1, T=1000,
+    one forward+backward after a short warm-up at T=64."""
+    import yaml
+    from oracle import lvtr_oracle as O
+    from oracle.weights import fill_like
+    with open(CONFIG) as f:
+        cfg = yaml.safe_load(f)
+    # intra-op threads: all cores up to 32 (more only adds synchronisation cost on these shapes)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    mcfg = cfg["model"]
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in fill_like(O.param_shapes(mcfg), 1).items()}
+
+    def one(T, seed):
+        g = torch.Generator().manual_seed(seed)
+        batch = dict(tokens=torch.randint(0, 200, (1, T), generator=g), mel=torch.randn(1, T, 80, generator=g),
+                     lengths=torch.tensor([T]), utt=torch.randn(1, 150, 80, generator=g),
+                     utt_lengths=torch.tensor([150]))
+        noise = dict(eps_q=torch.randn(1, T, 4, generator=g), init_state=torch.rand(1, 1, 64, generator=g) * 2 - 1,
+                     eps_p=torch.zeros(1, T, 4), t_diff=torch.randint(0, 1000, (1,), generator=g),
+                     eps_diff=torch.randn(1, T, 80, generator=g))
+        out = O.training_loss(sd, mcfg, cfg["training"], batch, noise)
+        out["loss"].backward()
+        for v in sd.values():
+            v.grad = None
+    one(64, 0)
+    # bounded sample: a quarter-length sequence first; the full 1000-frame step only
+    # if it is projected to stay within ~40 s of host time
+    T = SEQ_LEN // 4
+    t0 = time.perf_counter()
+    one(T, 1)
+    dt = time.perf_counter() - t0
+    if dt * 5 < 40.0:
+        T = SEQ_LEN
+        t0 = time.perf_counter()
+        one(T, 2)
+        dt = time.perf_counter() - t0
+    return {"value": T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 fwd+bwd, full config, B=1, T={T}, 1 step ({dt:.1f} s) after a warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, \
+        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    rank = dist.get_rank() if world > 1 else 0
+
+    import hipvg
+    from hparams.hp import Hparams
+    from trainers.speech.lvtr import LVTRTrainer
+    from training_lib.synthetic import make_batch
+
+    hipvg.lib()
+    hp = Hparams.from_yamlfile(CONFIG)
+    hp.hip.precision = args.precision
+    torch.manual_seed(1234)
+    trainer = LVTRTrainer(hp).to(device)
+    if world > 1:
+        for p in trainer.model.parameters():
+            dist.broadcast(p.data, 0)
+    trainer.configure_optimizers()
+    trainer.attach_reducer()
+    trainer.global_step = hp.training.scheduler.warmup_kld      # past the KL warm-up
+    B = hp.data.train.batch_size
+    accum = trainer.gradient_update_step
+    n_micro = (args.steps + args.warmup) * accum
+    batches = [make_batch(B, SEQ_LEN, device, seed=1234 + rank * 1000 + i) for i in range(n_micro)]
+    torch.cuda.synchronize()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup * accum):
+        trainer.training_step(batches[it], it)
+        it += 1
+    sync()
+    hipvg.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps * accum):
+        out = trainer.training_step(batches[it], it)
+        it += 1
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tokens = args.steps * accum * B * SEQ_LEN * world
+    value = tokens / elapsed
+
+    if rank == 0:
+        kinds = {}
+        tot_ms = tot_work = 0.0
+        for k in ("gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn", "gemm_f32", "attn_fwd", "attn_bwd"):
+            ms, work, n = hipvg.prof_read(k)
+            if n:
+                kinds[k] = {"launches": n, "avg_us": 1e3 * ms / n, "tflops": work / (ms * 1e-3) / 1e12}
+            if k.startswith("gemm_bf16"):
+                tot_ms += ms
+                tot_work += work
+        hipvg.prof_enable(False)
+        achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
+        line = {
+            "metric": "train tokens/sec (50 Hz frames) at seq_len=1000",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "vae-gslm.yaml full config (L=16, d=1024, H=16, ffd=4096, 227M params), "
+                                   "fwd+bwd+AdamW, micro-batch 8 x grad-accum 2 per step, seq_len 1000",
+                       "micro_batch": B, "grad_accum": accum, "seq_len": SEQ_LEN,
+                       "parallelism": f"dp{world}", "loss": float(out["loss"])},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
+                         "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                         "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
+                         "step_model_tflops": value / world * TRAIN_FLOP_PER_TOKEN / 1e12,
+                         "step_model_frac": value / world * TRAIN_FLOP_PER_TOKEN / PEAK_BF16,
+                         "kernels": kinds},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,6 +158,16 @@ int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, in
 /* fp32 -> bf16 copy (weights shadow) */
 int vg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vg_stream_t stream);
 
+/* ---------------------------------------------------------------- measurement hooks
+ * Optional HIP-event timing of the GEMM / attention launches (bench.py's roofline
+ * figure).  vg_prof_enable(1) clears and starts recording, vg_prof_enable(0)
+ * stops; vg_prof_read() synchronises and returns, for one kind, the summed
+ * launch durations (ms), the summed ALGORITHMIC work (FLOPs) and the launch count. */
+enum { VG_PROF_GEMM_BF16_NT = 0, VG_PROF_GEMM_BF16_NN = 1, VG_PROF_GEMM_BF16_TN = 2,
+       VG_PROF_GEMM_F32 = 3, VG_PROF_ATTN_FWD = 4, VG_PROF_ATTN_BWD = 5 };
+int vg_prof_enable(int on);
+int vg_prof_read(int kind, double* total_ms, double* total_work, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

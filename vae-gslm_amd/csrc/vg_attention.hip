@@ -444,8 +444,11 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
                const int32_t* lengths, hipStream_t stream) {
   const size_t lds = LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
   dim3 grid((Tn + QB - 1) / QB, H, B);
+  // algorithmic work: causal-exact QK^T + PV, 2*2*64 FLOP per (query, key <= query) pair
+  const int tok = vg_host::prof_begin(VG_PROF_ATTN_FWD, 256.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
                      lengths);
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_fwd");
 }
 
@@ -453,6 +456,8 @@ template <typename T>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
                void* dqkv, float* delta, int B, int Tn, int H, const int32_t* lengths, hipStream_t stream) {
   const long nthreads = (long)B * Tn * H * 8;
+  // algorithmic work of the backward: 5 products (S, dP, dV, dK, dQ) = 2.5 x forward
+  const int tok = vg_host::prof_begin(VG_PROF_ATTN_BWD, 640.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
                      (const T*)out, (const T*)dout, delta, B, Tn, H);
   dim3 grid((Tn + QB - 1) / QB, H, B);
@@ -468,6 +473,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   }
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, dim3(256), lds_k, stream, (const T*)qkv, (const T*)dout, lse,
                      delta, slopes, (T*)dqkv, Tn, H, lengths);
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_bwd");
 }
 

@@ -211,6 +211,9 @@ VG_DEVICE bool row_valid(const int* __restrict__ lengths, int T, int m) {
 namespace vg_host {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// optional HIP-event timing (vg_prof.hip); kinds are the VG_PROF_* enum of the public header
+int prof_begin(int kind, double work, hipStream_t stream);
+void prof_end(int token, hipStream_t stream);
 }  // namespace vg_host
 
 #define VG_REQUIRE(cond, ...)                 \

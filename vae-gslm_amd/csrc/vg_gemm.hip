@@ -217,7 +217,11 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_t stre
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done[ti][ki] = true;
   }
+  const int kind = sizeof(T) == 4 ? VG_PROF_GEMM_F32
+                    : (a_tr ? VG_PROF_GEMM_BF16_TN : (b_tr ? VG_PROF_GEMM_BF16_NN : VG_PROF_GEMM_BF16_NT));
+  const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream);
   hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_gemm");
 }
 

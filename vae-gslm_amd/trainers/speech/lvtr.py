@@ -1,0 +1,154 @@
+"""VAE-GSLM trainer: loss assembly and the optimisation step.
+
+Mirrors the reference ``trainers/speech/lvtr.py`` (``LVTRTrainer`` :14-180):
+same hparams, same KL-weight schedule, same total loss
+``rec * rec_scale + kld * w + ce * token_kld_weight * w``, manual optimisation
+with gradient accumulation, same logged scalar names.  Differences:
+
+* no Lightning: ``training_step`` is called by ``scripts/train.py``; data
+  parallelism is the bucketed RCCL reducer (``training_lib/dp.py``), which
+  all-reduces once per optimizer step instead of once per micro-batch (the
+  mean over ranks is linear, so the update is the same);
+* the HiFi-GAN vocoder is only consulted for ``n_mels`` in the reference's
+  training path (:32-34); when no vocoder checkpoint directory exists a stub
+  with ``n_mels = 80`` is used so training does not depend on that file;
+* the KL sum comes fused from the model (``out['kld']``).
+"""
+from __future__ import annotations
+
+import os
+from typing import Mapping, Optional
+
+import torch
+import yaml
+
+from hparams.hp import Hparams
+from models.speech.lvtr import LVTR
+from training_lib.dp import GradReducer
+from training_lib.optimizer import create_optimizer
+from training_lib.trainer import BaseTrainer
+
+
+def _vocoder_hparams(path: str) -> Hparams:
+    cfg = os.path.join(path, "hp.yaml")
+    if os.path.exists(cfg):
+        return Hparams.from_yamlfile(cfg)
+    return Hparams(n_mels=80, sample_rate=16000)
+
+
+class LVTRTrainer(BaseTrainer):
+    def __init__(self, hp: Hparams) -> None:
+        super().__init__(hp)
+        hp.check_arg_in_hparams("vocoder")
+        hp.vocoder.check_arg_in_hparams("path")
+        tr = hp.training
+        self.rec_loss_scale = tr.get("rec_loss_scale", 1.0)
+        self.kld_scale = tr.get("kld_scale", 1.0)
+        self.fixed_beta = tr.get("fixed_beta", None)
+        if self.fixed_beta is not None:
+            if tr.get("scale_rec_beta", True):
+                self.rec_loss_scale *= 1 - self.fixed_beta
+            self.kld_scale *= self.fixed_beta
+        self.mel_rescale = tr.get("mel_rescale", None)
+        self.vocoder_hp = _vocoder_hparams(hp.vocoder.path)
+        self.model = LVTR(hp.model, input_dim=self.vocoder_hp.n_mels)
+        self.apply(self.init_weights)
+        self.zero_kld = tr.scheduler.get("zero_kld", 0)
+        self.warmup_kld = tr.scheduler.get("warmup_kld", 0)
+        self.entropy_weight = tr.get("entropy_weight", 1.0)
+        self.use_tokens = self.model.use_tokens
+        self.token_kld_weight = tr.get("token_kld_weight", 1.0)
+        self.optimizer = self.scheduler = self.reducer = None
+
+    # ------------------------------------------------------------ optimisation plumbing
+    def configure_optimizers(self):
+        opt, sch = create_optimizer(self.hp.training, self.model.parameters(), self.hp.trainer.total_steps)
+        self.optimizer, self.scheduler = opt, sch["scheduler"]
+        return [opt], [sch]
+
+    def attach_reducer(self, group=None) -> GradReducer:
+        hip = self.hp.get("hip", None)
+        bucket = hip.get("bucket_mb", 50) if hip is not None else 50
+        overlap = hip.get("overlap", True) if hip is not None else True
+        self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group)
+        return self.reducer
+
+    def current_kld_weight(self) -> float:
+        w = self.kld_scale
+        step = self.global_step
+        if self.warmup_kld > 0 and self.zero_kld < step + 1 <= self.warmup_kld:
+            w = self.kld_scale * ((step - self.zero_kld) / self.warmup_kld)
+        if self.zero_kld > 0 and step <= self.zero_kld:
+            w = 0.0
+        return w
+
+    # ------------------------------------------------------------ one micro-batch
+    def _training_loop(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
+        kld_weight = self.current_kld_weight()
+        kwargs = {}
+        if self.model.utterance_encoder is not None:
+            kwargs["utterance"] = batch["cropped_mel_utt"]
+        if "cropped_mel" in batch:
+            kwargs["diff_input"] = batch["cropped_mel"]
+        model_input = batch["mel"]
+        if self.use_tokens:
+            model_input = batch["tokens"].expand().cat(batch["mel"])
+        out = self.model(model_input, noise=noise, **kwargs)
+        kld = out["kld"] * self.entropy_weight if self.entropy_weight == 1.0 else None
+        if kld is None:   # non-default entropy weighting: generic path
+            from training_lib.losses import masked_loss
+            kld = masked_loss(out["log_q"] * self.entropy_weight, out["log_p"], fn=lambda a, b: a - b)
+        rec = out["decoder_output"]
+        loss = rec * self.rec_loss_scale + kld * kld_weight
+        if self.use_tokens:
+            loss = loss + out["ce_loss"] * (self.token_kld_weight * kld_weight)
+        loss.backward()
+        result = {"kld": kld.detach(), "rec_loss": rec.detach(), "log_p": -out["log_p"].mean().detach(),
+                  "length": out["log_p"].length.sum(), "kld_weight": kld_weight,
+                  "logstd": out["logstd"].detach(), "q_logstd": out["q_logstd"].detach(),
+                  "log_q": -out["log_q"].mean().detach(), "q_mean_abs": out["q_mean_abs"].detach(),
+                  "loss": loss.detach()}
+        if self.use_tokens:
+            result["token_kld"] = out["ce_loss"].detach()
+        return result
+
+    def training_step(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
+        last = (batch_idx + 1) % self.gradient_update_step == 0
+        if self.reducer is not None:
+            self.reducer.sync_now = last
+        out = self._training_loop(batch, batch_idx, noise)
+        if last:
+            if self.reducer is not None:
+                self.reducer.finish()
+            clip = self.hp.training.get("gradient_clip_val", None)
+            if clip is not None:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
+            self.optimizer.step()
+            if self.reducer is not None:
+                self.reducer.zero_grad()
+            else:
+                self.optimizer.zero_grad(set_to_none=True)
+            n = out["length"]
+            self.log("train/kld", out["kld"] / n)
+            self.log("train/rec_loss", out["rec_loss"] / n)
+            self.log("train/kld_weight", out["kld_weight"])
+            self.log("train/z_given_logstd", out["logstd"])
+            self.log("train/q_logstd", out["q_logstd"])
+            self.log("train/q_entropy", out["log_q"])
+            self.log("train/q_mean_abs", out["q_mean_abs"])
+            self.log("train/cross_entropy", out["log_p"])
+            self.log("train/lr", self.scheduler.get_last_lr()[0])
+            if self.use_tokens:
+                self.log("train/token_kld", out["token_kld"] / n)
+            self.scheduler.step()
+            self.global_step += 1
+        return out
+
+    # ------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, filepath: str) -> None:
+        """Compact checkpoint = ``LVTR.state_dict()`` (reference :294-296)."""
+        torch.save(self.model.state_dict(), filepath)
+
+    def save_hparams(self, directory: str) -> None:
+        with open(os.path.join(directory, "hp.yaml"), "w") as f:
+            yaml.dump(self.hp.to_dict(), f)
