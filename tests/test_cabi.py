@@ -1,0 +1,73 @@
+"""The C-ABI library loads and exports every symbol include/vaegslm_hip.h
+declares; the ctypes table in hipvg covers exactly that set.  No compute
+calls (runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vaegslm_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(vg_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from hipvg.build import build
+    return build(force=False, verbose=False)
+
+
+def test_header_symbols_exported(built_lib):
+    handle = ctypes.CDLL(built_lib)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in the header but not exported"
+
+
+def test_ctypes_table_matches_header(built_lib):
+    import hipvg
+    assert sorted(hipvg.SIGNATURES) == declared_symbols()
+    lib = hipvg.lib()
+    assert lib.vg_version() >= 100
+    assert lib.vg_rmsnorm_bwd_blocks(8000) == 512 and lib.vg_colsum_blocks(100) == 4
+    assert hipvg.last_error() == ""
+
+
+def test_gemm_descriptor_layout_matches_header():
+    """Field order/types of the ctypes mirror == the C struct (parsed from the header)."""
+    import hipvg
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct vg_gemm_desc \{(.*?)\} vg_gemm_desc;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = [n.strip().lstrip("*") for n in decl.split(",")]
+        names[0] = names[0].split()[-1].lstrip("*")
+        fields += names
+    assert fields == [f[0] for f in hipvg.GemmDesc._fields_]
+
+
+def test_product_refuses_cpu_tensors(built_lib):
+    """No CPU fallback: HIP wrappers raise on host tensors instead of computing."""
+    import torch
+    from hipvg import functional as HF
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HF.rmsnorm(torch.randn(4, 256), torch.ones(256), 1e-6)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import hipvg
+    monkeypatch.setattr(hipvg, "_lib", None)
+    monkeypatch.setattr(hipvg, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        hipvg.lib()

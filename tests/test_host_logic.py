@@ -1,0 +1,147 @@
+"""Host-side logic of the drop-in layer (CPU only): TensorMask semantics,
+Hparams, the yaml, ALiBi slopes, LR / KL-weight schedules, state-dict layout."""
+import copy
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from hparams.hp import Hparams
+from utils.tensormask import TensorMask
+
+REF = "/root/reference"
+
+
+def test_tensormask_shift_and_mask():
+    x = torch.arange(2 * 5 * 3, dtype=torch.float32).reshape(2, 5, 3) + 1
+    tm = TensorMask.fromlength(x, torch.tensor([5, 3]))
+    assert tm.length.tolist() == [5, 3]
+    assert tm.lengths32.dtype == torch.int32 and tm.lengths32.tolist() == [5, 3]
+    masked = tm.apply_mask()
+    assert torch.all(masked.value[1, 3:] == 0) and torch.equal(masked.value[0], x[0])
+    init = torch.full((2, 1, 3), -7.0)
+    sh = tm.push(init).pop(1).apply_mask()          # shift right by one frame, lengths unchanged
+    assert sh.length.tolist() == [5, 3]
+    assert torch.equal(sh.value[:, 0], init[:, 0]) and torch.equal(sh.value[0, 1:], x[0, :4])
+    assert torch.all(sh.value[1, 3:] == 0) and torch.equal(sh.value[1, 1:3], x[1, :2])
+    a, b = tm.split(1)
+    assert a.value.shape == (2, 5, 1) and b.value.shape == (2, 5, 2)
+    cat = TensorMask(x[..., 0], tm.mask).expand().cat(b)
+    assert torch.equal(cat.value, x)
+    assert abs(float(tm.mean()) - float((masked.value.sum() / 3) / 8)) < 1e-6
+    assert TensorMask(x).lengths32 is None           # all-valid masks need no predicate
+    assert (tm + 1.0).value[0, 0, 0] == 2.0 and (tm / 2.0).value[0, 0, 0] == 0.5
+    assert tm.transpose().axis == 2
+    with pytest.raises(AssertionError):
+        TensorMask(x, torch.ones(2, 4, dtype=torch.bool))
+
+
+def test_hparams_contract(tmp_path):
+    hp = Hparams.from_dict({"a": 1, "b": {"c": [1, {"d": 2}], "e": None}})
+    assert hp.b.c[1].d == 2 and hp.get("zz", 5) == 5 and hp.has("a") and not hp.b.has("zz")
+    with pytest.raises(ValueError):
+        hp.check_arg_in_hparams("a", "missing")
+    p = tmp_path / "hp.yaml"
+    hp.save(str(p))
+    assert Hparams.from_yamlfile(str(p)) == hp
+    assert hp.merge(Hparams(z=3)).z == 3
+
+
+def test_yaml_matches_reference_values(full_cfg):
+    if not os.path.exists(REF):
+        pytest.skip("reference tree not present")
+    with open(os.path.join(REF, "configs/train/speech/vae-gslm.yaml")) as f:
+        ref = yaml.safe_load(f)
+    mine = {k: v for k, v in full_cfg.items() if k != "hip"}
+    assert mine == ref
+
+
+def test_alibi_slopes_closed_form():
+    from hipvg.functional import alibi_slopes
+    from modules.position.alibi import ALiBi
+    assert np.allclose(alibi_slopes(16), [2 ** (-(h + 1) / 2) for h in range(16)])
+    assert np.allclose(ALiBi(16).slopes.numpy(), alibi_slopes(16))
+    assert len(alibi_slopes(12)) == 12 and np.allclose(ALiBi(12).slopes.numpy(), alibi_slopes(12))
+    d = ALiBi(4).dense_bias(2, 5)
+    assert d.shape == (4, 2, 5) and float(d[0, 1, 4]) == 0.0 and float(d[0, 0, 0]) == -3 * alibi_slopes(4)[0]
+
+
+def test_lr_and_kl_schedules(full_cfg):
+    from training_lib.optimizer import create_optimizer
+    hp = Hparams.from_dict(copy.deepcopy(full_cfg))
+    w, b = torch.nn.Parameter(torch.zeros(4, 4)), torch.nn.Parameter(torch.zeros(4))
+    hp.training.scheduler.flat_steps = 5
+    opt, sch = create_optimizer(hp.training, [w, b], total_steps=25)
+    assert [g["weight_decay"] for g in opt.param_groups] == [0.1, 0]
+    lrs = []
+    for _ in range(25):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch["scheduler"].step()
+    assert all(abs(v - 5e-4) < 1e-12 for v in lrs[:5])
+    expect = [5e-5 + (5e-4 - 5e-5) * (1 + math.cos(math.pi * i / 20)) / 2 for i in range(20)]
+    assert np.allclose(lrs[5:], expect, rtol=1e-6)
+    # KL warm-up: trainers/speech/lvtr.py:104-110 of the reference
+    from oracle.lvtr_oracle import kld_weight
+    t = full_cfg["training"]
+    assert kld_weight(0, t) == 0.0 and abs(kld_weight(15000, t) - 0.02) < 1e-12
+    assert kld_weight(29999, t) == pytest.approx(0.04 * 29999 / 30000) and kld_weight(30000, t) == 0.04
+
+
+def test_reference_schedule_equivalence(full_cfg):
+    """Same LR trajectory as the reference's own scheduler factory (pure torch, importable)."""
+    if not os.path.exists(REF):
+        pytest.skip("reference tree not present")
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("ref_optimizer", os.path.join(REF, "training_lib/optimizer.py"))
+    sys.dont_write_bytecode = True
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from training_lib.optimizer import create_optimizer
+    traj = []
+    for factory in (mod.create_optimizer, create_optimizer):
+        hp = Hparams.from_dict(copy.deepcopy(full_cfg))
+        hp.training.scheduler.flat_steps = 7
+        p = [torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(3))]
+        opt, sch = factory(hp.training, p, 40)
+        out = []
+        for _ in range(40):
+            out.append(opt.param_groups[1]["lr"])
+            opt.step()
+            sch["scheduler"].step()
+        traj.append(out)
+    assert np.allclose(traj[0], traj[1], rtol=1e-9)
+
+
+def test_model_state_dict_layout(full_cfg):
+    """Parameter names/shapes are those of the reference (golden key list + oracle inventory)."""
+    from models.speech.lvtr import LVTR
+    from oracle.lvtr_oracle import param_shapes
+    model = LVTR(Hparams.from_dict(copy.deepcopy(full_cfg["model"])), input_dim=80)
+    sd = model.state_dict()
+    want = dict(param_shapes(full_cfg["model"]))
+    got = {k: tuple(v.shape) for k, v in sd.items()
+           if not (k.startswith("decoder.") and not k.startswith("decoder.model."))}
+    assert got == want
+    assert sum(p.numel() for p in model.parameters()) == 226_957_564
+    assert "transformer.0.rpe.slopes" not in sd          # non-persistent, like the reference's alibi buffer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "step_full.npz"))
+    assert sorted(got) == list(g["keys"])
+
+
+def test_unsupported_paths_raise():
+    from modules.position.embedding import get_positional_encoding
+    from modules.norm import get_norm_fn
+    from modules.activations import get_activation
+    with pytest.raises(ValueError):
+        get_positional_encoding("nope", Hparams())
+    with pytest.raises(NotImplementedError):
+        get_positional_encoding("Rotery", Hparams(), ndim=64)
+    with pytest.raises(ValueError):
+        get_norm_fn(8, Hparams(identifier="nope"))
+    with pytest.raises(ValueError):
+        get_activation(Hparams(identifier="nope"))
