@@ -71,6 +71,7 @@ typedef struct vg_gemm_desc {
   int accumulate;       /* C += (fp32 C, split_k == 1) */
   int split_k;
   float alpha;
+  int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..4 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 */
 } vg_gemm_desc;
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 

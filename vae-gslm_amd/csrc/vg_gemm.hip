@@ -18,6 +18,7 @@
 // MFMAs that hide them (one barrier per K tile).
 #include "vg_common.h"
 #include "../../include/vaegslm_hip.h"
+#include "vg_gemm_params.h"
 
 using namespace vg;
 
@@ -25,23 +26,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 constexpr int TILE_BYTES = 128 * 33 * 4;   // largest image (f32 RowTile 128 x (32+1))
-
-struct GemmParams {
-  const void* A; const void* B; void* C;
-  int M, N, K;
-  long lda, ldb, ldc;
-  const float* bias;        // [N] fp32 or null
-  const void* residual;     // [M][ldc] (type T) or null
-  const void* aux_in;       // [M][ldc] (type T): input of the activation derivative
-  void* aux_out;            // [M][ldc] (type T): pre-activation copy
-  const int* lengths; int T;
-  int act;                  // VG_ACT_*
-  int dact;                 // VG_ACT_* derivative applied to the result (uses aux_in)
-  int out_f32;              // C is fp32 regardless of T
-  int accumulate;           // C += result (fp32 C only)
-  int k_per_split;          // K range handled by one blockIdx.z (multiple of BK)
-  float alpha;
-};
 
 template <typename T> struct BKOf;
 template <> struct BKOf<bf16_t> { static constexpr int v = 64; };
@@ -202,7 +186,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 }
 
 template <typename T>
-int launch(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_t stream) {
+int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hipStream_t stream) {
+  const int kind = sizeof(T) == 4 ? VG_PROF_GEMM_F32
+                    : (a_tr ? VG_PROF_GEMM_BF16_TN : (b_tr ? VG_PROF_GEMM_BF16_NN : VG_PROF_GEMM_BF16_NT));
+  if (sizeof(T) == 2 && tile_cfg > 0) {   // LDS-DMA pipelined variant (vg_gemm_dma.hip)
+    const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream);
+    const int rc = vg_host::gemm_dma_launch(p, a_tr, b_tr, tile_cfg, splits, stream);
+    vg_host::prof_end(tok, stream);
+    if (rc == 0) return vg_host::check_launch("vg_gemm(dma)");
+  }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
   dim3 block(NTHREADS);
   const size_t lds = 4 * TILE_BYTES;
@@ -217,8 +209,6 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_t stre
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done[ti][ki] = true;
   }
-  const int kind = sizeof(T) == 4 ? VG_PROF_GEMM_F32
-                    : (a_tr ? VG_PROF_GEMM_BF16_TN : (b_tr ? VG_PROF_GEMM_BF16_NN : VG_PROF_GEMM_BF16_NT));
   const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream);
   hipLaunchKernelGGL(k, grid, block, lds, stream, p);
   vg_host::prof_end(tok, stream);
@@ -252,6 +242,19 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   kps = ((kps + bk - 1) / bk) * bk;
   splits = (d->K + kps - 1) / kps;
   p.k_per_split = kps;
-  if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, stream);
-  return launch<float>(p, d->a_tr, d->b_tr, splits, stream);
+  // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
+  int cfg = d->tile_cfg;
+  const bool dma_ok = d->dtype == VG_BF16 && d->K % 64 == 0 && !(d->a_tr && !d->b_tr) &&
+                      (long)(d->a_tr ? d->K : d->M) * d->lda * 2 < 0x7fffffffL &&
+                      (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7fffffffL;
+  if (!dma_ok) cfg = -1;
+  else if (cfg == 0) {
+    // measured on MI355X at M = 8000 (tools/gemm_bench.py): 128x128 wins or ties everywhere except
+    // the long-K / narrow-N forward GEMM (128x256) and the wide-N dgrad (256x256)
+    cfg = 1;
+    if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048) cfg = 4;
+    if (!d->a_tr && d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
+  }
+  if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, cfg, stream);
+  return launch<float>(p, d->a_tr, d->b_tr, splits, -1, stream);
 }

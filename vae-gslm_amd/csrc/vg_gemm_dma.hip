@@ -1,0 +1,271 @@
+// bf16 MFMA GEMM, LDS-DMA pipelined variant (the fast path of vg_gemm).
+//
+// Same operand modes, LDS images and epilogue as vg_gemm.hip, but the global->LDS
+// staging uses `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per wave-instruction,
+// no VGPR round trip, hardware range check = zero fill past the end of the
+// buffer).  The LDS images stay swizzled: the DMA writes lane-linear, so the
+// swizzle is applied to each lane's SOURCE address and undone by the same XOR on
+// the fragment reads (both-sides rule).
+//
+// Pipeline (one barrier per K tile): the tile for step k+1 is issued right after
+// the barrier that publishes tile k, and lands while the MFMAs of tile k run.
+// Tile shapes are template parameters; the host picks per problem shape.
+#include "vg_common.h"
+#include "../../include/vaegslm_hip.h"
+#include "vg_gemm_params.h"
+
+using namespace vg;
+
+namespace {
+
+constexpr int BK = 64;
+
+// ---- issue the LDS-DMA loads of one operand tile
+//  ROW image: [R rows][128 B], chunk position p of row r holds source chunk p ^ ((r >> 1) & 7)
+//  TR  image: R/128 sub-images of [64 krows][256 B]; 64-B granule position g of krow k holds
+//             source granule g ^ (k & 3)
+template <bool TR, int R, int NW>
+VG_DEVICE void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, long ld_bytes, int rc0, int k0, int wave, int lane) {
+  constexpr int PER_WAVE = (R / 8) / NW;
+  static_assert(PER_WAVE >= 1, "tile too small for the wave count");
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int piece = j * NW + wave;           // 1-KiB piece index inside the tile
+    unsigned voff;
+    if constexpr (!TR) {
+      const int row = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      voff = (unsigned)((long)(rc0 + row) * ld_bytes + (long)(k0 + chunk * 8) * 2);
+    } else {
+      const int sub = piece >> 4;              // 128-column sub-image
+      const int krow = (piece & 15) * 4 + (lane >> 4);
+      const int p16 = lane & 15;
+      const int gran = (p16 >> 2) ^ (krow & 3);
+      const int col = sub * 128 + gran * 32 + (p16 & 3) * 8;
+      voff = (unsigned)((long)(k0 + krow) * ld_bytes + (long)(rc0 + col) * 2);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(void, tile + piece * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+template <bool TR>
+VG_DEVICE bf16x8 frag_of(const char* tile, int rc, int s, int lane) {
+  // rc = first row/col of this wave's 32-wide MFMA tile inside the block tile
+  if constexpr (!TR) return RowTile<bf16_t, 64>::frag(tile, rc + (lane & 31), s, lane);
+  else return TrTile<bf16_t, 128>::template frag<false>(tile + (rc >> 7) * (64 * 256), 0, rc & 127, s, lane);
+}
+
+// ---- per-lane epilogue for 8 consecutive columns of one output row
+VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, float (&v)[8]) {
+  const long idx = (long)m * p.ldc + n;
+  if (split) {   // partial sums of a split-K wgrad: raw fp32 accumulation
+    float* c = reinterpret_cast<float*>(p.C) + idx;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
+    return;
+  }
+  if (p.bias) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+  }
+  if (p.aux_out) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx) = o;
+  }
+  if (p.act == VG_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if (p.act == VG_ACT_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+  }
+  if (p.dact != VG_ACT_NONE) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux_in) + idx);
+    if (p.dact == VG_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((float)a[e] > 0.f) ? v[e] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)a[e]);
+    }
+  }
+  if (p.residual) {
+    const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.residual) + idx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+  }
+  if (!row_valid(p.lengths, p.T, m)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  }
+  if (p.out_f32) {
+    f32x4* c = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx);
+    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+    if (p.accumulate) { o0 += c[0]; o1 += c[1]; }
+    c[0] = o0;
+    c[1] = o1;
+  } else {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
+  }
+}
+
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware remap (bijective): blocks that share an XCD get a contiguous run of tiles,
+  // n fastest, so the A row-panel and the B panels they share stay in that XCD's L2.
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int nwg = ntn * ntm;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nkt = (kend - kbeg) / BK;
+
+  const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+  const long a_rows = A_TR ? p.K : p.M, b_rows = B_TR ? p.K : p.N;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0,
+                                                                (int)min(a_rows * lda_b, 0x7fffffffL), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0,
+                                                                (int)min(b_rows * ldb_b, 0x7fffffffL), 0x00020000);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
+
+  dma_tile<A_TR, BM, NW>(ra, smem, lda_b, m0, kbeg, wave, lane);
+  dma_tile<B_TR, BN, NW>(rb, smem + A_BYTES, ldb_b, n0, kbeg, wave, lane);
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE;
+    __builtin_amdgcn_s_waitcnt(0x0F70 & 0x3F70);   // vmcnt(0): this wave's pieces of tile kt landed
+    __syncthreads();                               // ... everyone's did, and tile kt-1 is no longer read
+    if (kt + 1 < nkt) {
+      char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      dma_tile<A_TR, BM, NW>(ra, nxt, lda_b, m0, kbeg + (kt + 1) * BK, wave, lane);
+      dma_tile<B_TR, BN, NW>(rb, nxt + A_BYTES, ldb_b, n0, kbeg + (kt + 1) * BK, wave, lane);
+    }
+    const char* ta = cur;
+    const char* tb = cur + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = frag_of<A_TR>(ta, wm * (BM / WM) + i * 32, s, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = frag_of<B_TR>(tb, wn * (BN / WN) + j * 32, s, lane);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // ------------------------------------------------------------ epilogue (same contract as vg_gemm.hip)
+  // Each wave transposes its accumulators through a private LDS strip ([32 rows][TN*32 cols])
+  // so that every lane owns 8 consecutive columns of one row: residual / aux loads and the
+  // result stores are 16-byte, row-contiguous accesses.
+  constexpr int SW = TN * 32 + 4;          // strip pitch in floats (16-byte aligned rows)
+  constexpr int CPR = TN * 4;              // 8-column chunks per strip row
+  constexpr int RPP = 64 / CPR;            // rows covered per pass
+  static_assert(NW * 32 * SW * 4 <= 2 * STAGE, "epilogue strips must fit in the stage buffers");
+  const bool split = gridDim.z > 1;
+  if (split) {
+    // split-K partial sums (weight gradients): fp32 atomics straight from the accumulator
+    // layout -- one wave-instruction adds two 128-byte row segments, the shape the
+    // memory-side atomic units take at full rate.
+    float* __restrict__ c = reinterpret_cast<float*>(p.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + acc_row(rr, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+          if (m < p.M && n < p.N) atomicAdd(c + (long)m * p.ldc + n, acc[i][j][rr] * p.alpha);
+        }
+      }
+    return;
+  }
+  __syncthreads();                         // every wave is done reading the last stage
+  float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SW);
+  const int crow = lane / CPR, cch = lane % CPR;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) strip[acc_row(rr, lane) * SW + j * 32 + (lane & 31)] = acc[i][j][rr] * p.alpha;
+    for (int ps = 0; ps < 32 / RPP; ++ps) {
+      const int rloc = ps * RPP + crow;
+      const int m = m0 + wm * (BM / WM) + i * 32 + rloc;
+      const int n = n0 + wn * (BN / WN) + cch * 8;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
+      if (m >= p.M || n >= p.N) continue;
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      epilogue_emit(p, split, m, n, v);
+    }
+  }
+}
+
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmParams& p, int splits, hipStream_t stream) {
+  constexpr size_t lds = 2 * (BM + BN) * BK * 2;
+  auto k = gemm_dma_kernel<A_TR, B_TR, BM, BN, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(WM * WN * 64), lds, stream, p);
+  return 0;
+}
+
+template <bool A_TR, bool B_TR>
+int launch_mode(const GemmParams& p, int cfg, int splits, hipStream_t stream) {
+  switch (cfg) {
+    case 1: return launch_cfg<A_TR, B_TR, 128, 128, 2, 2>(p, splits, stream);
+    case 2: return launch_cfg<A_TR, B_TR, 256, 128, 4, 2>(p, splits, stream);
+    case 3: return launch_cfg<A_TR, B_TR, 256, 256, 2, 4>(p, splits, stream);
+    case 4: return launch_cfg<A_TR, B_TR, 128, 256, 2, 4>(p, splits, stream);
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+namespace vg_host {
+// returns 0 if launched, -1 if this variant does not apply (caller falls back)
+int gemm_dma_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits, hipStream_t stream) {
+  if (cfg <= 0) return -1;
+  if (!a_tr && !b_tr) return launch_mode<false, false>(p, cfg, splits, stream);
+  if (!a_tr && b_tr) return launch_mode<false, true>(p, cfg, splits, stream);
+  if (a_tr && b_tr) return launch_mode<true, true>(p, cfg, splits, stream);
+  return -1;
+}
+}  // namespace vg_host

@@ -1,0 +1,25 @@
+// Kernel-side parameter block shared by the GEMM variants (vg_gemm.hip, vg_gemm_dma.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GemmParams {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  const float* bias;        // [N] fp32 or null
+  const void* residual;     // [M][ldc] (type T) or null
+  const void* aux_in;       // [M][ldc] (type T): input of the activation derivative
+  void* aux_out;            // [M][ldc] (type T): pre-activation copy
+  const int* lengths; int T;
+  int act;                  // VG_ACT_*
+  int dact;                 // VG_ACT_* derivative applied to the result (uses aux_in)
+  int out_f32;              // C is fp32 regardless of T
+  int accumulate;           // C += result (fp32 C only)
+  int k_per_split;          // K range handled by one blockIdx.z (multiple of BK)
+  float alpha;
+};
+
+namespace vg_host {
+// LDS-DMA pipelined bf16 variant; returns 0 if launched, -1 if not applicable
+int gemm_dma_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits, hipStream_t stream);
+}

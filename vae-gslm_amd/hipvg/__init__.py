@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp), ("aux_in", _vp), ("aux_out", _vp),
                 ("lengths", _vp), ("T", _i),
                 ("act", _i), ("dact", _i), ("out_f32", _i), ("accumulate", _i),
-                ("split_k", _i), ("alpha", _f)]
+                ("split_k", _i), ("alpha", _f), ("tile_cfg", _i)]
 
 
 # name -> argtypes (restype is always int); must list EVERY symbol of the header

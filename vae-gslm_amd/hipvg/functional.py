@@ -49,7 +49,7 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
          residual: Optional[Tensor] = None, aux_in: Optional[Tensor] = None,
          aux_out: Optional[Tensor] = None, lengths: Optional[Tensor] = None, T: int = 0,
          act: int = ACT_NONE, dact: int = ACT_NONE, accumulate=False, split_k: int = 1,
-         alpha: float = 1.0) -> Tensor:
+         alpha: float = 1.0, tile_cfg: int = 0) -> Tensor:
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
     if out is None:
@@ -66,6 +66,7 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
     d.act, d.dact = act, dact
     d.out_f32 = int(out.dtype == torch.float32)
     d.accumulate, d.split_k, d.alpha = int(accumulate), int(split_k), float(alpha)
+    d.tile_cfg = int(tile_cfg)
     check(lib().vg_gemm(C.byref(d), stream()), "vg_gemm")
     return out
 
