@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the attention kernels (forward, backward) at the full-config
+shape; algorithmic (causal-exact) FLOPs.  GPU only."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vae-gslm_amd"))
+import torch
+
+import hipvg
+from hipvg import functional as F
+
+dev = torch.device("cuda:0")
+ITERS = int(os.environ.get("ITERS", "20"))
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(ITERS):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / ITERS * 1e-3
+
+
+def main():
+    hipvg.lib()
+    H = 16
+    D = H * 64
+    for (B, T) in [(8, 250), (8, 500), (8, 1000), (4, 2000)]:
+        g = torch.Generator(device="cpu").manual_seed(0)
+        qkv = torch.randn(B * T, 3 * D, generator=g).to(dev).bfloat16()
+        dout = torch.randn(B * T, D, generator=g).to(dev).bfloat16()
+        slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev)
+        out = torch.empty(B * T, D, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        L = hipvg.lib()
+        st = hipvg.stream()
+        p = hipvg.ptr
+        fwd = lambda: L.vg_attn_fwd(p(qkv), p(out), p(lse), p(slopes), B, T, H, None, 1, st)
+        bwd = lambda: L.vg_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(slopes), p(dqkv), p(delta), B, T, H, None, 1, st)
+        fl = 256.0 * B * H * 0.5 * T * (T + 1)
+        tf, tb = timeit(fwd), timeit(bwd)
+        print(f"B={B} T={T}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF | bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    main()

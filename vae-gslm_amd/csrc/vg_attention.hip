@@ -117,11 +117,44 @@ template <typename T> struct LdsPlan {
   static constexpr int TR_BYTES = sizeof(T) == 2 ? TB * 128 : TB * DH * 4;
 };
 
+// exp2 of a non-positive argument: raw v_exp_f32 for the bf16 path, accurate exp2f for fp32 parity
+template <typename T> VG_DEVICE float fexp2(float x) {
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(x);
+  else return exp2f(x);
+}
+
+VG_DEVICE float max16(const f32x16& s) {
+  float a = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+  float b = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+  float c = fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11]));
+  float d = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// 16 per-row constants (rows of the accumulator map) from an LDS float array
+VG_DEVICE f32x16 rows16(const float* arr, int row0, int lane) {
+  f32x16 r;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(arr + row0 + 8 * g + 4 * (lane >> 5));
+    r[4 * g] = v[0]; r[4 * g + 1] = v[1]; r[4 * g + 2] = v[2]; r[4 * g + 3] = v[3];
+  }
+  return r;
+}
+
 // =====================================================================================
 // forward
+//
+// Scores are kept in raw q.k units inside the accumulators; the ALiBi term is
+// split into (a) a loop-invariant per-register constant 8*slope*row (the MFMA's
+// initial accumulator -> free), (b) a per-tile scalar slope2*(tile start - wave's
+// first query) added inside the exp2 argument, (c) a per-lane constant that
+// softmax is invariant to (restored in the stored LSE).  Positions are taken
+// relative to the wave's first query so the large distances only appear where
+// the probability underflows anyway.  Causal compares run on diagonal tiles only.
 // =====================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const float* __restrict__ slopes,
                                                        int Tn, int H, const int* __restrict__ lengths) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,8 +181,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 
   RowRegs<T> qf;
   qf.load(base + (long)min(query, Tn - 1) * rs, lane);
-  const float slope2 = slopes[h] * LOG2E;
-  const float c2 = SCALE * LOG2E;
+  const float slope = slopes[h];
+  const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
+  f32x16 kinit;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) kinit[i] = slope * 8.0f * (float)acc_row(i, lane);
 
   f32x16 o[2] = {zero16(), zero16()};
   float m = -INFINITY, l = 0.f;
@@ -170,44 +206,47 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     if (qw0 + 31 < kv0) continue;   // this wave's queries all precede the tile (causal)
     f32x16 s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) s[kb] = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, zero16());
-    float mx = -INFINITY;
+    for (int kb = 0; kb < 2; ++kb) s[kb] = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, kinit);
+    if (kv0 + TB - 1 > qw0) {       // diagonal tile: mask key > query
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
+        const int lim = query - kv0 - kb * 32;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kv0 + kb * 32 + acc_row(i, lane);
-        float v = s[kb][i] * c2 - slope2 * (float)(query - key);
-        v = key <= query ? v : -INFINITY;
-        s[kb][i] = v;
-        mx = fmaxf(mx, v);
+        for (int i = 0; i < 16; ++i) s[kb][i] = acc_row(i, lane) <= lim ? s[kb][i] : -INFINITY;
       }
-    mx = xhalf_max(mx);
+    }
+    const float b0 = slope2 * (float)(kv0 - qw0), b1 = slope2 * (float)(kv0 + 32 - qw0);
+    const float mx = xhalf_max(fmaxf(fmaf(max16(s[0]), c2, b0), fmaf(max16(s[1]), c2, b1)));
     const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
+    const float alpha = fexp2<T>(m - m_new);
+    const float off0 = b0 - m_new, off1 = b1 - m_new;
     float ps = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = exp2f(s[kb][i] - m_new);
-        s[kb][i] = p;
-        ps += p;
-      }
+    for (int i = 0; i < 16; ++i) {
+      const float p0 = fexp2<T>(fmaf(s[0][i], c2, off0));
+      const float p1 = fexp2<T>(fmaf(s[1][i], c2, off1));
+      s[0][i] = p0;
+      s[1][i] = p1;
+      ps += p0 + p1;
+    }
     l = l * alpha + xhalf_sum(ps);
     m = m_new;
+    if (__any(alpha != 1.f)) {
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+      for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) o[db] = mma_tr_acc<T>(v_tr, kb * 32, db, s[kb], lane, o[db]);
-    }
   }
   if (query < Tn) {
     const bool valid = query < len;
     store_rows_T<T>(obase + (long)query * D, o, valid ? 1.f / l : 0.f, lane);
-    if (valid && lane < 32) lse[((long)b * H + h) * Tn + query] = (m + log2f(l)) * LN2;
+    if (valid && lane < 32)
+      lse[((long)b * H + h) * Tn + query] = (m + log2f(l) - slope2 * (float)(query - qw0)) * LN2;
   }
 }
 
@@ -239,9 +278,11 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
 
 // =====================================================================================
 // backward: dQ  (block owns 128 queries, sweeps key tiles; no atomics)
+// p = exp2(raw*c2 + slope2*(key - qw0) - [lse2 + slope2*(query - qw0)]);  dS = p * (dP - delta)
+// (the 1/sqrt(d) factor of dS is applied once to the final dQ)
 // =====================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
                                                           const float* __restrict__ slopes, T* __restrict__ dqkv,
@@ -270,9 +311,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
   RowRegs<T> qf, dof;
   qf.load(base + (long)qc * rs, lane);
   dof.load(dout + ((long)b * Tn + qc) * D + h * DH, lane);
-  const float lse2 = qvalid ? lse[((long)b * H + h) * Tn + query] * LOG2E : 0.f;
+  const float slope = slopes[h];
+  const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
+  // +inf for padded queries -> p = exp2(-inf) = 0 without a compare
+  const float Lq = qvalid ? lse[((long)b * H + h) * Tn + query] * LOG2E + slope2 * (float)(query - qw0) : INFINITY;
   const float dl = qvalid ? delta[((long)b * H + h) * Tn + query] : 0.f;
-  const float slope2 = slopes[h] * LOG2E, c2 = SCALE * LOG2E;
+  f32x16 kinit, dinit;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    kinit[i] = slope * 8.0f * (float)acc_row(i, lane);
+    dinit[i] = -dl;
+  }
 
   f32x16 dq[2] = {zero16(), zero16()};
   uint4 rk[NVec<T>::v], rv[NVec<T>::v];
@@ -289,28 +338,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
       slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
     }
     if (qw0 + 31 < kv0) continue;
+    const bool diag = kv0 + TB - 1 > qw0;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, zero16());
-      f32x16 dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, zero16());
+      f32x16 s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, kinit);
+      f32x16 dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, dinit);
+      if (diag) {
+        const int lim = query - kv0 - kb * 32;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kv0 + kb * 32 + acc_row(i, lane);
-        const float p = (key <= query && qvalid) ? exp2f(s[i] * c2 - slope2 * (float)(query - key) - lse2) : 0.f;
-        s[i] = p * (dp[i] - dl) * SCALE;
+        for (int i = 0; i < 16; ++i) s[i] = acc_row(i, lane) <= lim ? s[i] : -INFINITY;
       }
+      const float off = slope2 * (float)(kv0 + kb * 32 - qw0) - Lq;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(fmaf(s[i], c2, off)) * dp[i];
 #pragma unroll
       for (int db = 0; db < 2; ++db) dq[db] = mma_tr_acc<T>(k_tr, kb * 32, db, s, lane, dq[db]);
     }
   }
-  if (query < Tn) store_rows_T<T>(dqbase + (long)query * rs, dq, 1.f, lane);
+  if (query < Tn) store_rows_T<T>(dqbase + (long)query * rs, dq, SCALE, lane);
 }
 
 // =====================================================================================
 // backward: dK, dV (block owns 128 keys, sweeps query tiles; no atomics)
+// rows of the accumulator = queries: the per-query constants -(lse2 + slope2*(q - k0))/c2 and
+// -delta are the INITIAL accumulators of the S and dP products (staged in LDS per query tile;
+// -inf for padded queries), the per-key constant slope2*(key - k0) sits on the lane.
 // =====================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ slopes, T* __restrict__ dqkv,
@@ -320,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
   char* do_row = smem + LdsPlan<T>::ROW_BYTES;
   char* q_tr = smem + 2 * LdsPlan<T>::ROW_BYTES;
   char* do_tr = q_tr + LdsPlan<T>::TR_BYTES;
-  float* st = reinterpret_cast<float*>(do_tr + LdsPlan<T>::TR_BYTES);   // [2][64]: lse2, delta
+  float* st = reinterpret_cast<float*>(do_tr + LdsPlan<T>::TR_BYTES);   // [2][64]: S init, dP init
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ktile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int D = H * DH;
@@ -343,7 +398,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
   RowRegs<T> kf, vf;
   kf.load(base + D + (long)kc * rs, lane);
   vf.load(base + 2 * D + (long)kc * rs, lane);
-  const float slope2 = slopes[h] * LOG2E, c2 = SCALE * LOG2E;
+  const float slope = slopes[h];
+  const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
+  const float kl = slope2 * (float)(key - k0);
   const float* __restrict__ lse_bh = lse + ((long)b * H + h) * Tn;
   const float* __restrict__ dl_bh = delta + ((long)b * H + h) * Tn;
 
@@ -359,8 +416,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     if (tid < 64) {
       const int qq = qs0 + tid;
       const bool ok = qq < len;
-      st[tid] = ok ? lse_bh[qq] * LOG2E : 0.f;
-      st[64 + tid] = ok ? dl_bh[qq] : 0.f;
+      st[tid] = ok ? -(lse_bh[qq] * LOG2E + slope2 * (float)(qq - k0)) / c2 : -INFINITY;
+      st[64 + tid] = ok ? -dl_bh[qq] : 0.f;
     }
     __syncthreads();
     if (qt + 1 < qt_end) {
@@ -369,27 +426,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      if (qs0 + qb * 32 + 31 < kw0) continue;   // all queries precede this wave's keys
-      f32x16 s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, zero16());
-      f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, zero16());
-      f32x16 ds;
+      const int qb0 = qs0 + qb * 32;
+      if (qb0 + 31 < kw0) continue;   // all queries precede this wave's keys
+      f32x16 s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, rows16(st, qb * 32, lane));
+      f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, rows16(st + 64, qb * 32, lane));
+      if (qb0 < kw0 + 31) {            // diagonal block: mask query < key
+        const int lim = key - qb0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = acc_row(i, lane) >= lim ? s[i] : -INFINITY;
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int ql = qb * 32 + acc_row(i, lane);
-        const int qq = qs0 + ql;
-        const float p = (key <= qq && qq < len) ? exp2f(s[i] * c2 - slope2 * (float)(qq - key) - st[ql]) : 0.f;
-        s[i] = p;
-        ds[i] = p * (dp[i] - st[64 + ql]) * SCALE;
+        s[i] = fexp2<T>(fmaf(s[i], c2, kl));
+        dp[i] *= s[i];
       }
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         dv[db] = mma_tr_acc<T>(do_tr, qb * 32, db, s, lane, dv[db]);
-        dk[db] = mma_tr_acc<T>(q_tr, qb * 32, db, ds, lane, dk[db]);
+        dk[db] = mma_tr_acc<T>(q_tr, qb * 32, db, dp, lane, dk[db]);
       }
     }
   }
   if (key < Tn) {
-    store_rows_T<T>(dkbase + (long)key * rs, dk, 1.f, lane);
+    store_rows_T<T>(dkbase + (long)key * rs, dk, SCALE, lane);
     store_rows_T<T>(dvbase + (long)key * rs, dv, 1.f, lane);
   }
 }
