@@ -187,6 +187,29 @@ VG_DEVICE float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution), sharing
+// one exp(-x^2/2) between the cdf and the pdf; ~4x fewer VALU instructions than erff + expf.
+VG_DEVICE void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
+  const float e = __expf(-0.5f * x * x);
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
+                              0.254829592f);
+  const float erf_abs = fmaf(-poly, e, 1.0f);
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf_x = x * 0.39894228040143267794f * e;
+}
+VG_DEVICE float gelu_fast(float x) {
+  float cdf, px;
+  gelu_parts_fast(x, cdf, px);
+  return x * cdf;
+}
+VG_DEVICE float gelu_grad_fast(float x) {
+  float cdf, px;
+  gelu_parts_fast(x, cdf, px);
+  return cdf + px;
+}
+
 VG_DEVICE float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -80,7 +80,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
   } else if (p.act == VG_ACT_GELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
   }
   if (p.dact != VG_ACT_NONE) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux_in) + idx);
@@ -89,7 +89,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
       for (int e = 0; e < 8; ++e) v[e] = ((float)a[e] > 0.f) ? v[e] : 0.f;
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)a[e]);
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)a[e]);
     }
   }
   if (p.residual) {

@@ -54,13 +54,10 @@ class TransformerLayer(nn.Module):
     def forward_2d(self, x2: torch.Tensor, B: int, T: int, lens: Optional[torch.Tensor],
                    slopes: torch.Tensor) -> torch.Tensor:
         sa = self.self_attn
-        n1 = HF.rmsnorm(x2, self.norm1.scale, self.norm1.eps, lengths=lens, T=T)
-        qkv = HF.linear(n1, sa.in_proj.weight, sa.in_proj.bias)
-        ctx = HF.attention(qkv, slopes, B, T, sa.nheads, lens)
-        x1 = HF.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x2, lengths=lens, T=T)
-        n3 = HF.rmsnorm(x1, self.norm3.scale, self.norm3.eps, lengths=lens, T=T)
-        return HF.ffn(n3, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                      residual=x1, lengths=lens, T=T)
+        return HF.transformer_layer(x2, self.norm1.scale, sa.in_proj.weight, sa.in_proj.bias,
+                                    sa.out_proj.weight, sa.out_proj.bias, self.norm3.scale,
+                                    self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                    self.linear2.bias, slopes, lens, B, T, sa.nheads, self.norm1.eps)
 
     def forward(self, tgt: TensorMask, memory: Optional[TensorMask] = None,
                 rpe_pair: Optional[Tuple[str, Any]] = None, rpe_bias=None,

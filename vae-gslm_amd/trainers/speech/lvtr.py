@@ -59,6 +59,10 @@ class LVTRTrainer(BaseTrainer):
         self.use_tokens = self.model.use_tokens
         self.token_kld_weight = tr.get("token_kld_weight", 1.0)
         self.optimizer = self.scheduler = self.reducer = None
+        hip = hp.get("hip", None)
+        self.use_graph = bool(hip.get("graph", False)) if hip is not None else False
+        self._graphs = {}
+        self._kw_dev = None
 
     # ------------------------------------------------------------ optimisation plumbing
     def configure_optimizers(self):
@@ -83,8 +87,10 @@ class LVTRTrainer(BaseTrainer):
         return w
 
     # ------------------------------------------------------------ one micro-batch
-    def _training_loop(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
-        kld_weight = self.current_kld_weight()
+    def _training_loop(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None,
+                       kld_weight=None):
+        if kld_weight is None:
+            kld_weight = self.current_kld_weight()
         kwargs = {}
         if self.model.utterance_encoder is not None:
             kwargs["utterance"] = batch["cropped_mel_utt"]
@@ -116,7 +122,10 @@ class LVTRTrainer(BaseTrainer):
         last = (batch_idx + 1) % self.gradient_update_step == 0
         if self.reducer is not None:
             self.reducer.sync_now = last
-        out = self._training_loop(batch, batch_idx, noise)
+        if self.use_graph and noise is None:
+            out = self._graphed_micro_step(batch, batch_idx, last)
+        else:
+            out = self._training_loop(batch, batch_idx, noise)
         if last:
             if self.reducer is not None:
                 self.reducer.finish()
@@ -143,6 +152,55 @@ class LVTRTrainer(BaseTrainer):
             self.scheduler.step()
             self.global_step += 1
         return out
+
+    # ------------------------------------------------------------ hipGraph replay of a micro-step
+    def _graphed_micro_step(self, batch: Mapping, batch_idx: int, last: bool):
+        """Forward + backward of one micro-batch captured once per input shape into a hipGraph
+        and replayed afterwards: ~2,700 kernel launches per micro-batch become one graph launch,
+        so the GPU is never starved by the host.  The KL weight is a device scalar (it changes
+        during warm-up), inputs are copied into static buffers, gradients accumulate into the
+        reducer's static buckets.  With N > 1 ranks the bucket all-reduces are issued after the
+        last replay of the window (bulk, not overlapped with backward)."""
+        key = tuple((k, tuple(v.value.shape), getattr(v.mask, "_vg_full", False)) for k, v in sorted(batch.items()))
+        dev = batch["mel"].value.device
+        if self._kw_dev is None:
+            self._kw_dev = torch.zeros((), dtype=torch.float32, device=dev)
+        self._kw_dev.fill_(self.current_kld_weight())
+        ent = self._graphs.get(key)
+        if ent is None:
+            from utils.tensormask import TensorMask
+            static = {k: TensorMask(v.value.clone(), v.mask if getattr(v.mask, "_vg_full", False) else v.mask.clone())
+                      for k, v in batch.items()}
+            if self.reducer is not None:
+                self.reducer.sync_now = False          # collectives stay outside the graph
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):              # eager pass on the capture side-stream (lazy inits)
+                self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
+            torch.cuda.current_stream().wait_stream(side)
+            if self.reducer is not None:
+                self.reducer.zero_grad()
+            if getattr(self, "profile_in_graph", False):
+                import hipvg
+                hipvg.prof_enable(True)                # event-record nodes become part of the graph
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
+            if self.reducer is not None:
+                self.reducer.zero_grad()               # capture does not execute; start from clean buckets
+            ent = self._graphs[key] = (graph, static, out)
+        graph, static, out = ent
+        for k, v in batch.items():
+            static[k].value.copy_(v.value, non_blocking=True)
+            if static[k].mask is not v.mask and not getattr(static[k].mask, "_vg_full", False):
+                static[k].mask.copy_(v.mask, non_blocking=True)
+                static[k].mask._vg_len32 = None
+        graph.replay()
+        if last and self.reducer is not None and self.reducer.world > 1:
+            self.reducer.reduce_all()
+        res = dict(out)
+        res["kld_weight"] = self.current_kld_weight()
+        return res
 
     # ------------------------------------------------------------ checkpoints
     def save_checkpoint(self, filepath: str) -> None:

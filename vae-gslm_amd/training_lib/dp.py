@@ -55,7 +55,9 @@ class GradReducer:
         self._handles = []
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
-                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+                hook = self._make_hook(bi)
+                p.register_post_accumulate_grad_hook(hook)
+                p._vg_grad_hooks = [hook]      # fired by hipvg's gradient sink (bypasses AccumulateGrad)
 
     def _close(self, plist, n, dev):
         flat = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -91,6 +93,12 @@ class GradReducer:
         h.wait()
         flat.div_(self.world)
         return None
+
+    def reduce_all(self) -> None:
+        """Launch the all-reduce of every bucket now (used when backward ran inside a hipGraph)."""
+        if self.world > 1:
+            for b in self.buckets:
+                self._launch(b)
 
     def finish(self) -> None:
         """Call after the last backward of the window, before ``optimizer.step()``."""
