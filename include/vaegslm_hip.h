@@ -32,7 +32,7 @@ extern "C" {
 typedef struct ihipStream_t* vg_stream_t; /* == hipStream_t */
 
 enum { VG_F32 = 0, VG_BF16 = 1 };
-enum { VG_ACT_NONE = 0, VG_ACT_RELU = 1, VG_ACT_GELU = 2 };
+enum { VG_ACT_NONE = 0, VG_ACT_RELU = 1, VG_ACT_GELU = 2, VG_ACT_SILU = 3 };
 
 int vg_version(void);
 /* copies the calling thread's last error message (NUL terminated) */
@@ -47,7 +47,7 @@ int vg_last_error(char* buf, int buflen);
  * head mean/logstd projections).
  *   a_tr = 0: A stored [M][lda] (k contiguous);  a_tr = 1: A stored [K][lda] (m contiguous)
  *   b_tr = 0: B stored [N][ldb] (k contiguous);  b_tr = 1: B stored [K][ldb] (n contiguous)
- * Epilogue order: +bias[n] -> (aux_out = value) -> act -> *dact'(aux_in) ->
+ * Epilogue order: +bias[n] -> +pre_add -> (aux_out = value) -> act -> *dact'(aux_in) ->
  * +residual -> row mask (zero rows t >= lengths[b]) -> store.
  * split_k > 1: fp32 C must be pre-zeroed; partial sums are added atomically
  * and the epilogue is skipped (used for weight gradients only).
@@ -71,6 +71,7 @@ typedef struct vg_gemm_desc {
   int accumulate;       /* C += (fp32 C, split_k == 1) */
   int split_k;
   float alpha;
+  const void* pre_add;  /* [M][ldc] added before the activation (conditioning term of the conv blocks) or NULL */
   int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..4 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 */
 } vg_gemm_desc;
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
@@ -156,8 +157,29 @@ int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, in
 /* dx = dy * act'(aux): ReLU takes aux = activation output, GELU (erf) takes aux = pre-activation
  * (modules/activations.py:5-18 backward, for Linear+activation heads with several consumers). */
 int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, vg_stream_t stream);
+/* y = rows t < lengths[b] of x, zeros elsewhere (utils/tensormask.py:63-67 on [M][C] rows; backward of a
+ * masked Linear when the incoming gradient is not already zero on padded frames) */
+int vg_mask_rows(const void* x, void* y, int M, int C, const int32_t* lengths, int T, int dtype, vg_stream_t stream);
 /* fp32 -> bf16 copy (weights shadow) */
 int vg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vg_stream_t stream);
+
+/* ---------------------------------------------------------------- conv-block row kernels (channels-last)
+ * Depthwise conv along time (taps k = 0..taps-1 read input frame t + k - shift; shift = taps-1 causal,
+ * 0 look-ahead; zero padding inside each sequence) + conv bias + per-sequence time embedding, followed by
+ * the per-frame channel norm with UNBIASED variance -- the fused front half of the reference's
+ * ResidualBlock / TemporalResidualBlock / TCResidualBlock (modules/conv/layers.py:114-124,243-251,
+ * 277-286; modules/norm.py:43-47) on [M = B*T][C] rows.  taps = 0: the norm alone (final_norm).
+ * w: fp32 [C][taps]; cbias, gamma, beta: fp32 [C]; temb: fp32 [B][C] or NULL; mean/rstd: fp32 [M].
+ * Backward: du = dL/d(conv output) [M][C]; dx = dx_add + conv^T(du) (taps > 0); norm_part: fp32
+ * [vg_dwnorm_blocks(M)][2][C] (gamma, beta partial sums), w_part: fp32 [blocks][C][taps]. */
+int vg_dwnorm_blocks(int M);
+int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, const float* temb, const float* gamma,
+                  const float* beta, void* y, float* mean, float* rstd, int M, int C, int T, int taps, int shift,
+                  float eps, int dtype, vg_stream_t stream);
+int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cbias, const float* temb,
+                  const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
+                  float* norm_part, float* w_part, int M, int C, int T, int taps, int shift, int dtype,
+                  vg_stream_t stream);
 
 /* ---------------------------------------------------------------- measurement hooks
  * Optional HIP-event timing of the GEMM / attention launches (bench.py's roofline

@@ -210,6 +210,12 @@ VG_DEVICE float gelu_grad_fast(float x) {
   return cdf + px;
 }
 
+VG_DEVICE float silu(float x) { return x / (1.0f + expf(-x)); }
+VG_DEVICE float silu_grad(float x) {
+  const float sg = 1.0f / (1.0f + expf(-x));
+  return sg * (1.0f + x * (1.0f - sg));
+}
+
 VG_DEVICE float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -167,11 +167,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
           continue;
         }
         if (p.bias) v += p.bias[n];
+        if (p.pre_add) v += to_f32<T>(reinterpret_cast<const T*>(p.pre_add)[idx]);
         if (auxo) auxo[idx] = from_f32<T>(v);
         if (p.act == VG_ACT_RELU) v = fmaxf(v, 0.f);
         else if (p.act == VG_ACT_GELU) v = gelu_erf(v);
+        else if (p.act == VG_ACT_SILU) v = silu(v);
         if (p.dact == VG_ACT_RELU) v = (to_f32<T>(auxi[idx]) > 0.f) ? v : 0.f;
         else if (p.dact == VG_ACT_GELU) v *= gelu_erf_grad(to_f32<T>(auxi[idx]));
+        else if (p.dact == VG_ACT_SILU) v *= silu_grad(to_f32<T>(auxi[idx]));
         if (res) v += to_f32<T>(res[idx]);
         if (!valid) v = 0.f;
         if (p.out_f32) {
@@ -235,6 +238,7 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.bias = d->bias; p.residual = d->residual; p.aux_in = d->aux_in; p.aux_out = d->aux_out;
+  p.pre_add = d->pre_add;
   p.lengths = d->lengths; p.T = d->T > 0 ? d->T : 1;
   p.act = d->act; p.dact = d->dact; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
   p.alpha = d->alpha;

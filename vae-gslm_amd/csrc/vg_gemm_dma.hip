@@ -69,6 +69,11 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
   }
+  if (p.pre_add) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.pre_add) + idx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
+  }
   if (p.aux_out) {
     bf16x8 o;
 #pragma unroll
@@ -81,15 +86,21 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
   } else if (p.act == VG_ACT_GELU) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+  } else if (p.act == VG_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
   }
   if (p.dact != VG_ACT_NONE) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux_in) + idx);
     if (p.dact == VG_ACT_RELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((float)a[e] > 0.f) ? v[e] : 0.f;
-    } else {
+    } else if (p.dact == VG_ACT_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)a[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= silu_grad((float)a[e]);
     }
   }
   if (p.residual) {

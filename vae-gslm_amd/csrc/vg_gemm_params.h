@@ -10,6 +10,7 @@ struct GemmParams {
   const void* residual;     // [M][ldc] (type T) or null
   const void* aux_in;       // [M][ldc] (type T): input of the activation derivative
   void* aux_out;            // [M][ldc] (type T): pre-activation copy
+  const void* pre_add;      // [M][ldc] (type T) added BEFORE the activation, or null
   const int* lengths; int T;
   int act;                  // VG_ACT_*
   int dact;                 // VG_ACT_* derivative applied to the result (uses aux_in)

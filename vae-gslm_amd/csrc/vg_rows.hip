@@ -251,8 +251,18 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a
     float r = g;
     if (act == VG_ACT_RELU) r = a > 0.f ? g : 0.f;
     else if (act == VG_ACT_GELU) r = g * gelu_erf_grad(a);
+    else if (act == VG_ACT_SILU) r = g * silu_grad(a);
     dx[i] = from_f32<T>(r);
   }
+}
+
+// ------------------------------------------------------------------ row mask (apply_mask on [M][C] rows)
+template <typename T>
+__global__ void mask_rows_kernel(const T* __restrict__ x, T* __restrict__ y, long n, int C,
+                                 const int* __restrict__ lengths, int Tlen) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = row_valid(lengths, Tlen, (int)(i / C)) ? x[i] : from_f32<T>(0.f);
 }
 
 // ------------------------------------------------------------------ token cross-entropy
@@ -500,6 +510,22 @@ extern "C" int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, 
     act_bwd_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)dy, (const float*)aux,
                                                                             (float*)dx, (long)n, act);
   return vg_host::check_launch("vg_act_bwd");
+}
+
+extern "C" int vg_mask_rows(const void* x, void* y, int M, int C, const int32_t* lengths, int T, int dtype,
+                            hipStream_t stream) {
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_mask_rows: bad dtype %d", dtype);
+  const long n = (long)M * C;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (dtype == VG_BF16)
+    mask_rows_kernel<bf16_t><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const bf16_t*)x, (bf16_t*)y, n, C,
+                                                                               lengths, T > 0 ? T : 1);
+  else
+    mask_rows_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)x, (float*)y, n, C,
+                                                                              lengths, T > 0 ? T : 1);
+  return vg_host::check_launch("vg_mask_rows");
 }
 
 extern "C" int vg_ce_fwd(const void* logits, const int64_t* targets, float* loss_rows, float* lse, int32_t* argmax,

@@ -18,8 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libvaegslm_hip.so")
 
 VG_F32, VG_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "silu": ACT_SILU}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp), ("aux_in", _vp), ("aux_out", _vp),
                 ("lengths", _vp), ("T", _i),
                 ("act", _i), ("dact", _i), ("out_f32", _i), ("accumulate", _i),
-                ("split_k", _i), ("alpha", _f), ("tile_cfg", _i)]
+                ("split_k", _i), ("alpha", _f), ("pre_add", _vp), ("tile_cfg", _i)]
 
 
 # name -> argtypes (restype is always int); must list EVERY symbol of the header
@@ -57,6 +57,10 @@ SIGNATURES = {
     "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _vp],
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "vg_mask_rows": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "vg_dwnorm_blocks": [_i],
+    "vg_dwnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "vg_dwnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vg_prof_enable": [_i],
     "vg_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
 }

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import (ACT_GELU, ACT_IDS, ACT_NONE, ACT_RELU, GemmDesc, check, dtype_id, lib, ptr,
+from . import (ACT_GELU, ACT_IDS, ACT_NONE, ACT_RELU, ACT_SILU, GemmDesc, check, dtype_id, lib, ptr,
                stream)
 
 Tensor = torch.Tensor
@@ -49,7 +49,7 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
          residual: Optional[Tensor] = None, aux_in: Optional[Tensor] = None,
          aux_out: Optional[Tensor] = None, lengths: Optional[Tensor] = None, T: int = 0,
          act: int = ACT_NONE, dact: int = ACT_NONE, accumulate=False, split_k: int = 1,
-         alpha: float = 1.0, tile_cfg: int = 0) -> Tensor:
+         alpha: float = 1.0, tile_cfg: int = 0, pre_add: Optional[Tensor] = None) -> Tensor:
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
     if out is None:
@@ -67,6 +67,7 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
     d.out_f32 = int(out.dtype == torch.float32)
     d.accumulate, d.split_k, d.alpha = int(accumulate), int(split_k), float(alpha)
     d.tile_cfg = int(tile_cfg)
+    d.pre_add = ptr(pre_add)
     check(lib().vg_gemm(C.byref(d), stream()), "vg_gemm")
     return out
 
@@ -97,6 +98,13 @@ def act_bwd(dy: Tensor, aux: Tensor, act: int) -> Tensor:
     out = torch.empty_like(dy)
     check(lib().vg_act_bwd(ptr(dy), ptr(aux), ptr(out), dy.numel(), act, dtype_id(dy.dtype), stream()),
           "vg_act_bwd")
+    return out
+
+
+def mask_rows(x: Tensor, lengths: Tensor, T: int) -> Tensor:
+    out = torch.empty_like(x)
+    check(lib().vg_mask_rows(ptr(x), ptr(out), x.shape[0], x.shape[1], ptr(lengths), int(T), dtype_id(x.dtype),
+                             stream()), "vg_mask_rows")
     return out
 
 
@@ -141,6 +149,8 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = wshape[0]
         dy = _as(dy, x.dtype)
+        if lengths is not None:      # forward masked the output rows: so is the gradient
+            dy = mask_rows(dy, lengths, T)
         du = dy
         if act != ACT_NONE:
             du = act_bwd(dy, _as(aux, x.dtype), act)
@@ -551,3 +561,151 @@ class TransformerLayerFn(torch.autograd.Function):
 
 def transformer_layer(x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps):
     return TransformerLayerFn.apply(x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps)
+
+
+# ---------------------------------------------------------------- conv bottleneck block (channels-last)
+def dwnorm_fwd_raw(x, w, cb, te, gamma, beta, T, taps, shift, eps):
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    check(lib().vg_dwnorm_fwd(ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(beta), ptr(y), ptr(mean),
+                              ptr(rstd), M, Cc, int(T), int(taps), int(shift), float(eps), dtype_id(x.dtype),
+                              stream()), "vg_dwnorm_fwd")
+    return y, mean, rstd
+
+
+def dwnorm_bwd_raw(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
+    M, Cc = x.shape
+    nb = lib().vg_dwnorm_blocks(M)
+    du = torch.empty_like(x)
+    dx = torch.empty_like(x) if taps > 0 else du
+    npart = torch.empty((nb, 2 * Cc), dtype=torch.float32, device=x.device)
+    wpart = torch.empty((nb, Cc * max(taps, 1)), dtype=torch.float32, device=x.device)
+    check(lib().vg_dwnorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
+                              ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, int(T), int(taps),
+                              int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd")
+    gb = colsum(npart)
+    dw = colsum(wpart) if taps > 0 else None
+    return du, dx, gb[:Cc], gb[Cc:], dw
+
+
+def _sink_or_return(p, value):
+    """value: fp32 tensor shaped like p (or broadcastable view)."""
+    if p is None:
+        return None
+    if _sinkable(p):
+        sink_vector(p, value)
+        return None
+    return value.view_as(p)
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """x + conv3(act(conv2([norm(dwconv(x) + t_emb) ; cond])))  -- one bottleneck block of the posterior
+    encoder / diffusion UNet (reference modules/conv/layers.py:70-135,231-295) on [B*T, C] rows:
+    fused depthwise-conv+norm row kernel, the two 1x1 convolutions as MFMA GEMMs (conditioning enters
+    as a pre-activation add, the residual in the second GEMM's epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, te, cond, c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b, T, taps, shift, eps, act):
+        M, Cc = x.shape
+        dt = x.dtype
+        Hd = c2w.shape[0]
+        w1 = c1w.detach().float().reshape(Cc, taps).contiguous()
+        cb = c1b.detach().float().contiguous()
+        gamma, beta = nw.detach().float().contiguous(), nb_.detach().float().contiguous()
+        te32 = None if te is None else te.detach().float().contiguous()
+        u, mean, rstd = dwnorm_fwd_raw(x, w1, cb, te32, gamma, beta, T, taps, shift, eps)
+        s2 = shadow(c2w, dt).view(Hd, -1)
+        s3 = shadow(c3w, dt).view(Cc, Hd)
+        Wa = s2[:, :Cc]
+        pre_add = None
+        if cond is not None:
+            Wc = s2[:, Cc:]
+            pre_add = gemm(cond, Wc, M, Hd, cond.shape[1])
+        pre = torch.empty((M, Hd), dtype=dt, device=x.device) if act != ACT_RELU else None
+        h = gemm(u, Wa, M, Hd, Cc, bias=c2b.detach().float(), pre_add=pre_add, act=act, aux_out=pre)
+        y = gemm(h, s3, M, Cc, Hd, bias=c3b.detach().float(), residual=x)
+        ctx.save_for_backward(x, u, mean, rstd, h, pre, cond, s2, s3, w1, cb, te32, gamma)
+        ctx.params = (c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b)
+        ctx.meta = (T, taps, shift, act, te is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, u, mean, rstd, h, pre, cond, s2, s3, w1, cb, te32, gamma = ctx.saved_tensors
+        c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b = ctx.params
+        T, taps, shift, act, has_te = ctx.meta
+        M, Cc = x.shape
+        Hd = s2.shape[0]
+        dt = x.dtype
+        dy = _as(dy, dt)
+        Wa = s2[:, :Cc]
+        dpre = gemm(dy, s3, M, Hd, Cc, b_tr=True, dact=act, aux_in=(h if act == ACT_RELU else pre))
+
+        def wgrad_into(p, rows, col0, cols, g_out, inp):
+            """p.grad[:, col0:col0+cols] (+)= g_out^T inp, or return the dense gradient."""
+            if _sinkable(p):
+                g = _grad_buffer(p).view(rows, -1)[:, col0:col0 + cols]
+                s = wgrad_splits(rows, cols, M, dt)
+                gemm(g_out, inp, rows, cols, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1))
+                return None
+            return gemm(g_out, inp, rows, cols, M, a_tr=True, b_tr=True, out_f32=True,
+                        split_k=wgrad_splits(rows, cols, M, dt))
+
+        g_c3 = wgrad_into(c3w, Cc, 0, Hd, dy, h)
+        g_c3b = _sink_or_return(c3b, colsum(dy))
+        du = gemm(dpre, Wa, M, Cc, Hd, b_tr=True)
+        ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u)
+        dcond = gc = None
+        if cond is not None:
+            Wc = s2[:, Cc:]
+            Kc = cond.shape[1]
+            dcond = gemm(dpre, Wc, M, Kc, Hd, b_tr=True)
+            gc = wgrad_into(c2w, Hd, Cc, Kc, dpre, cond)
+        if _sinkable(c2w):
+            _fire(c2w)
+            g_c2 = None
+        else:
+            g_c2 = (ga if gc is None else torch.cat([ga, gc], 1)).view_as(c2w)
+        if _sinkable(c3w):
+            _fire(c3w)
+        elif g_c3 is not None:
+            g_c3 = g_c3.view_as(c3w)
+        g_c2b = _sink_or_return(c2b, colsum(dpre))
+        dv, dx, dgamma, dbeta, dw1 = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
+        dte = dv.view(-1, T, Cc).float().sum(1)
+        g_c1w = _sink_or_return(c1w, dw1)
+        g_c1b = _sink_or_return(c1b, dte.sum(0))
+        g_nw = _sink_or_return(nw, dgamma)
+        g_nb = _sink_or_return(nb_, dbeta)
+        return (dx, dte if has_te else None, dcond, g_c1w, g_c1b, g_nw, g_nb, g_c2, g_c2b, g_c3, g_c3b,
+                None, None, None, None, None)
+
+
+def conv_block(x, te, cond, c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b, *, T, taps, shift, eps, act):
+    return ConvBlockFn.apply(x, te, cond, c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b, T, taps, shift, eps,
+                             ACT_IDS[act] if not isinstance(act, int) else act)
+
+
+class ChannelNormFn(torch.autograd.Function):
+    """Per-frame channel norm with unbiased variance (reference modules/norm.py:43-47) on [M, C] rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, T, eps):
+        gamma, beta = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y, mean, rstd = dwnorm_fwd_raw(x, None, None, None, gamma, beta, T, 0, 0, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.T = T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        du, _, dgamma, dbeta, _ = dwnorm_bwd_raw(_as(dy, x.dtype), x, None, None, None, gamma, mean, rstd, None,
+                                                 ctx.T, 0, 0)
+        return du, dgamma, dbeta, None, None
+
+
+def channel_norm(x, weight, bias, *, T, eps):
+    return ChannelNormFn.apply(x, weight, bias, T, eps)

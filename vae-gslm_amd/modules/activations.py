@@ -1,7 +1,7 @@
 """Activation factory (reference modules/activations.py:5-18).
 
 ``hip_act_id`` tells the GEMM epilogue which activations it can fuse
-(ReLU, exact-erf GELU); anything else runs as a separate torch op."""
+(ReLU, exact-erf GELU, SiLU); anything else runs as a separate torch op."""
 import torch.nn as nn
 
 from hparams.hp import Hparams
@@ -31,4 +31,6 @@ def hip_act_id(module) -> "str | None":
         return "relu"
     if isinstance(module, nn.GELU) and getattr(module, "approximate", "none") == "none":
         return "gelu"
+    if isinstance(module, nn.SiLU):
+        return "silu"
     return None

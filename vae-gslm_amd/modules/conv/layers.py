@@ -14,15 +14,19 @@ optional diffusion-time embedding, concat skip connections.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import hipvg
+from hipvg import functional as HF
 from hparams.hp import Hparams
-from modules.activations import get_activation
-from modules.norm import get_norm_fn
+from modules.activations import get_activation, hip_act_id
+from modules.linear.layers import dense_2d
+from modules.norm import InstanceNorm, get_norm_fn
 from utils.helpers import get_padding
 from utils.tensormask import TensorMask
 
@@ -65,6 +69,22 @@ class BottleneckBlock(nn.Module):
         if time_dim is not None:
             self.time_emb = nn.Linear(time_dim, channels)
         self.has_time, self.has_cond = time_dim is not None, cond_dim > 0
+        k = lhp.kernel_size
+        self.taps = k
+        self.shift = (k - 1) if lhp.get("causal_padding", False) else (0 if lhp.get("future_padding", False)
+                                                                      else (k - 1) // 2)
+
+    def hip_ready(self) -> bool:
+        return isinstance(self.norm, InstanceNorm) and hip_act_id(self.act) in ("relu", "silu")
+
+    def forward_rows(self, x2: torch.Tensor, T: int, cond2: Optional[torch.Tensor],
+                     temb: Optional[torch.Tensor]) -> torch.Tensor:
+        """Channels-last HIP path: x2 [B*T, C] in the compute dtype."""
+        te = self.time_emb(self.act(temb)) if self.has_time else None
+        return HF.conv_block(x2, te, cond2 if self.has_cond else None, self.conv1.weight, self.conv1.bias,
+                             self.norm.weight, self.norm.bias, self.conv2.weight, self.conv2.bias,
+                             self.conv3.weight, self.conv3.bias, T=T, taps=self.taps, shift=self.shift,
+                             eps=self.norm.eps, act=hip_act_id(self.act))
 
     def forward(self, x: torch.Tensor, cond: Optional[torch.Tensor] = None,
                 temb: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -118,9 +138,50 @@ class BottleNeckResNet(nn.Module):
         self.final_norm = get_norm_fn(widths[-1], hp.layer.norm) if hp.get("final_norm", False) else None
         self.first_norm = get_norm_fn(widths[0], hp.layer.norm) if hp.get("first_norm", False) else None
 
+    def _hip_ok(self, x: TensorMask) -> bool:
+        norms_ok = all(n is None or isinstance(n, InstanceNorm) for n in (self.final_norm, self.first_norm))
+        return (x.value.is_cuda and os.environ.get("VG_CONV_STOCK", "0") != "1" and norms_ok
+                and all(b.hip_ready() for b in self.layers))
+
+    def forward_hip(self, x: TensorMask, c: Optional[TensorMask], t: Optional[torch.Tensor]) -> TensorMask:
+        """Same computation on [B*T, C] rows: 1x1 convs on the MFMA GEMM, fused depthwise-conv+norm
+        row kernels, skip connections as two accumulating GEMMs (no concat, no transposes)."""
+        mask, lens = x.mask, x.lengths32
+        B, T = mask.shape
+        dt = hipvg.compute_dtype()
+        h = x.value.reshape(B * T, -1)
+        if self.linear is not None:
+            h = dense_2d(h, self.linear.weight, self.linear.bias, lengths=lens, T=T)
+        h = h.to(dt).contiguous()
+        if self.first_norm is not None:
+            h = HF.channel_norm(h, self.first_norm.weight, self.first_norm.bias, T=T, eps=self.first_norm.eps)
+        cond2 = None if c is None else c.value.reshape(B * T, -1).to(dt).contiguous()
+        temb = None if t is None else t.float()
+        history = [h]
+        for i, block in enumerate(self.layers):
+            h = block.forward_rows(h, T, cond2 if self.conditional[i] else None,
+                                   temb if self.time_dim is not None else None)
+            src = self.skip_connection[i]
+            if src is not None:
+                if self.skip_concat:
+                    W = self.skip_conv[i].weight
+                    Cw = h.shape[1]
+                    part = HF.linear(h, W[:, :Cw, 0], self.skip_conv[i].bias)
+                    h = HF.linear(history[src], W[:, Cw:, 0], None, residual=part)
+                else:
+                    h = h + history[src]
+            history.append(h)
+        if self.final_norm is not None:
+            h = HF.channel_norm(h, self.final_norm.weight, self.final_norm.bias, T=T, eps=self.final_norm.eps)
+        if self.out_linear is not None:
+            h = dense_2d(h, self.out_linear.weight, self.out_linear.bias, out_f32=True, lengths=lens, T=T)
+        return TensorMask(h.view(B, T, -1), mask).apply_mask()
+
     def forward(self, x: TensorMask, c: Optional[TensorMask] = None,
                 t: Optional[torch.Tensor] = None) -> TensorMask:
         """x: (B, T, C) TensorMask; c: (B, T, Cc) TensorMask; t: (B, time_dim)."""
+        if self._hip_ok(x):
+            return self.forward_hip(x, c, t)
         mask = x.mask
         h = x.value
         if self.linear is not None:
