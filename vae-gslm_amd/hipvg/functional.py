@@ -73,12 +73,13 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
 
 
 def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -> int:
-    """Split the reduction (frame) dimension of a weight-gradient GEMM so that
-    the grid fills 256 CUs x 2 blocks.  fp32 (parity) stays un-split so the
-    result is deterministic."""
-    if dtype == torch.float32:
-        return 1
+    """Split the reduction (frame) dimension of a weight-gradient GEMM so that the grid fills
+    256 CUs x 2 blocks (partial sums are combined with fp32 atomics).  The exact-f32 kernel is
+    only split for the tiny latent-side weights (a single tile would otherwise walk all 8000
+    frames serially)."""
     tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
+    if dtype == torch.float32:
+        return 1 if tiles > 4 else max(1, min(32, k_red // 256))
     s = max(1, 512 // max(tiles, 1))
     s = min(s, max(1, k_red // 256), 16)
     return s

@@ -226,6 +226,23 @@ class ConvNormAct(nn.Module):
         self.norm = get_norm_fn(cout, lhp.norm)
         self.act = get_activation(lhp.activation)
 
+    def forward_rows(self, h3: torch.Tensor, length: torch.Tensor):
+        """Channels-last HIP path on (B, T, C): the strided convolution is a window gather followed by
+        one MFMA GEMM ([B*T_out, k*C] x [k*C, C_out]), then the channel-norm row kernel."""
+        B, T, C = h3.shape
+        k, stride = self.conv.kernel_size[0], self.conv.stride[0]
+        pl, pr = self.conv.two_side_padding if self.conv.two_side_padding is not None else (self.conv.padding[0],) * 2
+        win = F.pad(h3, (0, 0, pl, pr)).unfold(1, k, stride)            # (B, T_out, C, k) view
+        t_out = win.shape[1]
+        rows = win.permute(0, 1, 3, 2).reshape(B * t_out, k * C)        # tap-major, channel-minor
+        w2 = self.conv.weight.permute(0, 2, 1).reshape(self.conv.out_channels, k * C)
+        y = HF.linear(rows.to(hipvg.compute_dtype()).contiguous(), w2, self.conv.bias)
+        y = HF.channel_norm(y, self.norm.weight, self.norm.bias, T=t_out, eps=self.norm.eps)
+        y = self.act(y).view(B, t_out, -1)
+        if self.factor != 1:
+            length = torch.clamp(TensorMask.resize_length(length, float(self.factor)), max=t_out)
+        return y, length
+
     def forward(self, h: torch.Tensor, length: torch.Tensor):
         h = self.act(self.norm(self.conv(h)))
         if self.factor != 1:
@@ -253,6 +270,18 @@ class CNNStack(nn.Module):
 
     def forward(self, x: TensorMask) -> TensorMask:
         h = x.value
+        hip = (h.is_cuda and os.environ.get("VG_CONV_STOCK", "0") != "1"
+               and all(isinstance(l.norm, InstanceNorm) for l in self.layers))
+        if hip:
+            B, T = x.mask.shape
+            if self.linear is not None:
+                h = dense_2d(h, self.linear.weight, self.linear.bias, lengths=x.lengths32, T=T)
+            length = x.length
+            for layer in self.layers:
+                h, length = layer.forward_rows(h, length)
+            if self.out_linear is not None:
+                h = dense_2d(h, self.out_linear.weight, self.out_linear.bias, out_f32=True)
+            return TensorMask.fromlength(h.float(), length).apply_mask()
         if self.linear is not None:
             h = TensorMask(self.linear(h), x.mask).apply_mask().value
         h, length = h.transpose(1, 2), x.length
