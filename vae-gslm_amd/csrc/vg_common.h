@@ -89,6 +89,10 @@ template <int KD> struct RowTile<bf16_t, KD> {
   static VG_DEVICE bf16x8 frag(const char* base, int row, int s, int lane) {
     return *reinterpret_cast<const bf16x8*>(base + chunk_off(row, 2 * s + (lane >> 5)));
   }
+  // 16x16x32 operand fragment of k-step s (32 deep): row = row0 + (lane & 15), k = 32 s + 8 (lane >> 4) + j
+  static VG_DEVICE bf16x8 frag16(const char* base, int row0, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(base + chunk_off(row0 + (lane & 15), 4 * s + (lane >> 4)));
+  }
 };
 
 template <int KD> struct RowTile<float, KD> {
@@ -123,8 +127,28 @@ template <int COLS> struct TrTile<bf16_t, COLS> {
   static VG_DEVICE int bytes(int krows) { return krows * PITCH; }
   static VG_DEVICE int swz(int krow) { return COLS == 128 ? (krow & 3) : ((krow >> 1) & 1); }
   // byte offset of element (krow, col); col multiple of 4 for vector access
+  // COLS = 128 additionally XORs the 32-byte half inside a granule with bit 3 of krow, so that the
+  // two 16-lane groups of a half-wave that read the SAME 16 columns 8 k-rows apart (the
+  // 16x16x32 operand pattern) also land on different banks.
   static VG_DEVICE int off(int krow, int col) {
-    return krow * PITCH + ((((col >> 5) ^ swz(krow))) << 6) + ((col & 31) << 1);
+    if constexpr (COLS == 128)
+      return krow * PITCH + ((((col >> 5) ^ (krow & 3))) << 6) + ((((col >> 4) & 1) ^ ((krow >> 3) & 1)) << 5) +
+             ((col & 15) << 1);
+    else
+      return krow * PITCH + ((((col >> 5) ^ swz(krow))) << 6) + ((col & 31) << 1);
+  }
+  // 16x16x32 operand fragment (natural k order): element j <-> k = 32 s + 8 (lane >> 4) + j,
+  // operand row/col index = col0 + (lane & 15)
+  static VG_DEVICE bf16x8 frag16(const char* base, int k0, int col0, int s, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int col = col0 + 4 * p;
+    const int ka = k0 + 32 * s + 8 * g + q;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + off(ka, col)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + off(ka + 4, col)));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
   }
   static VG_DEVICE void store_vec(char* base, int krow, int c16, uint4 v) {
     *reinterpret_cast<uint4*>(base + off(krow, c16 * 8)) = v;

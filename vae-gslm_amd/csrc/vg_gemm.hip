@@ -258,6 +258,7 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
     cfg = 1;
     if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048) cfg = 4;
     if (!d->a_tr && d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
+    if (!d->a_tr && !d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
   }
   if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, cfg, stream);
   return launch<float>(p, d->a_tr, d->b_tr, splits, -1, stream);

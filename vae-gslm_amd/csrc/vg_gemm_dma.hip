@@ -23,7 +23,7 @@ constexpr int BK = 64;
 // ---- issue the LDS-DMA loads of one operand tile
 //  ROW image: [R rows][128 B], chunk position p of row r holds source chunk p ^ ((r >> 1) & 7)
 //  TR  image: R/128 sub-images of [64 krows][256 B]; 64-B granule position g of krow k holds
-//             source granule g ^ (k & 3)
+//             source granule g ^ (k & 3), its 32-B halves swapped when bit 3 of k is set
 template <bool TR, int R, int NW>
 VG_DEVICE void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, long ld_bytes, int rc0, int k0, int wave, int lane) {
   constexpr int PER_WAVE = (R / 8) / NW;
@@ -41,7 +41,8 @@ VG_DEVICE void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, long ld_bytes, 
       const int krow = (piece & 15) * 4 + (lane >> 4);
       const int p16 = lane & 15;
       const int gran = (p16 >> 2) ^ (krow & 3);
-      const int col = sub * 128 + gran * 32 + (p16 & 3) * 8;
+      const int half = ((p16 >> 1) & 1) ^ ((krow >> 3) & 1);
+      const int col = sub * 128 + gran * 32 + half * 16 + (p16 & 1) * 8;
       voff = (unsigned)((long)(k0 + krow) * ld_bytes + (long)(rc0 + col) * 2);
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(void, tile + piece * 1024), 16, voff, 0, 0, 0);
@@ -50,9 +51,9 @@ VG_DEVICE void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, long ld_bytes, 
 
 template <bool TR>
 VG_DEVICE bf16x8 frag_of(const char* tile, int rc, int s, int lane) {
-  // rc = first row/col of this wave's 32-wide MFMA tile inside the block tile
-  if constexpr (!TR) return RowTile<bf16_t, 64>::frag(tile, rc + (lane & 31), s, lane);
-  else return TrTile<bf16_t, 128>::template frag<false>(tile + (rc >> 7) * (64 * 256), 0, rc & 127, s, lane);
+  // rc = first row/col of this wave's 16-wide MFMA tile inside the block tile; k-step s is 32 deep
+  if constexpr (!TR) return RowTile<bf16_t, 64>::frag16(tile, rc, s, lane);
+  else return TrTile<bf16_t, 128>::frag16(tile + (rc >> 7) * (64 * 256), 0, rc & 127, s, lane);
 }
 
 // ---- per-lane epilogue for 8 consecutive columns of one output row
@@ -129,7 +130,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
 template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;     // 16x16 MFMA tiles per wave
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -150,26 +151,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nkt = (kend - kbeg) / BK;
 
+  // buffer descriptors: the hardware range check zero-fills rows past the end of each operand
   const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
-  const long a_rows = A_TR ? p.K : p.M, b_rows = B_TR ? p.K : p.N;
+  const long a_bytes = A_TR ? (long)(p.K - 1) * lda_b + (long)p.M * 2 : (long)(p.M - 1) * lda_b + (long)p.K * 2;
+  const long b_bytes = B_TR ? (long)(p.K - 1) * ldb_b + (long)p.N * 2 : (long)(p.N - 1) * ldb_b + (long)p.K * 2;
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0,
-                                                                (int)min(a_rows * lda_b, 0x7fffffffL), 0x00020000);
+                                                                (int)min(a_bytes, 0x7fffffffL), 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0,
-                                                                (int)min(b_rows * ldb_b, 0x7fffffffL), 0x00020000);
+                                                                (int)min(b_bytes, 0x7fffffffL), 0x00020000);
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   dma_tile<A_TR, BM, NW>(ra, smem, lda_b, m0, kbeg, wave, lane);
   dma_tile<B_TR, BN, NW>(rb, smem + A_BYTES, ldb_b, n0, kbeg, wave, lane);
 
+  const int arow = wm * (BM / WM), bcol = wn * (BN / WN);
   for (int kt = 0; kt < nkt; ++kt) {
     char* cur = smem + (kt & 1) * STAGE;
-    __builtin_amdgcn_s_waitcnt(0x0F70 & 0x3F70);   // vmcnt(0): this wave's pieces of tile kt landed
-    __syncthreads();                               // ... everyone's did, and tile kt-1 is no longer read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt landed
+    __builtin_amdgcn_s_barrier();                      // ... everyone's did, and tile kt-1 is no longer read
     if (kt + 1 < nkt) {
       char* nxt = smem + ((kt + 1) & 1) * STAGE;
       dma_tile<A_TR, BM, NW>(ra, nxt, lda_b, m0, kbeg + (kt + 1) * BK, wave, lane);
@@ -177,68 +181,72 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
     }
     const char* ta = cur;
     const char* tb = cur + A_BYTES;
+    // two 32-deep k-steps per tile; the fragments of step 1 are read while the MFMAs of step 0 run
+    bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 fa[TM], fb[TN];
+    for (int i = 0; i < TM; ++i) fa[0][i] = frag_of<A_TR>(ta, arow + i * 16, 0, lane);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = frag_of<A_TR>(ta, wm * (BM / WM) + i * 32, s, lane);
+    for (int j = 0; j < TN; ++j) fb[0][j] = frag_of<B_TR>(tb, bcol + j * 16, 0, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = frag_of<B_TR>(tb, wn * (BN / WN) + j * 32, s, lane);
+    for (int s = 0; s < 2; ++s) {
+      if (s == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[1][i] = frag_of<A_TR>(ta, arow + i * 16, 1, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[1][j] = frag_of<B_TR>(tb, bcol + j * 16, 1, lane);
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
   }
 
   // ------------------------------------------------------------ epilogue (same contract as vg_gemm.hip)
-  // Each wave transposes its accumulators through a private LDS strip ([32 rows][TN*32 cols])
-  // so that every lane owns 8 consecutive columns of one row: residual / aux loads and the
-  // result stores are 16-byte, row-contiguous accesses.
-  constexpr int SW = TN * 32 + 4;          // strip pitch in floats (16-byte aligned rows)
-  constexpr int CPR = TN * 4;              // 8-column chunks per strip row
-  constexpr int RPP = 64 / CPR;            // rows covered per pass
-  static_assert(NW * 32 * SW * 4 <= 2 * STAGE, "epilogue strips must fit in the stage buffers");
+  // Accumulator map of the 16x16 tiles: col = lane & 15, row = 4 * (lane >> 4) + reg.  Each wave
+  // transposes one 16-row band at a time through a private LDS strip ([16 rows][TN*16 cols]) so that
+  // global accesses are row-contiguous: 16-byte vectors for the normal epilogue, two 128-byte row
+  // segments per wave-instruction for the split-K fp32 atomics (the shape the memory-side atomic
+  // units take at full rate).
+  constexpr int WCOLS = TN * 16;
+  constexpr int SW = WCOLS + 4;            // strip pitch in floats (16-byte aligned rows)
+  static_assert(NW * 16 * SW * 4 <= 2 * STAGE, "epilogue strips must fit in the stage buffers");
   const bool split = gridDim.z > 1;
-  if (split) {
-    // split-K partial sums (weight gradients): fp32 atomics straight from the accumulator
-    // layout -- one wave-instruction adds two 128-byte row segments, the shape the
-    // memory-side atomic units take at full rate.
-    float* __restrict__ c = reinterpret_cast<float*>(p.C);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int m = m0 + wm * (BM / WM) + i * 32 + acc_row(rr, lane);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-          if (m < p.M && n < p.N) atomicAdd(c + (long)m * p.ldc + n, acc[i][j][rr] * p.alpha);
-        }
-      }
-    return;
-  }
   __syncthreads();                         // every wave is done reading the last stage
-  float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SW);
-  const int crow = lane / CPR, cch = lane % CPR;
+  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) strip[acc_row(rr, lane) * SW + j * 32 + (lane & 31)] = acc[i][j][rr] * p.alpha;
-    for (int ps = 0; ps < 32 / RPP; ++ps) {
-      const int rloc = ps * RPP + crow;
-      const int m = m0 + wm * (BM / WM) + i * 32 + rloc;
-      const int n = n0 + wn * (BN / WN) + cch * 8;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
-      if (m >= p.M || n >= p.N) continue;
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      epilogue_emit(p, split, m, n, v);
+      for (int rr = 0; rr < 4; ++rr)
+        strip[(4 * (lane >> 4) + rr) * SW + j * 16 + (lane & 15)] = acc[i][j][rr] * p.alpha;
+    const int mband = m0 + arow + i * 16;
+    if (split) {
+      float* __restrict__ c = reinterpret_cast<float*>(p.C);
+      constexpr int SEGS = WCOLS / 32;     // 32-float segments per strip row
+      for (int it = lane >> 5; it < 16 * SEGS; it += 2) {
+        const int rloc = it / SEGS, seg = it % SEGS;
+        const int m = mband + rloc, n = n0 + bcol + seg * 32 + (lane & 31);
+        if (m < p.M && n < p.N) atomicAdd(c + (long)m * p.ldc + n, strip[rloc * SW + seg * 32 + (lane & 31)]);
+      }
+    } else {
+      constexpr int CPR = WCOLS / 8;       // 8-column chunks per strip row
+      constexpr int RPP = 64 / CPR;        // rows covered per pass
+      const int crow = lane / CPR, cch = lane % CPR;
+      for (int ps = 0; ps < (16 + RPP - 1) / RPP; ++ps) {
+        const int rloc = ps * RPP + crow;
+        if (rloc >= 16) continue;
+        const int m = mband + rloc, n = n0 + bcol + cch * 8;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
+        if (m >= p.M || n >= p.N) continue;
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        epilogue_emit(p, false, m, n, v);
+      }
     }
   }
 }

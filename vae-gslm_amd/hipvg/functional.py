@@ -80,9 +80,15 @@ def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -
     tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
     if dtype == torch.float32:
         return 1 if tiles > 4 else max(1, min(32, k_red // 256))
-    s = max(1, 512 // max(tiles, 1))
-    s = min(s, max(1, k_red // 256), 16)
-    return s
+    # measured on MI355X (tools/wgrad_split_sweep.py): 2 for the big layer weights, ~6 for 64-tile
+    # outputs, up to 12 for the small ones
+    if tiles >= 128:
+        s = 2
+    elif tiles >= 48:
+        s = 6
+    else:
+        s = min(12, max(1, 768 // max(tiles, 1)))
+    return max(1, min(s, k_red // 256))
 
 
 def colsum(x: Tensor) -> Tensor:
