@@ -151,9 +151,11 @@ int vg_prior_logp_bwd(const float* dlog_p, const float* dkl_rows, const float* m
  * deterministic fp32 sum of n values -> out[0] (single block tree) */
 int vg_sum_f32(const float* x, int64_t n, float* out, vg_stream_t stream);
 /* column sums of a [M][N] matrix (dtype) -> fp32 [N]; bias gradients and the
- * second stage of the RMSNorm scale gradient.  ws: fp32 [vg_colsum_blocks(M)][N]. */
+ * second stage of the RMSNorm scale gradient.  ws: fp32 [vg_colsum_blocks(M)][N].
+ * accumulate != 0: out[n] += sum (gradient accumulation straight into param.grad). */
 int vg_colsum_blocks(int M);
-int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, int dtype, vg_stream_t stream);
+int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, int dtype, int accumulate,
+              vg_stream_t stream);
 /* dx = dy * act'(aux): ReLU takes aux = activation output, GELU (erf) takes aux = pre-activation
  * (modules/activations.py:5-18 backward, for Linear+activation heads with several consumers). */
 int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, vg_stream_t stream);

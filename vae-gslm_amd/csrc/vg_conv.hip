@@ -8,7 +8,9 @@
 //   dwnorm_bwd_norm : du = d(loss)/dv   (+ per-block partial sums for gamma/beta grads)
 //   dwnorm_bwd_conv : dx[t] = sum_k w[k] du[t - off_k]  (+ optional residual-gradient add),
 //                     per-block partial sums of the tap gradients
-// One wave64 per frame, 16-byte loads, fp32 statistics; channels per lane = C / 64.
+// One wave64 per frame, 16-byte loads, fp32 statistics.  Every wave walks a strided set of
+// frames with its channels' tap weights, bias and affine parameters held in registers
+// (they are frame-invariant), so the inner loop is loads of x / dy rows and FMAs only.
 // The per-frame norm is the reference's "InstanceNorm" (modules/norm.py:43-47:
 // statistics over the channel axis, unbiased variance, fp32).
 #include "vg_common.h"
@@ -18,7 +20,6 @@ using namespace vg;
 
 namespace {
 
-constexpr int MAXV = 2;       // 16-byte vectors per lane (C <= 1024 bf16 / 512 f32)
 constexpr int MAXTAPS = 8;
 
 template <typename T> struct V8;
@@ -53,39 +54,58 @@ struct DwArgs {
   float eps;
 };
 
+// frame-invariant per-lane parameters (NV 16-byte channel vectors per lane)
+template <typename T, int NV> struct LaneParams {
+  float w[NV][MAXTAPS][V8<T>::N];
+  float cb[NV][V8<T>::N];
+  VG_DEVICE void load(const float* __restrict__ wsrc, const float* __restrict__ cbias, const DwArgs& a, int lane) {
+    constexpr int N = V8<T>::N;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        cb[i][e] = (cbias && a.taps > 0) ? cbias[c * N + e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXTAPS; ++k) w[i][k][e] = (k < a.taps) ? wsrc[(c * N + e) * a.taps + k] : 0.f;
+      }
+    }
+  }
+};
+
 // v = conv(x)[row] + cbias + temb[b]   for this lane's channels (taps == 0: v = x[row])
-template <typename T>
-VG_DEVICE void conv_row(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ cbias,
-                        const float* __restrict__ temb, const DwArgs& a, int row, int lane, float (&v)[MAXV][8]) {
+template <typename T, int NV>
+VG_DEVICE void conv_row(const T* __restrict__ x, const LaneParams<T, NV>& lp, const float* __restrict__ temb,
+                        const DwArgs& a, int row, int lane, float (&v)[NV][8]) {
   constexpr int N = V8<T>::N;
-  const int nvec = a.C / N;
   const int b = row / a.Tn, t = row - b * a.Tn;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
-    if (c >= nvec) continue;
     if (a.taps == 0) {
       V8<T>::load(x + (long)row * a.C + c * N, v[i]);
       continue;
     }
 #pragma unroll
-    for (int e = 0; e < N; ++e) v[i][e] = cbias ? cbias[c * N + e] : 0.f;
+    for (int e = 0; e < N; ++e) v[i][e] = lp.cb[i][e];
     if (temb) {
 #pragma unroll
       for (int e = 0; e < N; ++e) v[i][e] += temb[(long)b * a.C + c * N + e];
     }
-    for (int k = 0; k < a.taps; ++k) {
-      const int ts = t + k - a.shift;
-      if (ts < 0 || ts >= a.Tn) continue;
-      float xv[8];
-      V8<T>::load(x + ((long)b * a.Tn + ts) * a.C + c * N, xv);
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[i][e] = fmaf(w[(c * N + e) * a.taps + k], xv[e], v[i][e]);
+    for (int k = 0; k < MAXTAPS; ++k) {
+      const int ts = t + k - a.shift;
+      if (k < a.taps && ts >= 0 && ts < a.Tn) {
+        float xv[8];
+        V8<T>::load(x + ((long)b * a.Tn + ts) * a.C + c * N, xv);
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[i][e] = fmaf(lp.w[i][k][e], xv[e], v[i][e]);
+      }
     }
   }
 }
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void dwnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ cbias,
                                                          const float* __restrict__ temb,
@@ -94,43 +114,46 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_kernel(const T* __restrict__ x
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                          DwArgs a) {
   constexpr int N = V8<T>::N;
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.M) return;
-  const int nvec = a.C / N;
-  float v[MAXV][8];
-  conv_row<T>(x, w, cbias, temb, a, row, lane, v);
-  float s = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LaneParams<T, NV> lp;
+  lp.load(w, cbias, a, lane);
+  float gm[NV][N], bt[NV][N];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (lane + 64 * i < nvec) {
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      gm[i][e] = gamma[(lane + 64 * i) * N + e];
+      bt[i][e] = beta[(lane + 64 * i) * N + e];
+    }
+  for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
+    float v[NV][8];
+    conv_row<T, NV>(x, lp, temb, a, row, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
 #pragma unroll
       for (int e = 0; e < N; ++e) s += v[i][e];
-    }
-  const float mean = wave_sum(s) / (float)a.C;
-  float q = 0.f;
+    const float mean = wave_sum(s) / (float)a.C;
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (lane + 64 * i < nvec) {
+    for (int i = 0; i < NV; ++i)
 #pragma unroll
       for (int e = 0; e < N; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)(a.C - 1) + a.eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] = fmaf(gm[i][e], (v[i][e] - mean) * rstd, bt[i][e]);
+      V8<T>::store(y + (long)row * a.C + (lane + 64 * i) * N, o);
     }
-  const float rstd = rsqrtf(wave_sum(q) / (float)(a.C - 1) + a.eps);
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
-    if (c >= nvec) continue;
-    float o[8];
-#pragma unroll
-    for (int e = 0; e < N; ++e) o[e] = fmaf(gamma[c * N + e], (v[i][e] - mean) * rstd, beta[c * N + e]);
-    V8<T>::store(y + (long)row * a.C + c * N, o);
   }
 }
 
 // du = r * (g - mean(g)) - r^3 / (C - 1) * d * sum(g * d),  g = dy * gamma, d = v - mean
 // part[block][0][c] = sum_rows dy * xhat ; part[block][1][c] = sum_rows dy
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void dwnorm_bwd_norm_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                               const float* __restrict__ w,
                                                               const float* __restrict__ cbias,
@@ -142,28 +165,30 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_kernel(const T* __restric
   constexpr int N = V8<T>::N;
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nvec = a.C / N;
-  float sg[MAXV][8], sb[MAXV][8];
+  LaneParams<T, NV> lp;
+  lp.load(w, cbias, a, lane);
+  float gm[NV][N], sg[NV][N], sb[NV][N];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sg[i][e] = sb[i][e] = 0.f;
+    for (int e = 0; e < N; ++e) {
+      gm[i][e] = gamma[(lane + 64 * i) * N + e];
+      sg[i][e] = sb[i][e] = 0.f;
+    }
   for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
-    float v[MAXV][8], g[MAXV][8];
-    conv_row<T>(x, w, cbias, temb, a, row, lane, v);
+    float v[NV][8], g[NV][8];
+    conv_row<T, NV>(x, lp, temb, a, row, lane, v);
     const float mean = mean_in[row], r = rstd_in[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c >= nvec) continue;
+    for (int i = 0; i < NV; ++i) {
       float dyv[8];
-      V8<T>::load(dy + (long)row * a.C + c * N, dyv);
+      V8<T>::load(dy + (long)row * a.C + (lane + 64 * i) * N, dyv);
 #pragma unroll
       for (int e = 0; e < N; ++e) {
         const float d = v[i][e] - mean;
         v[i][e] = d;
-        g[i][e] = dyv[e] * gamma[c * N + e];
+        g[i][e] = dyv[e] * gm[i][e];
         s1 += g[i][e];
         s2 += g[i][e] * d;
         sg[i][e] += dyv[e] * d * r;
@@ -173,39 +198,36 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_kernel(const T* __restric
     s1 = wave_sum(s1) / (float)a.C;
     s2 = wave_sum(s2) * r * r * r / (float)(a.C - 1);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c >= nvec) continue;
+    for (int i = 0; i < NV; ++i) {
       float o[8];
 #pragma unroll
       for (int e = 0; e < N; ++e) o[e] = r * (g[i][e] - s1) - s2 * v[i][e];
-      V8<T>::store(du + (long)row * a.C + c * N, o);
+      V8<T>::store(du + (long)row * a.C + (lane + 64 * i) * N, o);
     }
   }
   float* scratch = &red[0][0];
 #pragma unroll
   for (int which = 0; which < 2; ++which)
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < N; ++e) scratch[(wave * 64 + lane) * N + e] = which ? sb[i][e] : sg[i][e];
       __syncthreads();
-      const int c = lane + 64 * i;
-      if (wave == 0 && c < nvec) {
+      if (wave == 0) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           float t = 0.f;
 #pragma unroll
           for (int ww = 0; ww < 4; ++ww) t += scratch[(ww * 64 + lane) * N + e];
-          part[((long)blockIdx.x * 2 + which) * a.C + c * N + e] = t;
+          part[((long)blockIdx.x * 2 + which) * a.C + (lane + 64 * i) * N + e] = t;
         }
       }
     }
 }
 
 // dx[t] = dx_add[t] + sum_k w[c][k] * du[t - (k - shift)] ; wpart[block][c][k] = sum_rows du[t] * x[t + k - shift]
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void dwnorm_bwd_conv_kernel(const T* __restrict__ du, const T* __restrict__ x,
                                                               const float* __restrict__ w,
                                                               const T* __restrict__ dx_add, T* __restrict__ dx,
@@ -213,20 +235,20 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_kernel(const T* __restric
   constexpr int N = V8<T>::N;
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nvec = a.C / N;
-  float gw[MAXV][MAXTAPS][8];
+  LaneParams<T, NV> lp;
+  lp.load(w, nullptr, a, lane);
+  float gw[NV][MAXTAPS][N];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int k = 0; k < MAXTAPS; ++k)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) gw[i][k][e] = 0.f;
+      for (int e = 0; e < N; ++e) gw[i][k][e] = 0.f;
   for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
     const int b = row / a.Tn, t = row - b * a.Tn;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
-      if (c >= nvec) continue;
       float o[8], duv[8];
       if (dx_add) V8<T>::load(dx_add + (long)row * a.C + c * N, o);
       else {
@@ -236,16 +258,15 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_kernel(const T* __restric
       V8<T>::load(du + (long)row * a.C + c * N, duv);
 #pragma unroll
       for (int k = 0; k < MAXTAPS; ++k) {
-        if (k >= a.taps) break;
         const int td = t - (k - a.shift);     // output frame whose tap k read input frame t
-        if (td >= 0 && td < a.Tn) {
+        if (k < a.taps && td >= 0 && td < a.Tn) {
           float dv[8];
           V8<T>::load(du + ((long)b * a.Tn + td) * a.C + c * N, dv);
 #pragma unroll
-          for (int e = 0; e < N; ++e) o[e] = fmaf(w[(c * N + e) * a.taps + k], dv[e], o[e]);
+          for (int e = 0; e < N; ++e) o[e] = fmaf(lp.w[i][k][e], dv[e], o[e]);
         }
         const int ts = t + k - a.shift;       // input frame tap k of output frame t reads
-        if (ts >= 0 && ts < a.Tn) {
+        if (k < a.taps && ts >= 0 && ts < a.Tn) {
           float xv[8];
           V8<T>::load(x + ((long)b * a.Tn + ts) * a.C + c * N, xv);
 #pragma unroll
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_kernel(const T* __restric
   }
   float* scratch = &red[0][0];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int k = 0; k < MAXTAPS; ++k) {
       if (k >= a.taps) break;
@@ -265,14 +286,13 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_kernel(const T* __restric
 #pragma unroll
       for (int e = 0; e < N; ++e) scratch[(wave * 64 + lane) * N + e] = gw[i][k][e];
       __syncthreads();
-      const int c = lane + 64 * i;
-      if (wave == 0 && c < nvec) {
+      if (wave == 0) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           float t = 0.f;
 #pragma unroll
           for (int ww = 0; ww < 4; ++ww) t += scratch[(ww * 64 + lane) * N + e];
-          wpart[(long)blockIdx.x * a.C * a.taps + (c * N + e) * a.taps + k] = t;
+          wpart[(long)blockIdx.x * a.C * a.taps + ((lane + 64 * i) * N + e) * a.taps + k] = t;
         }
       }
     }
@@ -282,16 +302,34 @@ int check_shape(const char* who, int M, int C, int T, int taps, int dtype) {
   const int n = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "%s: bad dtype %d", who, dtype);
   VG_REQUIRE(M > 0 && T > 0 && M % T == 0, "%s: M=%d must be a multiple of T=%d", who, M, T);
-  VG_REQUIRE(C % n == 0 && C / n <= 64 * MAXV && C > 1, "%s: C=%d unsupported", who, C);
+  VG_REQUIRE(C % (64 * n) == 0 && C / (64 * n) <= 2, "%s: C=%d unsupported (multiple of %d, at most %d)", who, C,
+             64 * n, 128 * n);
   VG_REQUIRE(taps >= 0 && taps <= MAXTAPS, "%s: taps=%d unsupported", who, taps);
   return 0;
+}
+
+template <typename T, int NV>
+void launch_fwd(const void* x, const float* w, const float* cbias, const float* temb, const float* gamma,
+                const float* beta, void* y, float* mean, float* rstd, const DwArgs& a, int nb, hipStream_t stream) {
+  dwnorm_fwd_kernel<T, NV><<<dim3(nb), dim3(256), 0, stream>>>((const T*)x, w, cbias, temb, gamma, beta, (T*)y, mean,
+                                                              rstd, a);
+}
+template <typename T, int NV>
+void launch_bwd(const void* dy, const void* x, const float* w, const float* cbias, const float* temb,
+                const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
+                float* norm_part, float* w_part, const DwArgs& a, int nb, hipStream_t stream) {
+  dwnorm_bwd_norm_kernel<T, NV><<<dim3(nb), dim3(256), 0, stream>>>((const T*)dy, (const T*)x, w, cbias, temb, gamma,
+                                                                   mean, rstd, (T*)du, norm_part, a);
+  if (a.taps > 0)
+    dwnorm_bwd_conv_kernel<T, NV><<<dim3(nb), dim3(256), 0, stream>>>((const T*)du, (const T*)x, w,
+                                                                     (const T*)dx_add, (T*)dx, w_part, a);
 }
 
 }  // namespace
 
 extern "C" int vg_dwnorm_blocks(int M) {
   const int b = (M + 3) / 4;
-  return b < 256 ? b : 256;
+  return b < 512 ? b : 512;
 }
 
 extern "C" int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, const float* temb,
@@ -299,12 +337,15 @@ extern "C" int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, 
                              int T, int taps, int shift, float eps, int dtype, hipStream_t stream) {
   if (int e = check_shape("vg_dwnorm_fwd", M, C, T, taps, dtype)) return e;
   DwArgs a{M, C, T, taps, shift, eps};
-  if (dtype == VG_BF16)
-    dwnorm_fwd_kernel<bf16_t><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>(
-        (const bf16_t*)x, w, cbias, temb, gamma, beta, (bf16_t*)y, mean, rstd, a);
-  else
-    dwnorm_fwd_kernel<float><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const float*)x, w, cbias, temb, gamma,
-                                                                         beta, (float*)y, mean, rstd, a);
+  const int nb = min((M + 3) / 4, 1024);
+  const int nv = C / (64 * (dtype == VG_BF16 ? 8 : 4));
+  if (dtype == VG_BF16) {
+    if (nv == 1) launch_fwd<bf16_t, 1>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
+    else launch_fwd<bf16_t, 2>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
+  } else {
+    if (nv == 1) launch_fwd<float, 1>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
+    else launch_fwd<float, 2>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
+  }
   return vg_host::check_launch("vg_dwnorm_fwd");
 }
 
@@ -315,18 +356,13 @@ extern "C" int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, cons
   if (int e = check_shape("vg_dwnorm_bwd", M, C, T, taps, dtype)) return e;
   DwArgs a{M, C, T, taps, shift, 0.f};
   const int nb = vg_dwnorm_blocks(M);
+  const int nv = C / (64 * (dtype == VG_BF16 ? 8 : 4));
   if (dtype == VG_BF16) {
-    dwnorm_bwd_norm_kernel<bf16_t><<<dim3(nb), dim3(256), 0, stream>>>(
-        (const bf16_t*)dy, (const bf16_t*)x, w, cbias, temb, gamma, mean, rstd, (bf16_t*)du, norm_part, a);
-    if (taps > 0)
-      dwnorm_bwd_conv_kernel<bf16_t><<<dim3(nb), dim3(256), 0, stream>>>(
-          (const bf16_t*)du, (const bf16_t*)x, w, (const bf16_t*)dx_add, (bf16_t*)dx, w_part, a);
+    if (nv == 1) launch_bwd<bf16_t, 1>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
+    else launch_bwd<bf16_t, 2>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
   } else {
-    dwnorm_bwd_norm_kernel<float><<<dim3(nb), dim3(256), 0, stream>>>(
-        (const float*)dy, (const float*)x, w, cbias, temb, gamma, mean, rstd, (float*)du, norm_part, a);
-    if (taps > 0)
-      dwnorm_bwd_conv_kernel<float><<<dim3(nb), dim3(256), 0, stream>>>(
-          (const float*)du, (const float*)x, w, (const float*)dx_add, (float*)dx, w_part, a);
+    if (nv == 1) launch_bwd<float, 1>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
+    else launch_bwd<float, 2>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
   }
   return vg_host::check_launch("vg_dwnorm_bwd");
 }

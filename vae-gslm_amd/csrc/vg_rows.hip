@@ -212,6 +212,26 @@ __global__ void colsum_kernel(const T* __restrict__ x, int M, int N, long ld, fl
   }
 }
 
+// final / small-input stage: one column per thread, 16 row lanes per block, optional accumulate
+template <typename T>
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const T* __restrict__ x, int M, int N, long ld,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (c < N)
+    for (int m = ty; m < M; m += 16) s += to_f32<T>(x[(long)m * ld + c]);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][tx];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
   __shared__ float red[16];
   float s = 0.f;
@@ -466,20 +486,28 @@ extern "C" int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale,
 }
 
 extern "C" int vg_colsum_blocks(int M) {
+  if (M <= 2048) return 1;            // small inputs (partial-sum arrays): one pass, one launch
   const int b = (M + 31) / 32;
-  return b < 128 ? (b > 0 ? b : 1) : 128;
+  return b < 128 ? b : 128;
 }
 
 extern "C" int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, int dtype,
-                         hipStream_t stream) {
+                         int accumulate, hipStream_t stream) {
   VG_REQUIRE(N % 4 == 0 && M > 0, "vg_colsum: N=%d must be a multiple of 4", N);
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_colsum: bad dtype %d", dtype);
   const int nb = vg_colsum_blocks(M);
-  dim3 grid1((N + 255) / 256, nb), grid2((N + 255) / 256, 1);
-  float* first = nb == 1 ? out : ws;
-  if (dtype == VG_BF16) run_colsum<bf16_t>(nb == 1 ? grid2 : grid1, x, M, N, (long)ld, first, stream);
-  else run_colsum<float>(nb == 1 ? grid2 : grid1, x, M, N, (long)ld, first, stream);
-  if (nb > 1) run_colsum<float>(grid2, ws, nb, N, (long)N, out, stream);
+  dim3 gridf((N + 63) / 64), blockf(64, 16);
+  if (nb == 1) {
+    if (dtype == VG_BF16)
+      colsum_final_kernel<bf16_t><<<gridf, blockf, 0, stream>>>((const bf16_t*)x, M, N, (long)ld, out, accumulate);
+    else
+      colsum_final_kernel<float><<<gridf, blockf, 0, stream>>>((const float*)x, M, N, (long)ld, out, accumulate);
+  } else {
+    dim3 grid1((N + 255) / 256, nb);
+    if (dtype == VG_BF16) run_colsum<bf16_t>(grid1, x, M, N, (long)ld, ws, stream);
+    else run_colsum<float>(grid1, x, M, N, (long)ld, ws, stream);
+    colsum_final_kernel<float><<<gridf, blockf, 0, stream>>>(ws, nb, N, (long)N, out, accumulate);
+  }
   return vg_host::check_launch("vg_colsum");
 }
 

@@ -54,7 +54,7 @@ SIGNATURES = {
     "vg_prior_logp_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
     "vg_sum_f32": [_vp, _i64, _vp, _vp],
     "vg_colsum_blocks": [_i],
-    "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _vp],
+    "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp],
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "vg_mask_rows": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],

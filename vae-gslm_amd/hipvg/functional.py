@@ -91,14 +91,32 @@ def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -
     return max(1, min(s, k_red // 256))
 
 
-def colsum(x: Tensor) -> Tensor:
+def colsum(x: Tensor, into: Optional[Tensor] = None) -> Tensor:
+    """Column sums of [M, N]; ``into`` (fp32, N elements, contiguous) receives ``+=`` the result."""
     M, N = x.shape
     nb = lib().vg_colsum_blocks(M)
-    ws = torch.empty((nb, N), dtype=torch.float32, device=x.device)
-    out = torch.empty((N,), dtype=torch.float32, device=x.device)
-    check(lib().vg_colsum(ptr(x), M, N, x.stride(0), ptr(ws), ptr(out), dtype_id(x.dtype), stream()),
-          "vg_colsum")
+    ws = torch.empty((nb, N), dtype=torch.float32, device=x.device) if nb > 1 else None
+    out = into if into is not None else torch.empty((N,), dtype=torch.float32, device=x.device)
+    check(lib().vg_colsum(ptr(x), M, N, x.stride(0), ptr(ws), ptr(out), dtype_id(x.dtype),
+                          int(into is not None), stream()), "vg_colsum")
     return out
+
+
+def vec_grad(p, src2d: Tensor):
+    """Gradient of a vector-like parameter = column sums of ``src2d``: accumulated straight into
+    ``p.grad`` when the gradient sink applies (returns None), else returned as a tensor."""
+    if p is None:
+        return None
+    if _sinkable(p):
+        sink_colsum(p, src2d)
+        return None
+    return colsum(src2d).view_as(p)
+
+
+def sink_colsum(p: Tensor, x: Tensor) -> None:
+    """p.grad (any shape with N elements) += column sums of x[M, N]."""
+    colsum(x, into=_grad_buffer(p).view(-1))
+    _fire(p)
 
 
 def act_bwd(dy: Tensor, aux: Tensor, act: int) -> Tensor:
@@ -147,6 +165,7 @@ class LinearFn(torch.autograd.Function):
             aux = y
         ctx.save_for_backward(x, w, aux, lengths)
         ctx.meta = (T, act, bias is not None, residual is not None, weight.shape)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -164,11 +183,18 @@ class LinearFn(torch.autograd.Function):
         dx = dW = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = gemm(du, w, M, K, N, b_tr=True, lengths=lengths, T=T)
+        weight, bias = ctx.params
         if ctx.needs_input_grad[1]:
-            s = wgrad_splits(N, K, M, x.dtype)
-            dW = gemm(du, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=s)
+            if _sinkable(weight) and weight.dim() == 2 and weight.is_contiguous():
+                sink_wgrad(weight, du, x)          # accumulate straight into weight.grad
+            else:
+                s = wgrad_splits(N, K, M, x.dtype)
+                dW = gemm(du, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=s)
         if has_bias and ctx.needs_input_grad[2]:
-            db = colsum(du)
+            if _sinkable(bias):
+                sink_colsum(bias, du)
+            else:
+                db = colsum(du)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dW, db, dres, None, None, None, None
@@ -464,7 +490,7 @@ def rmsnorm_bwd_raw(dy, x, sc, rstd, dx_add, lengths, T):
     part = torch.empty((nb, Cc), dtype=torch.float32, device=x.device)
     check(lib().vg_rmsnorm_bwd(ptr(dy), ptr(x), ptr(sc), ptr(rstd), ptr(dx_add), ptr(dx), ptr(part), M, Cc,
                                ptr(lengths), int(T), dtype_id(x.dtype), stream()), "vg_rmsnorm_bwd")
-    return dx, colsum(part)
+    return dx, part
 
 
 def rmsnorm_fwd_raw(x, sc, eps, lengths, T):
@@ -543,25 +569,25 @@ class TransformerLayerFn(torch.autograd.Function):
         # ---- FFN
         du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_GELU, aux_in=u)
         g_w2 = wgrad(w2, dy, h)
-        g_b2 = vgrad(b2, lambda: colsum(dy))
+        g_b2 = vec_grad(b2, dy)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
         g_w1 = wgrad(w1, du, n3)
-        g_b1 = vgrad(b1, lambda: colsum(du))
+        g_b1 = vec_grad(b1, du)
         dx1, ds3 = rmsnorm_bwd_raw(dn3, x1, sc3, rstd3, dy, lengths, T)
-        g_n3 = vgrad(n3s, lambda: ds3)
+        g_n3 = vec_grad(n3s, ds3)
         # ---- attention
         datt = gemm(dx1, so, M, D, D, b_tr=True)
         g_wo = wgrad(wo, dx1, att)
-        g_bo = vgrad(bo, lambda: colsum(dx1))
+        g_bo = vec_grad(bo, dx1)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
         check(lib().vg_attn_bwd(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
                                 B, T, H, ptr(lengths), dtype_id(dt), stream()), "vg_attn_bwd")
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
         g_wq = wgrad(wqkv, dqkv, n1)
-        g_bq = vgrad(bqkv, lambda: colsum(dqkv))
+        g_bq = vec_grad(bqkv, dqkv)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
-        g_n1 = vgrad(n1s, lambda: ds1)
+        g_n1 = vec_grad(n1s, ds1)
         return (dx, g_n1, g_wq, g_bq, g_wo, g_bo, g_n3, g_w1, g_b1, g_w2, g_b2,
                 None, None, None, None, None, None)
 
@@ -592,9 +618,7 @@ def dwnorm_bwd_raw(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
     check(lib().vg_dwnorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
                               ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, int(T), int(taps),
                               int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd")
-    gb = colsum(npart)
-    dw = colsum(wpart) if taps > 0 else None
-    return du, dx, gb[:Cc], gb[Cc:], dw
+    return du, dx, npart[:, :Cc], npart[:, Cc:], (wpart if taps > 0 else None)
 
 
 def _sink_or_return(p, value):
@@ -661,7 +685,7 @@ class ConvBlockFn(torch.autograd.Function):
                         split_k=wgrad_splits(rows, cols, M, dt))
 
         g_c3 = wgrad_into(c3w, Cc, 0, Hd, dy, h)
-        g_c3b = _sink_or_return(c3b, colsum(dy))
+        g_c3b = vec_grad(c3b, dy)
         du = gemm(dpre, Wa, M, Cc, Hd, b_tr=True)
         ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u)
         dcond = gc = None
@@ -679,13 +703,13 @@ class ConvBlockFn(torch.autograd.Function):
             _fire(c3w)
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
-        g_c2b = _sink_or_return(c2b, colsum(dpre))
-        dv, dx, dgamma, dbeta, dw1 = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
+        g_c2b = vec_grad(c2b, dpre)
+        dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
         dte = dv.view(-1, T, Cc).float().sum(1)
-        g_c1w = _sink_or_return(c1w, dw1)
-        g_c1b = _sink_or_return(c1b, dte.sum(0))
-        g_nw = _sink_or_return(nw, dgamma)
-        g_nb = _sink_or_return(nb_, dbeta)
+        g_c1w = vec_grad(c1w, pw)
+        g_c1b = vec_grad(c1b, dte)
+        g_nw = vec_grad(nw, pg)
+        g_nb = vec_grad(nb_, pb)
         return (dx, dte if has_te else None, dcond, g_c1w, g_c1b, g_nw, g_nb, g_c2, g_c2b, g_c3, g_c3b,
                 None, None, None, None, None)
 
@@ -709,9 +733,9 @@ class ChannelNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
-        du, _, dgamma, dbeta, _ = dwnorm_bwd_raw(_as(dy, x.dtype), x, None, None, None, gamma, mean, rstd, None,
-                                                 ctx.T, 0, 0)
-        return du, dgamma, dbeta, None, None
+        du, _, pg, pb, _ = dwnorm_bwd_raw(_as(dy, x.dtype), x, None, None, None, gamma, mean, rstd, None,
+                                          ctx.T, 0, 0)
+        return du, colsum(pg), colsum(pb), None, None
 
 
 def channel_norm(x, weight, bias, *, T, eps):
