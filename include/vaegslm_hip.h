@@ -72,7 +72,7 @@ typedef struct vg_gemm_desc {
   int split_k;
   float alpha;
   const void* pre_add;  /* [M][ldc] added before the activation (conditioning term of the conv blocks) or NULL */
-  int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..4 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 */
+  int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..5 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 / 256x128 with a 3-stage ring */
 } vg_gemm_desc;
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 

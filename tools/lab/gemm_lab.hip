@@ -180,8 +180,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 // ---- variant B: v_mfma_f32_16x16x32_bf16, wave tile (BM/WM) x (BN/WN) as 16x16 tiles, optional
 //      software-pipelined fragment reads (PIPE = 1: fragments of k-step s+1 are read before the MFMAs of s)
-template <int BM, int BN, int WM, int WN, int PIPE>
+template <int BM, int BN, int WM, int WN, int PIPE, int STAGES = 2>
 __global__ __launch_bounds__(WM* WN * 64) void lab16_kernel(P p) {
+  constexpr int PIECES16 = ((BM + BN) / 8) / (WM * WN);
   constexpr int NW = WM * WN, TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(WM* WN * 64) void lab16_kernel(P p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
   auto issue = [&](int kt) {
-    char* st = smem + (kt & 1) * STAGE;
+    char* st = smem + (kt % STAGES) * STAGE;
     dma_rows<BM, NW>(ra, st, ldb, m0, kt * BK, wave, lane);
     dma_rows<BN, NW>(rb, st + A_BYTES, ldb, n0, kt * BK, wave, lane);
   };
@@ -211,12 +212,18 @@ __global__ __launch_bounds__(WM* WN * 64) void lab16_kernel(P p) {
     const int row = row0 + (lane & 15);
     return *reinterpret_cast<const bf16x8*>(tile + RowTile<bf16_t, 64>::chunk_off(row, 4 * s + (lane >> 4)));
   };
-  issue(0);
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nkt) issue(s0);
   for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tiles kt .. kt+STAGES-2 are in flight: wait for tile kt only
+    const int ahead = min(STAGES - 2, nkt - 1 - kt);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES16) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES16) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nkt) issue(kt + 1);
-    const char* ta = smem + (kt & 1) * STAGE;
+    if (kt + STAGES - 1 < nkt) issue(kt + STAGES - 1);
+    const char* ta = smem + (kt % STAGES) * STAGE;
     const char* tb = ta + A_BYTES;
     bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -273,10 +280,10 @@ __global__ __launch_bounds__(WM* WN * 64) void lab16_kernel(P p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PIPE>
+template <int BM, int BN, int WM, int WN, int PIPE, int STAGES = 2>
 float run16(const P& p, const char* name, int iters) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * BK * 2;
-  auto k = lab16_kernel<BM, BN, WM, WN, PIPE>;
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  auto k = lab16_kernel<BM, BN, WM, WN, PIPE, STAGES>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   hipEvent_t a, b;
@@ -316,14 +323,13 @@ int main() {
     printf("operand sets: %d\n", g_nsets);
     p.M = M; p.N = N; p.K = K;
     const int it = 36;
-    run<128, 128, 2, 2, 2, 0>(p, "128x128 4w 2st mfma32", it);
     run16<128, 128, 2, 2, 1>(p, "128x128 4w 2st mfma16 pipe", it);
-    run<128, 128, 2, 2, 3, 0>(p, "128x128 4w 3st mfma32", it);
-    run<256, 128, 4, 2, 2, 0>(p, "256x128 8w(4x2) 2st mfma32", it);
-    run<256, 128, 4, 2, 3, 0>(p, "256x128 8w(4x2) 3st mfma32", it);
-    run16<256, 128, 4, 2, 1>(p, "256x128 8w(4x2) 2st mfma16 pipe", it);
-    run<256, 256, 2, 4, 2, 0>(p, "256x256 8w(2x4) 2st mfma32", it);
-    run16<256, 256, 2, 4, 1>(p, "256x256 8w(2x4) 2st mfma16 pipe", it);
+    run16<128, 128, 2, 4, 1, 3>(p, "128x128 8w(2x4) 3st mfma16 pipe", it);
+    run16<128, 128, 2, 4, 1, 4>(p, "128x128 8w(2x4) 4st mfma16 pipe", it);
+    run16<128, 128, 4, 2, 1, 4>(p, "128x128 8w(4x2) 4st mfma16 pipe", it);
+    run16<256, 128, 4, 2, 1, 2>(p, "256x128 8w(4x2) 2st mfma16 pipe", it);
+    run16<256, 128, 4, 2, 1, 3>(p, "256x128 8w(4x2) 3st mfma16 pipe", it);
+    run16<256, 256, 2, 4, 1, 2>(p, "256x256 8w(2x4) 2st mfma16 pipe", it);
     hipFree((void*)p.A); hipFree((void*)p.B); hipFree((void*)p.C);
   }
   return 0;

@@ -127,9 +127,10 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
   }
 }
 
-template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN>
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
+  constexpr int PIECES = ((BM + BN) / 8) / NW;            // LDS-DMA instructions per wave per K tile
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;     // 16x16 MFMA tiles per wave
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,19 +167,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  dma_tile<A_TR, BM, NW>(ra, smem, lda_b, m0, kbeg, wave, lane);
-  dma_tile<B_TR, BN, NW>(rb, smem + A_BYTES, ldb_b, n0, kbeg, wave, lane);
+  // ring of STAGES LDS stages: tiles kt .. kt+STAGES-2 are in flight while tile kt is consumed
+  auto issue = [&](int kt) {
+    char* st = smem + (kt % STAGES) * STAGE;
+    dma_tile<A_TR, BM, NW>(ra, st, lda_b, m0, kbeg + kt * BK, wave, lane);
+    dma_tile<B_TR, BN, NW>(rb, st + A_BYTES, ldb_b, n0, kbeg + kt * BK, wave, lane);
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nkt) issue(s0);
 
   const int arow = wm * (BM / WM), bcol = wn * (BN / WN);
   for (int kt = 0; kt < nkt; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt landed
-    __builtin_amdgcn_s_barrier();                      // ... everyone's did, and tile kt-1 is no longer read
-    if (kt + 1 < nkt) {
-      char* nxt = smem + ((kt + 1) & 1) * STAGE;
-      dma_tile<A_TR, BM, NW>(ra, nxt, lda_b, m0, kbeg + (kt + 1) * BK, wave, lane);
-      dma_tile<B_TR, BN, NW>(rb, nxt + A_BYTES, ldb_b, n0, kbeg + (kt + 1) * BK, wave, lane);
-    }
+    char* cur = smem + (kt % STAGES) * STAGE;
+    // counted wait: only this wave's pieces of tile kt must have landed, younger tiles stay in flight
+    if (STAGES >= 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; tile kt-1 is no longer read
+    if (kt + STAGES - 1 < nkt) issue(kt + STAGES - 1);
     const char* ta = cur;
     const char* tb = cur + A_BYTES;
     // two 32-deep k-steps per tile; the fragments of step 1 are read while the MFMAs of step 0 run
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   // units take at full rate).
   constexpr int WCOLS = TN * 16;
   constexpr int SW = WCOLS + 4;            // strip pitch in floats (16-byte aligned rows)
-  static_assert(NW * 16 * SW * 4 <= 2 * STAGE, "epilogue strips must fit in the stage buffers");
+  static_assert(NW * 16 * SW * 4 <= STAGES * STAGE, "epilogue strips must fit in the stage buffers");
   const bool split = gridDim.z > 1;
   __syncthreads();                         // every wave is done reading the last stage
   float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
@@ -251,10 +257,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   }
 }
 
-template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN>
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES = 2>
 int launch_cfg(const GemmParams& p, int splits, hipStream_t stream) {
-  constexpr size_t lds = 2 * (BM + BN) * BK * 2;
-  auto k = gemm_dma_kernel<A_TR, B_TR, BM, BN, WM, WN>;
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  auto k = gemm_dma_kernel<A_TR, B_TR, BM, BN, WM, WN, STAGES>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -272,6 +278,7 @@ int launch_mode(const GemmParams& p, int cfg, int splits, hipStream_t stream) {
     case 2: return launch_cfg<A_TR, B_TR, 256, 128, 4, 2>(p, splits, stream);
     case 3: return launch_cfg<A_TR, B_TR, 256, 256, 2, 4>(p, splits, stream);
     case 4: return launch_cfg<A_TR, B_TR, 128, 256, 2, 4>(p, splits, stream);
+    case 5: return launch_cfg<A_TR, B_TR, 256, 128, 4, 2, 3>(p, splits, stream);   // 3-stage ring (144 KiB LDS)
     default: return -1;
   }
 }
