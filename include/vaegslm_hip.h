@@ -73,6 +73,8 @@ typedef struct vg_gemm_desc {
   float alpha;
   const void* pre_add;  /* [M][ldc] added before the activation (conditioning term of the conv blocks) or NULL */
   int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..5 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 / 256x128 with a 3-stage ring */
+  float* colsum_out;    /* a_tr = b_tr = 1 only (weight gradient dY^T X): colsum_out[m] += sum_k A(m,k), i.e. the bias
+                           gradient of the same Linear (modules/linear/layers.py:192) from the tiles already in LDS; NULL = off */
 } vg_gemm_desc;
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 

@@ -96,6 +96,24 @@ def test_gemm_epilogues(F, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("frames", [8 * 125, 8 * 111])     # reduction length: 1000 (tail of 40) and 888 (tail of 56)
+def test_wgrad_with_fused_bias_gradient(F, dtype, frames):
+    """Weight-gradient launch that also accumulates the bias gradient (colsum_out), split-K and
+    single pass, accumulate-into-existing-gradient semantics, ragged frame counts."""
+    M, N, K = frames, 328, 192            # N = out features (not a tile multiple), K = in features
+    dy, x = rnd(M, N, dtype=dtype), rnd(M, K, dtype=dtype, seed=1)
+    ref_w = dy.double().T @ x.double()
+    ref_b = dy.double().sum(0)
+    wt = dict(atol=1e-3, rtol=1e-4) if dtype == torch.float32 else dict(atol=8e-2, rtol=2e-2)
+    for s in (1, 4):
+        gw = torch.ones(N, K, device=dev())
+        gb = torch.full((N,), 2.0, device=dev())
+        F.gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=gw, split_k=s, accumulate=(s == 1), colsum_out=gb)
+        torch.testing.assert_close(gw.double(), ref_w + 1.0, **wt)
+        torch.testing.assert_close(gb.double(), ref_b + 2.0, **wt)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_and_ffn_autograd(F, dtype):
     B_, T, D, Fd = 2, 75, 256, 512
     M = B_ * T

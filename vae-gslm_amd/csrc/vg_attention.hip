@@ -26,6 +26,13 @@ constexpr int TB = 64;       // time rows staged per LDS tile
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.69314718055994530942f;
 constexpr float SCALE = 0.125f;   // 1 / sqrt(64)
+// resident blocks per CU the bf16 kernels are register-budgeted for (measured: forward 3, backward 2)
+#ifndef VG_ATTN_OCC_FWD
+#define VG_ATTN_OCC_FWD 3
+#endif
+#ifndef VG_ATTN_OCC
+#define VG_ATTN_OCC 2
+#endif
 
 template <typename T> struct NVec { static constexpr int v = TB * DH / Traits<T>::VEC / 256; };  // 2 bf16 / 4 f32
 
@@ -154,14 +161,17 @@ VG_DEVICE f32x16 rows16(const float* arr, int row0, int lane) {
 // the probability underflows anyway.  Causal compares run on diagonal tiles only.
 // =====================================================================================
 template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const float* __restrict__ slopes,
                                                        int Tn, int H, const int* __restrict__ lengths) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_row = smem;
   char* v_tr = smem + LdsPlan<T>::ROW_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, longest sweeps first over the whole launch (LPT order); the tiles of one (b, h)
+  // are H*B apart, i.e. on the same XCD whenever H*B is a multiple of 8, and share K/V in its L2
+  const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt, hb = blockIdx.x % HB;
+  const int qt = nqt - 1 - (int)(blockIdx.x / HB), h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int len = lengths ? min(lengths[b], Tn) : Tn;
@@ -282,7 +292,7 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
 // (the 1/sqrt(d) factor of dS is applied once to the final dQ)
 // =====================================================================================
 template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
                                                           const float* __restrict__ slopes, T* __restrict__ dqkv,
@@ -292,7 +302,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
   char* v_row = smem + LdsPlan<T>::ROW_BYTES;
   char* k_tr = smem + 2 * LdsPlan<T>::ROW_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, longest sweeps first over the whole launch (LPT order); the tiles of one (b, h)
+  // are H*B apart, i.e. on the same XCD whenever H*B is a multiple of 8, and share K/V in its L2
+  const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt, hb = blockIdx.x % HB;
+  const int qt = nqt - 1 - (int)(blockIdx.x / HB), h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int len = lengths ? min(lengths[b], Tn) : Tn;
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
 // -inf for padded queries), the per-key constant slope2*(key - k0) sits on the lane.
 // =====================================================================================
 template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ slopes, T* __restrict__ dqkv,
@@ -377,7 +390,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kern
   char* do_tr = q_tr + LdsPlan<T>::TR_BYTES;
   float* st = reinterpret_cast<float*>(do_tr + LdsPlan<T>::TR_BYTES);   // [2][64]: S init, dP init
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ktile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int HB = gridDim.x / ((Tn + QB - 1) / QB), hb = blockIdx.x % HB;   // low key tiles sweep the most query tiles: first
+  const int ktile = blockIdx.x / HB, h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int len = lengths ? min(lengths[b], Tn) : Tn;
@@ -502,7 +516,7 @@ template <typename T>
 int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tn, int H,
                const int32_t* lengths, hipStream_t stream) {
   const size_t lds = LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
-  dim3 grid((Tn + QB - 1) / QB, H, B);
+  dim3 grid(((Tn + QB - 1) / QB) * H * B);
   // algorithmic work: causal-exact QK^T + PV, 2*2*64 FLOP per (query, key <= query) pair
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_FWD, 256.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
@@ -519,7 +533,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_BWD, 640.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
                      (const T*)out, (const T*)dout, delta, B, Tn, H);
-  dim3 grid((Tn + QB - 1) / QB, H, B);
+  dim3 grid(((Tn + QB - 1) / QB) * H * B);
   const size_t lds_q = 3 * LdsPlan<T>::ROW_BYTES;
   hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
                      delta, slopes, (T*)dqkv, Tn, H, lengths);

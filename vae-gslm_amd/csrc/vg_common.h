@@ -267,6 +267,8 @@ int check_launch(const char* what);
 // optional HIP-event timing (vg_prof.hip); kinds are the VG_PROF_* enum of the public header
 int prof_begin(int kind, double work, hipStream_t stream);
 void prof_end(int token, hipStream_t stream);
+// out[n] += sum_m x[m][n] in one launch without workspace (vg_rows.hip; slow path of fused bias gradients)
+void colsum_accumulate(const void* x, int M, int N, long ld, float* out, int dtype, hipStream_t stream);
 }  // namespace vg_host
 
 #define VG_REQUIRE(cond, ...)                 \

@@ -200,6 +200,8 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
     vg_host::prof_end(tok, stream);
     if (rc == 0) return vg_host::check_launch("vg_gemm(dma)");
   }
+  if (p.colsum_out)   // register-staged path: the bias gradient is a separate pass over A = dY [K][lda]
+    vg_host::colsum_accumulate(p.A, p.K, p.M, p.lda, p.colsum_out, sizeof(T) == 4 ? VG_F32 : VG_BF16, stream);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
   dim3 block(NTHREADS);
   const size_t lds = 4 * TILE_BYTES;
@@ -244,13 +246,16 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   p.lengths = d->lengths; p.T = d->T > 0 ? d->T : 1;
   p.act = d->act; p.dact = d->dact; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
   p.alpha = d->alpha;
+  p.colsum_out = d->colsum_out;
+  VG_REQUIRE(d->colsum_out == nullptr || (d->a_tr && d->b_tr), "vg_gemm: colsum_out needs a_tr = b_tr = 1");
   int kps = (d->K + splits - 1) / splits;
   kps = ((kps + bk - 1) / bk) * bk;
   splits = (d->K + kps - 1) / kps;
   p.k_per_split = kps;
   // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
   int cfg = d->tile_cfg;
-  const bool dma_ok = d->dtype == VG_BF16 && d->K % 64 == 0 && !(d->a_tr && !d->b_tr) &&
+  // K tails: fine when both operands are k-major (rows past K are zero-filled by the buffer range check)
+  const bool dma_ok = d->dtype == VG_BF16 && (d->K % 64 == 0 || (d->a_tr && d->b_tr)) && !(d->a_tr && !d->b_tr) &&
                       (long)(d->a_tr ? d->K : d->M) * d->lda * 2 < 0x7fffffffL &&
                       (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7fffffffL;
   if (!dma_ok) cfg = -1;

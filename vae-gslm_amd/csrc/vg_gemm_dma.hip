@@ -127,7 +127,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
   }
 }
 
-template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES>
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES, bool COLSUM = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int PIECES = ((BM + BN) / 8) / NW;            // LDS-DMA instructions per wave per K tile
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
 
   const int kbeg = blockIdx.z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nkt = (kend - kbeg) / BK;
+  const int nkt = (kend - kbeg + BK - 1) / BK;   // a K tail only occurs with both operands k-major (zero-filled rows)
 
   // buffer descriptors: the hardware range check zero-fills rows past the end of each operand
   const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
@@ -166,6 +166,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // COLSUM (weight-gradient launches): the waves that own the first column panel also multiply their
+  // A fragments by a constant all-ones operand -> row sums of A = the bias gradient, no extra LDS traffic
+  f32x4 csum[COLSUM ? TM : 1];
+  bool do_cs = false;
+  bf16x8 ones;
+  if constexpr (COLSUM) {
+    do_cs = p.colsum_out != nullptr && n0 == 0 && wn == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  }
 
   // ring of STAGES LDS stages: tiles kt .. kt+STAGES-2 are in flight while tile kt is consumed
   auto issue = [&](int kt) {
@@ -207,6 +220,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+      if constexpr (COLSUM) {
+        if (do_cs) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], ones, csum[i], 0, 0, 0);
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
     }
   }
@@ -221,6 +241,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   constexpr int SW = WCOLS + 4;            // strip pitch in floats (16-byte aligned rows)
   static_assert(NW * 16 * SW * 4 <= STAGES * STAGE, "epilogue strips must fit in the stage buffers");
   const bool split = gridDim.z > 1;
+  if constexpr (COLSUM) {
+    if (do_cs && (lane & 15) == 0) {       // every column of csum holds the same row sums
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int m = m0 + arow + i * 16 + 4 * (lane >> 4) + rr;
+          if (m < p.M) atomicAdd(p.colsum_out + m, csum[i][rr]);
+        }
+    }
+  }
   __syncthreads();                         // every wave is done reading the last stage
   float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
 #pragma unroll
@@ -257,10 +288,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   }
 }
 
-template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES = 2>
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES = 2, bool COLSUM = false>
 int launch_cfg(const GemmParams& p, int splits, hipStream_t stream) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
-  auto k = gemm_dma_kernel<A_TR, B_TR, BM, BN, WM, WN, STAGES>;
+  auto k = gemm_dma_kernel<A_TR, B_TR, BM, BN, WM, WN, STAGES, COLSUM>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -273,6 +304,9 @@ int launch_cfg(const GemmParams& p, int splits, hipStream_t stream) {
 
 template <bool A_TR, bool B_TR>
 int launch_mode(const GemmParams& p, int cfg, int splits, hipStream_t stream) {
+  if constexpr (A_TR && B_TR) {   // fused bias gradient: 128x128 tiles only (register budget)
+    if (p.colsum_out) return launch_cfg<A_TR, B_TR, 128, 128, 2, 2, 2, true>(p, splits, stream);
+  }
   switch (cfg) {
     case 1: return launch_cfg<A_TR, B_TR, 128, 128, 2, 2>(p, splits, stream);
     case 2: return launch_cfg<A_TR, B_TR, 256, 128, 4, 2>(p, splits, stream);

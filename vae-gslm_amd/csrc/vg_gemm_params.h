@@ -18,6 +18,7 @@ struct GemmParams {
   int accumulate;           // C += result (fp32 C only)
   int k_per_split;          // K range handled by one blockIdx.z (multiple of BK)
   float alpha;
+  float* colsum_out;        // TN mode: [M] fp32, += sum_k A(m,k) (unscaled), or null
 };
 
 namespace vg_host {

@@ -72,38 +72,62 @@ template <> struct Vec<bf16_t> {
 };
 
 // ------------------------------------------------------------------ RMSNorm forward
+// one wave per frame, grid-stride over frames; the scale vector is read once per wave and the
+// next frame's loads are issued before the current frame's reduction (two frames in flight)
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                           T* __restrict__ y, float* __restrict__ rstd, int M, int C,
                                                           float eps, const int* __restrict__ lengths, int Tlen) {
   constexpr int N = Vec<T>::N;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
   const int nvec = C / N;
-  const bool valid = row_valid(lengths, Tlen, row);
-  float v[MAXV][8];
-  float ss = 0.f;
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float sc[MAXV][8], v[MAXV][8], nx[MAXV][8];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + 64 * i;
     if (c < nvec) {
       Vec<T>::load(x + (long)row * C + c * N, v[i]);
 #pragma unroll
-      for (int e = 0; e < N; ++e) ss += v[i][e] * v[i][e];
+      for (int e = 0; e < N; ++e) sc[i][e] = scale[c * N + e];
     }
   }
-  ss = wave_sum(ss);
-  const float r = rsqrtf(ss / (float)C + eps);
-  if (lane == 0) rstd[row] = r;
+  const float inv_c = 1.0f / (float)C;
+  for (; row < M; row += stride) {
+    const int nrow = row + stride;
+    if (nrow < M) {
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) {
-      float o[8];
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) Vec<T>::load(x + (long)nrow * C + c * N, nx[i]);
+      }
+    }
+    const bool valid = row_valid(lengths, Tlen, row);
+    float ss = 0.f;
 #pragma unroll
-      for (int e = 0; e < N; ++e) o[e] = valid ? scale[c * N + e] * (v[i][e] * r) : 0.f;
-      Vec<T>::store(y + (long)row * C + c * N, o);
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) ss += v[i][e] * v[i][e];
+      }
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss * inv_c + eps);
+    if (lane == 0) rstd[row] = r;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = valid ? sc[i][e] * (v[i][e] * r) : 0.f;
+        Vec<T>::store(y + (long)row * C + c * N, o);
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[i][e] = nx[i][e];
+      }
     }
   }
 }
@@ -430,7 +454,8 @@ int check_row_shape(const char* who, int M, int C, int dtype) {
 template <typename T>
 void run_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, int M, int C, float eps,
                      const int32_t* lengths, int Tn, hipStream_t stream) {
-  rmsnorm_fwd_kernel<T><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const T*)x, scale, (T*)y, rstd, M, C, eps,
+  const int nb = (M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024;
+  rmsnorm_fwd_kernel<T><<<dim3(nb), dim3(256), 0, stream>>>((const T*)x, scale, (T*)y, rstd, M, C, eps,
                                                                      lengths, Tn);
 }
 template <typename T>
@@ -484,6 +509,14 @@ extern "C" int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale,
     run_rmsnorm_bwd<float>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, M, C, lengths, Tn, stream);
   return vg_host::check_launch("vg_rmsnorm_bwd");
 }
+
+namespace vg_host {
+void colsum_accumulate(const void* x, int M, int N, long ld, float* out, int dtype, hipStream_t stream) {
+  dim3 gridf((N + 63) / 64), blockf(64, 16);
+  if (dtype == VG_BF16) colsum_final_kernel<bf16_t><<<gridf, blockf, 0, stream>>>((const bf16_t*)x, M, N, ld, out, 1);
+  else colsum_final_kernel<float><<<gridf, blockf, 0, stream>>>((const float*)x, M, N, ld, out, 1);
+}
+}  // namespace vg_host
 
 extern "C" int vg_colsum_blocks(int M) {
   if (M <= 2048) return 1;            // small inputs (partial-sum arrays): one pass, one launch

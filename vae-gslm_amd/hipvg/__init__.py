@@ -15,7 +15,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libvaegslm_hip.so")
+# VG_LIB: load another build of the same C ABI (A/B runs of two kernel versions in one session)
+LIB_PATH = os.environ.get("VG_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libvaegslm_hip.so")
 
 VG_F32, VG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
@@ -32,7 +33,7 @@ class GemmDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp), ("aux_in", _vp), ("aux_out", _vp),
                 ("lengths", _vp), ("T", _i),
                 ("act", _i), ("dact", _i), ("out_f32", _i), ("accumulate", _i),
-                ("split_k", _i), ("alpha", _f), ("pre_add", _vp), ("tile_cfg", _i)]
+                ("split_k", _i), ("alpha", _f), ("pre_add", _vp), ("tile_cfg", _i), ("colsum_out", _vp)]
 
 
 # name -> argtypes (restype is always int); must list EVERY symbol of the header

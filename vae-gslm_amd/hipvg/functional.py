@@ -49,7 +49,8 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
          residual: Optional[Tensor] = None, aux_in: Optional[Tensor] = None,
          aux_out: Optional[Tensor] = None, lengths: Optional[Tensor] = None, T: int = 0,
          act: int = ACT_NONE, dact: int = ACT_NONE, accumulate=False, split_k: int = 1,
-         alpha: float = 1.0, tile_cfg: int = 0, pre_add: Optional[Tensor] = None) -> Tensor:
+         alpha: float = 1.0, tile_cfg: int = 0, pre_add: Optional[Tensor] = None,
+         colsum_out: Optional[Tensor] = None) -> Tensor:
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
     if out is None:
@@ -68,6 +69,7 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
     d.accumulate, d.split_k, d.alpha = int(accumulate), int(split_k), float(alpha)
     d.tile_cfg = int(tile_cfg)
     d.pre_add = ptr(pre_add)
+    d.colsum_out = ptr(colsum_out)     # fp32 [M], += row sums of A (bias gradient of a wgrad launch)
     check(lib().vg_gemm(C.byref(d), stream()), "vg_gemm")
     return out
 
@@ -184,17 +186,11 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm(du, w, M, K, N, b_tr=True, lengths=lengths, T=T)
         weight, bias = ctx.params
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            if _sinkable(weight) and weight.dim() == 2 and weight.is_contiguous():
-                sink_wgrad(weight, du, x)          # accumulate straight into weight.grad
-            else:
-                s = wgrad_splits(N, K, M, x.dtype)
-                dW = gemm(du, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=s)
-        if has_bias and ctx.needs_input_grad[2]:
-            if _sinkable(bias):
-                sink_colsum(bias, du)
-            else:
-                db = colsum(du)
+            dW, db = wgrad_pair(weight, bias if want_b else None, du, x)
+        elif want_b:
+            db = vec_grad(bias, du)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dW, db, dres, None, None, None, None
@@ -468,14 +464,35 @@ def _fire(p: Tensor) -> None:
         h(p)
 
 
-def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor) -> None:
-    """p.grad[N,K] += dy[M,N]^T x[M,K]."""
-    N, K = p.shape
+def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor, bias: Optional[Tensor] = None) -> None:
+    """p.grad viewed as [N,K] += dy[M,N]^T x[M,K] (conv-shaped [N,K,1] weights share that memory); with
+    ``bias`` also bias.grad[N] += column sums of dy, computed by the same launch from the dy tiles it
+    already staged in LDS."""
+    N = p.shape[0]
+    K = p.numel() // N
     M = x.shape[0]
-    g = _grad_buffer(p)
+    g = _grad_buffer(p).view(N, K)
     s = wgrad_splits(N, K, M, x.dtype)
-    gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1))
+    bg = None if bias is None else _grad_buffer(bias).view(-1)
+    gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1), colsum_out=bg)
     _fire(p)
+    if bias is not None:
+        _fire(bias)
+
+
+def wgrad_pair(weight, bias, g_out: Tensor, inp: Tensor):
+    """(dW, db) of y = inp W^T + b for the incoming gradient ``g_out``; an entry is None where the
+    gradient went straight into ``.grad`` (sink) or the parameter is absent."""
+    if _sinkable(weight) and weight.is_contiguous():
+        fused = bias is not None and _sinkable(bias)
+        sink_wgrad(weight, g_out, inp, bias if fused else None)
+        return None, (None if fused else vec_grad(bias, g_out))
+    N = weight.shape[0]
+    K = weight.numel() // N
+    M = inp.shape[0]
+    dW = gemm(g_out, inp, N, K, M, a_tr=True, b_tr=True, out_f32=True,
+              split_k=wgrad_splits(N, K, M, inp.dtype)).view_as(weight)
+    return dW, vec_grad(bias, g_out)
 
 
 def sink_vector(p: Tensor, value: Tensor) -> None:
@@ -549,14 +566,6 @@ class TransformerLayerFn(torch.autograd.Function):
         dy = _as(dy, dt)
         grads = {}
 
-        def wgrad(p, g_out, inp):
-            if _sinkable(p):
-                sink_wgrad(p, g_out, inp)
-                return None
-            N, K = p.shape
-            return gemm(g_out, inp, N, K, M, a_tr=True, b_tr=True, out_f32=True,
-                        split_k=wgrad_splits(N, K, M, dt))
-
         def vgrad(p, value_fn):
             if p is None:
                 return None
@@ -568,24 +577,20 @@ class TransformerLayerFn(torch.autograd.Function):
 
         # ---- FFN
         du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_GELU, aux_in=u)
-        g_w2 = wgrad(w2, dy, h)
-        g_b2 = vec_grad(b2, dy)
+        g_w2, g_b2 = wgrad_pair(w2, b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
-        g_w1 = wgrad(w1, du, n3)
-        g_b1 = vec_grad(b1, du)
+        g_w1, g_b1 = wgrad_pair(w1, b1, du, n3)
         dx1, ds3 = rmsnorm_bwd_raw(dn3, x1, sc3, rstd3, dy, lengths, T)
         g_n3 = vec_grad(n3s, ds3)
         # ---- attention
         datt = gemm(dx1, so, M, D, D, b_tr=True)
-        g_wo = wgrad(wo, dx1, att)
-        g_bo = vec_grad(bo, dx1)
+        g_wo, g_bo = wgrad_pair(wo, bo, dx1, att)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
         check(lib().vg_attn_bwd(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
                                 B, T, H, ptr(lengths), dtype_id(dt), stream()), "vg_attn_bwd")
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
-        g_wq = wgrad(wqkv, dqkv, n1)
-        g_bq = vec_grad(bqkv, dqkv)
+        g_wq, g_bq = wgrad_pair(wqkv, bqkv, dqkv, n1)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
         g_n1 = vec_grad(n1s, ds1)
         return (dx, g_n1, g_wq, g_bq, g_wo, g_bo, g_n3, g_w1, g_b1, g_w2, g_b2,
@@ -674,20 +679,30 @@ class ConvBlockFn(torch.autograd.Function):
         Wa = s2[:, :Cc]
         dpre = gemm(dy, s3, M, Hd, Cc, b_tr=True, dact=act, aux_in=(h if act == ACT_RELU else pre))
 
-        def wgrad_into(p, rows, col0, cols, g_out, inp):
-            """p.grad[:, col0:col0+cols] (+)= g_out^T inp, or return the dense gradient."""
+        fused_bias = set()
+
+        def wgrad_into(p, rows, col0, cols, g_out, inp, bias=None):
+            """p.grad[:, col0:col0+cols] (+)= g_out^T inp (+ the bias gradient from the same launch), or
+            return the dense gradient."""
             if _sinkable(p):
                 g = _grad_buffer(p).view(rows, -1)[:, col0:col0 + cols]
                 s = wgrad_splits(rows, cols, M, dt)
-                gemm(g_out, inp, rows, cols, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1))
+                bg = None
+                if bias is not None and _sinkable(bias):
+                    bg = _grad_buffer(bias).view(-1)
+                    fused_bias.add(id(bias))
+                gemm(g_out, inp, rows, cols, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1),
+                     colsum_out=bg)
+                if bg is not None:
+                    _fire(bias)
                 return None
             return gemm(g_out, inp, rows, cols, M, a_tr=True, b_tr=True, out_f32=True,
                         split_k=wgrad_splits(rows, cols, M, dt))
 
-        g_c3 = wgrad_into(c3w, Cc, 0, Hd, dy, h)
-        g_c3b = vec_grad(c3b, dy)
+        g_c3 = wgrad_into(c3w, Cc, 0, Hd, dy, h, c3b)
+        g_c3b = None if id(c3b) in fused_bias else vec_grad(c3b, dy)
         du = gemm(dpre, Wa, M, Cc, Hd, b_tr=True)
-        ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u)
+        ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u, c2b)
         dcond = gc = None
         if cond is not None:
             Wc = s2[:, Cc:]
@@ -703,7 +718,7 @@ class ConvBlockFn(torch.autograd.Function):
             _fire(c3w)
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
-        g_c2b = vec_grad(c2b, dpre)
+        g_c2b = None if id(c2b) in fused_bias else vec_grad(c2b, dpre)
         dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
         dte = dv.view(-1, T, Cc).float().sum(1)
         g_c1w = vec_grad(c1w, pw)
