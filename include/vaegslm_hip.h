@@ -32,7 +32,12 @@ extern "C" {
 typedef struct ihipStream_t* vg_stream_t; /* == hipStream_t */
 
 enum { VG_F32 = 0, VG_BF16 = 1 };
-enum { VG_ACT_NONE = 0, VG_ACT_RELU = 1, VG_ACT_GELU = 2, VG_ACT_SILU = 3 };
+enum { VG_ACT_NONE = 0, VG_ACT_RELU = 1, VG_ACT_GELU = 2, VG_ACT_SILU = 3,
+       /* dact only: multiply by aux_in, a derivative stored by a forward launch with VG_ACT_SAVE_DERIV */
+       VG_ACT_STORED = 4,
+       /* flag OR-ed into act: aux_out receives act'(pre-activation) instead of the pre-activation, so the
+          backward epilogue is one multiply instead of re-evaluating erf/exp per element */
+       VG_ACT_SAVE_DERIV = 16 };
 
 int vg_version(void);
 /* copies the calling thread's last error message (NUL terminated) */
@@ -47,7 +52,8 @@ int vg_last_error(char* buf, int buflen);
  * head mean/logstd projections).
  *   a_tr = 0: A stored [M][lda] (k contiguous);  a_tr = 1: A stored [K][lda] (m contiguous)
  *   b_tr = 0: B stored [N][ldb] (k contiguous);  b_tr = 1: B stored [K][ldb] (n contiguous)
- * Epilogue order: +bias[n] -> +pre_add -> (aux_out = value) -> act -> *dact'(aux_in) ->
+ * Epilogue order: +bias[n] -> +pre_add -> (aux_out = value, or act'(value) with VG_ACT_SAVE_DERIV) -> act ->
+ * *dact'(aux_in) (or *aux_in for VG_ACT_STORED) ->
  * +residual -> row mask (zero rows t >= lengths[b]) -> store.
  * split_k > 1: fp32 C must be pre-zeroed; partial sums are added atomically
  * and the epilogue is skipped (used for weight gradients only).

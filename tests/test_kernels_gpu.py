@@ -88,6 +88,16 @@ def test_gemm_epilogues(F, dtype):
     gp = 0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
     ref = torch.where(mask, (dy.double() @ w.double()) * gp, 0.0)
     torch.testing.assert_close(dx.double(), ref, **tol(dtype))
+    # stored-derivative form: the forward launch writes act'(u) to aux_out, the dgrad multiplies by it
+    for act_id, fn in ((2, torch.nn.functional.gelu), (3, torch.nn.functional.silu)):
+        ud = u_ref.clone().requires_grad_(True)
+        fn(ud).sum().backward()
+        deriv = torch.empty(M, N, dtype=dtype, device=dev())
+        y = F.gemm(x, w, M, N, K, bias=bias, act=act_id | 16, aux_out=deriv)
+        torch.testing.assert_close(y.double(), fn(u_ref), **tol(dtype))
+        torch.testing.assert_close(deriv.double(), ud.grad, **tol(dtype))
+        dx = F.gemm(dy, w, M, K, N, b_tr=True, dact=4, aux_in=wide)
+        torch.testing.assert_close(dx.double(), (dy.double() @ w.double()) * wide.double(), **tol(dtype))
     # wgrad, split-K (atomic) and single pass agree with the reference
     for s in (1, 3):
         dW = F.gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=s)

@@ -46,6 +46,21 @@ def main():
             "TN wgrad": lambda cfg: F.gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out_f32=True,
                                            split_k=F.wgrad_splits(N, K, M, torch.bfloat16), tile_cfg=cfg),
         }
+        if os.environ.get("TORCH_REF", "1") == "1":    # hipBLASLt through torch, same operands (reference point)
+            tt = [timeit(lambda: torch.matmul(x, w.t())), timeit(lambda: torch.matmul(dy, w)),
+                  timeit(lambda: torch.matmul(dy.t(), x))]
+            print(f"N={N:5d} K={K:5d} hipBLASLt | " + " | ".join(
+                f"{n}: {flops / t / 1e12:7.1f} TF ({t * 1e6:6.1f} us)" for n, t in zip(("NT", "NN", "TN"), tt)), flush=True)
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        res = torch.randn(M, N, generator=g).to(dev).bfloat16()
+        pre = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        if os.environ.get("EPI", "0") == "1":
+            cases = {
+                "NT +bias+GELU+aux ": lambda cfg: F.gemm(x, w, M, N, K, bias=bias, act=2, aux_out=aux, tile_cfg=cfg),
+                "NT +bias+residual ": lambda cfg: F.gemm(x, w, M, N, K, bias=bias, residual=res, tile_cfg=cfg),
+                "NN +dGELU(aux)    ": lambda cfg: F.gemm(dy, w, M, K, N, b_tr=True, dact=2, aux_in=pre, tile_cfg=cfg),
+            }
         for name, fn in cases.items():
             ref = fn(-1).float()
             row = []

@@ -62,6 +62,33 @@ VG_DEVICE void slab_store(const uint4 (&r)[NVec<T>::v], char* row_img, char* tr_
   }
 }
 
+// ---- bf16 fast path: the same two LDS images written by LDS-DMA (`buffer_load ... lds`, 1 KiB per
+// wave-instruction, no VGPR hop).  The DMA writes lane-linear, so each lane's SOURCE address carries the
+// image's swizzle; rows past the end of the sequence are zero-filled by the buffer range check.
+// 4 waves: each issues pieces wave, wave + 4 of the 8 pieces (8 rows x 128 B) of an image.
+VG_DEVICE __amdgpu_buffer_rsrc_t slab_rsrc(const bf16_t* base, long row_stride, int Tn) {
+  const long bytes = (long)(Tn - 1) * row_stride * 2 + DH * 2;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, (int)bytes, 0x00020000);
+}
+template <bool TR>
+VG_DEVICE void slab_dma(__amdgpu_buffer_rsrc_t rsrc, char* img, long row_stride, int t0, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int piece = wave + 4 * j;
+    const int row = piece * 8 + (lane >> 3);
+    const int pos = lane & 7;               // 16-byte position inside the 128-byte LDS row
+    int col;
+    if constexpr (!TR) col = (pos ^ ((row >> 1) & 7)) * 8;
+    else col = (((pos >> 2) ^ ((row >> 1) & 1)) * 32) + (pos & 3) * 8;
+    const unsigned voff = (unsigned)(((long)(t0 + row) * row_stride + col) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(void, img + piece * 1024), 16, voff, 0, 0, 0);
+  }
+}
+VG_DEVICE void dma_wait_and_publish() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces have landed ...
+  __builtin_amdgcn_s_barrier();                      // ... and so have everyone else's; the other stage is free
+}
+
 // ---- per-lane operand fragments of one time row held in registers (B operand, k = d)
 template <typename T> struct RowRegs;
 template <> struct RowRegs<bf16_t> {
@@ -200,18 +227,41 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
   f32x16 o[2] = {zero16(), zero16()};
   float m = -INFINITY, l = 0.f;
 
-  uint4 rk[NVec<T>::v], rv[NVec<T>::v];
-  slab_load<T>(rk, base + D, rs, 0, Tn, tid);
-  slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+  // bf16: two LDS stages filled by LDS-DMA, one barrier per tile (tile kt+1 lands while tile kt is
+  // consumed); fp32 parity path: register-staged single stage
+  constexpr bool DMA = sizeof(T) == 2;
+  constexpr int STAGE = LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
+  uint4 rk[DMA ? 1 : NVec<T>::v], rv[DMA ? 1 : NVec<T>::v];
+  __amdgpu_buffer_rsrc_t rsk, rsv;
+  if constexpr (DMA) {
+    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tn);
+    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tn);
+    slab_dma<false>(rsk, smem, rs, 0, wave, lane);
+    slab_dma<true>(rsv, smem + LdsPlan<T>::ROW_BYTES, rs, 0, wave, lane);
+  } else {
+    slab_load<T>(rk, base + D, rs, 0, Tn, tid);
+    slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int kv0 = kt * TB;
-    __syncthreads();
-    slab_store<T, true, false>(rk, k_row, nullptr, tid);
-    slab_store<T, false, true>(rv, nullptr, v_tr, tid);
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
-      slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+    if constexpr (DMA) {
+      dma_wait_and_publish();
+      if (kt + 1 < nkt) {
+        char* nx = smem + ((kt + 1) & 1) * STAGE;
+        slab_dma<false>(rsk, nx, rs, kv0 + TB, wave, lane);
+        slab_dma<true>(rsv, nx + LdsPlan<T>::ROW_BYTES, rs, kv0 + TB, wave, lane);
+      }
+      k_row = smem + (kt & 1) * STAGE;
+      v_tr = k_row + LdsPlan<T>::ROW_BYTES;
+    } else {
+      __syncthreads();
+      slab_store<T, true, false>(rk, k_row, nullptr, tid);
+      slab_store<T, false, true>(rv, nullptr, v_tr, tid);
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
+        slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+      }
     }
     if (qw0 + 31 < kv0) continue;   // this wave's queries all precede the tile (causal)
     f32x16 s[2];
@@ -337,18 +387,40 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   }
 
   f32x16 dq[2] = {zero16(), zero16()};
-  uint4 rk[NVec<T>::v], rv[NVec<T>::v];
-  slab_load<T>(rk, base + D, rs, 0, Tn, tid);
-  slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+  constexpr bool DMA = sizeof(T) == 2;
+  constexpr int STAGE = 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
+  uint4 rk[DMA ? 1 : NVec<T>::v], rv[DMA ? 1 : NVec<T>::v];
+  __amdgpu_buffer_rsrc_t rsk, rsv;
+  auto issue = [&](int t0, char* st) {
+    slab_dma<false>(rsk, st, rs, t0, wave, lane);
+    slab_dma<false>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);
+    slab_dma<true>(rsk, st + 2 * LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);
+  };
+  if constexpr (DMA) {
+    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tn);
+    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tn);
+    issue(0, smem);
+  } else {
+    slab_load<T>(rk, base + D, rs, 0, Tn, tid);
+    slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int kv0 = kt * TB;
-    __syncthreads();
-    slab_store<T, true, true>(rk, k_row, k_tr, tid);
-    slab_store<T, true, false>(rv, v_row, nullptr, tid);
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
-      slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+    if constexpr (DMA) {
+      dma_wait_and_publish();
+      if (kt + 1 < nkt) issue(kv0 + TB, smem + ((kt + 1) & 1) * STAGE);
+      k_row = smem + (kt & 1) * STAGE;
+      v_row = k_row + LdsPlan<T>::ROW_BYTES;
+      k_tr = k_row + 2 * LdsPlan<T>::ROW_BYTES;
+    } else {
+      __syncthreads();
+      slab_store<T, true, true>(rk, k_row, k_tr, tid);
+      slab_store<T, true, false>(rv, v_row, nullptr, tid);
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
+        slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+      }
     }
     if (qw0 + 31 < kv0) continue;
     const bool diag = kv0 + TB - 1 > qw0;
@@ -419,24 +491,70 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const float* __restrict__ dl_bh = delta + ((long)b * H + h) * Tn;
 
   const int qt_beg = k0 / TB, qt_end = (len + TB - 1) / TB;
-  uint4 rq[NVec<T>::v], rd[NVec<T>::v];
-  slab_load<T>(rq, base, rs, qt_beg * TB, Tn, tid);
-  slab_load<T>(rd, dobase, D, qt_beg * TB, Tn, tid);
+  constexpr bool DMA = sizeof(T) == 2;
+  constexpr int IMG = 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES;
+  constexpr int STAGE = IMG + 2 * 64 * (int)sizeof(float);     // + the per-query constants of the tile
+  uint4 rq[DMA ? 1 : NVec<T>::v], rd[DMA ? 1 : NVec<T>::v];
+  __amdgpu_buffer_rsrc_t rsq, rsd;
+  auto issue = [&](int t0, char* sg) {
+    slab_dma<false>(rsq, sg, rs, t0, wave, lane);
+    slab_dma<false>(rsd, sg + LdsPlan<T>::ROW_BYTES, D, t0, wave, lane);
+    slab_dma<true>(rsq, sg + 2 * LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);
+    slab_dma<true>(rsd, sg + 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES, D, t0, wave, lane);
+  };
+  // per-query constants of a tile: S init = -(lse2 + slope2 (q - k0)) / c2 (-inf for padded queries), dP init = -delta
+  auto st_values = [&](int qs, float& a, float& d) {
+    const int qq = qs + tid;
+    const bool ok = tid < 64 && qq < len;
+    a = ok ? -(lse_bh[qq] * LOG2E + slope2 * (float)(qq - k0)) / c2 : -INFINITY;
+    d = ok ? -dl_bh[qq] : 0.f;
+  };
+  float st_a = 0.f, st_d = 0.f;    // wave 0: constants of the NEXT tile, fetched one iteration ahead
+  if constexpr (DMA) {
+    rsq = slab_rsrc(reinterpret_cast<const bf16_t*>(base), rs, Tn);
+    rsd = slab_rsrc(reinterpret_cast<const bf16_t*>(dobase), D, Tn);
+    if (tid < 64) {
+      st_values(qt_beg * TB, st_a, st_d);
+      float* s0 = reinterpret_cast<float*>(smem + IMG);
+      s0[tid] = st_a;
+      s0[64 + tid] = st_d;
+      if (qt_beg + 1 < qt_end) st_values((qt_beg + 1) * TB, st_a, st_d);
+    }
+    issue(qt_beg * TB, smem);
+  } else {
+    slab_load<T>(rq, base, rs, qt_beg * TB, Tn, tid);
+    slab_load<T>(rd, dobase, D, qt_beg * TB, Tn, tid);
+  }
   for (int qt = qt_beg; qt < qt_end; ++qt) {
     const int qs0 = qt * TB;
-    __syncthreads();
-    slab_store<T, true, true>(rq, q_row, q_tr, tid);
-    slab_store<T, true, true>(rd, do_row, do_tr, tid);
-    if (tid < 64) {
-      const int qq = qs0 + tid;
-      const bool ok = qq < len;
-      st[tid] = ok ? -(lse_bh[qq] * LOG2E + slope2 * (float)(qq - k0)) / c2 : -INFINITY;
-      st[64 + tid] = ok ? -dl_bh[qq] : 0.f;
-    }
-    __syncthreads();
-    if (qt + 1 < qt_end) {
-      slab_load<T>(rq, base, rs, qs0 + TB, Tn, tid);
-      slab_load<T>(rd, dobase, D, qs0 + TB, Tn, tid);
+    if constexpr (DMA) {
+      dma_wait_and_publish();
+      const int sl = (qt - qt_beg) & 1;
+      if (qt + 1 < qt_end) {
+        char* nx = smem + (sl ^ 1) * STAGE;
+        if (tid < 64) {              // registers were filled one iteration ago: no wait behind the DMA below
+          float* sn = reinterpret_cast<float*>(nx + IMG);
+          sn[tid] = st_a;
+          sn[64 + tid] = st_d;
+        }
+        issue(qs0 + TB, nx);
+        if (tid < 64 && qt + 2 < qt_end) st_values(qs0 + 2 * TB, st_a, st_d);
+      }
+      q_row = smem + sl * STAGE;
+      do_row = q_row + LdsPlan<T>::ROW_BYTES;
+      q_tr = q_row + 2 * LdsPlan<T>::ROW_BYTES;
+      do_tr = q_tr + LdsPlan<T>::TR_BYTES;
+      st = reinterpret_cast<float*>(q_row + IMG);
+    } else {
+      __syncthreads();
+      slab_store<T, true, true>(rq, q_row, q_tr, tid);
+      slab_store<T, true, true>(rd, do_row, do_tr, tid);
+      if (tid < 64) st_values(qs0, st[tid], st[64 + tid]);
+      __syncthreads();
+      if (qt + 1 < qt_end) {
+        slab_load<T>(rq, base, rs, qs0 + TB, Tn, tid);
+        slab_load<T>(rd, dobase, D, qs0 + TB, Tn, tid);
+      }
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -515,7 +633,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const T* __restrict__ q
 template <typename T>
 int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tn, int H,
                const int32_t* lengths, hipStream_t stream) {
-  const size_t lds = LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
+  const size_t lds = (sizeof(T) == 2 ? 2 : 1) * (LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   // algorithmic work: causal-exact QK^T + PV, 2*2*64 FLOP per (query, key <= query) pair
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_FWD, 256.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
@@ -534,10 +652,10 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
                      (const T*)out, (const T*)dout, delta, B, Tn, H);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
-  const size_t lds_q = 3 * LdsPlan<T>::ROW_BYTES;
+  const size_t lds_q = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
                      delta, slopes, (T*)dqkv, Tn, H, lengths);
-  const size_t lds_k = 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float);
+  const size_t lds_k = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float));
   static bool attr[2] = {false, false};
   if (!attr[sizeof(T) == 2]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>),

@@ -170,13 +170,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
         }
         if (p.bias) v += p.bias[n];
         if (p.pre_add) v += to_f32<T>(reinterpret_cast<const T*>(p.pre_add)[idx]);
-        if (auxo) auxo[idx] = from_f32<T>(v);
-        if (p.act == VG_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == VG_ACT_GELU) v = gelu_erf(v);
-        else if (p.act == VG_ACT_SILU) v = silu(v);
+        const int act = p.act & 15;
+        if (p.act & VG_ACT_SAVE_DERIV) {
+          float d = 1.f;
+          if (act == VG_ACT_RELU) d = v > 0.f ? 1.f : 0.f;
+          else if (act == VG_ACT_GELU) d = gelu_erf_grad(v);
+          else if (act == VG_ACT_SILU) d = silu_grad(v);
+          if (auxo) auxo[idx] = from_f32<T>(d);
+        } else if (auxo) {
+          auxo[idx] = from_f32<T>(v);
+        }
+        if (act == VG_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == VG_ACT_GELU) v = gelu_erf(v);
+        else if (act == VG_ACT_SILU) v = silu(v);
         if (p.dact == VG_ACT_RELU) v = (to_f32<T>(auxi[idx]) > 0.f) ? v : 0.f;
         else if (p.dact == VG_ACT_GELU) v *= gelu_erf_grad(to_f32<T>(auxi[idx]));
         else if (p.dact == VG_ACT_SILU) v *= silu_grad(to_f32<T>(auxi[idx]));
+        else if (p.dact == VG_ACT_STORED) v *= to_f32<T>(auxi[idx]);
         if (res) v += to_f32<T>(res[idx]);
         if (!valid) v = 0.f;
         if (p.out_f32) {
@@ -247,6 +257,8 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   p.act = d->act; p.dact = d->dact; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
   p.alpha = d->alpha;
   p.colsum_out = d->colsum_out;
+  static const int cs_rr = [] { const char* e = getenv("VG_COLSUM_RR"); return e ? atoi(e) : 1; }();
+  p.colsum_rr = cs_rr;
   VG_REQUIRE(d->colsum_out == nullptr || (d->a_tr && d->b_tr), "vg_gemm: colsum_out needs a_tr = b_tr = 1");
   int kps = (d->K + splits - 1) / splits;
   kps = ((kps + bk - 1) / bk) * bk;

@@ -75,25 +75,57 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
   }
-  if (p.aux_out) {
+  const int act = p.act & 15;
+  if (p.act & VG_ACT_SAVE_DERIV) {
+    // the activation and its derivative share their transcendental; the derivative goes to aux_out
     bf16x8 o;
+    if (act == VG_ACT_GELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx) = o;
-  }
-  if (p.act == VG_ACT_RELU) {
+      for (int e = 0; e < 8; ++e) {
+        float cdf, px;
+        gelu_parts_fast(v[e], cdf, px);
+        o[e] = (bf16_t)(cdf + px);
+        v[e] *= cdf;
+      }
+    } else if (act == VG_ACT_SILU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-  } else if (p.act == VG_ACT_GELU) {
+      for (int e = 0; e < 8; ++e) {
+        const float sg = __frcp_rn(1.0f + __expf(-v[e]));
+        o[e] = (bf16_t)(sg * (1.0f + v[e] * (1.0f - sg)));
+        v[e] *= sg;
+      }
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-  } else if (p.act == VG_ACT_SILU) {
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (bf16_t)((act != VG_ACT_RELU || v[e] > 0.f) ? 1.0f : 0.0f);
+        if (act == VG_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+      }
+    }
+    if (p.aux_out) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx) = o;
+  } else {
+    if (p.aux_out) {
+      bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx) = o;
+    }
+    if (act == VG_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (act == VG_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+    } else if (act == VG_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+    }
   }
   if (p.dact != VG_ACT_NONE) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux_in) + idx);
-    if (p.dact == VG_ACT_RELU) {
+    if (p.dact == VG_ACT_STORED) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= (float)a[e];
+    } else if (p.dact == VG_ACT_RELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((float)a[e] > 0.f) ? v[e] : 0.f;
     } else if (p.dact == VG_ACT_GELU) {
@@ -167,13 +199,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // COLSUM (weight-gradient launches): the waves that own the first column panel also multiply their
-  // A fragments by a constant all-ones operand -> row sums of A = the bias gradient, no extra LDS traffic
+  // COLSUM (weight-gradient launches): row sums of A = the bias gradient, from one extra MFMA of the
+  // staged A fragments against a constant all-ones operand (no extra LDS traffic).  All blocks of an
+  // m-panel stage the same A tiles, so the K-steps are dealt round-robin over the panel's blocks and
+  // over the WN waves that share a fragment set: every block pays 1/ntn of the extra MFMAs.
   f32x4 csum[COLSUM ? TM : 1];
-  bool do_cs = false;
   bf16x8 ones;
+  const int cs_n = wg % ntn;
+  int cs_turn = 0, cs_wave = 0;             // kt % ntn and (kt / ntn) % WN, kept incrementally (no division per K-step)
+  bool cs_any = false;
   if constexpr (COLSUM) {
-    do_cs = p.colsum_out != nullptr && n0 == 0 && wn == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -221,13 +256,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
       if constexpr (COLSUM) {
-        if (do_cs) {
+        if (p.colsum_out != nullptr &&
+            (p.colsum_rr ? (cs_turn == cs_n && cs_wave == wn) : (cs_n == 0 && wn == 0))) {
+          cs_any = true;
 #pragma unroll
           for (int i = 0; i < TM; ++i)
             csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], ones, csum[i], 0, 0, 0);
         }
       }
       __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (COLSUM) {
+      if (++cs_turn == ntn) {
+        cs_turn = 0;
+        if (++cs_wave == WN) cs_wave = 0;
+      }
     }
   }
 
@@ -242,7 +285,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   static_assert(NW * 16 * SW * 4 <= STAGES * STAGE, "epilogue strips must fit in the stage buffers");
   const bool split = gridDim.z > 1;
   if constexpr (COLSUM) {
-    if (do_cs && (lane & 15) == 0) {       // every column of csum holds the same row sums
+    if (cs_any && (lane & 15) == 0) {      // all columns of csum are equal
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll

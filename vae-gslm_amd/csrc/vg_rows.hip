@@ -256,6 +256,37 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const T* __restrict_
   }
 }
 
+// fp32 partial-sum arrays ([<=2048 rows][N], the second stage of every two-stage reduction): 16 columns
+// per block so that a 1024-column array still spreads over 64 CUs, 64 row lanes with all loads of a
+// thread independent (one memory latency instead of M/16 dependent round trips)
+__global__ __launch_bounds__(256) void colsum_small_f32_kernel(const float* __restrict__ x, int M, int N, long ld,
+                                                               float* __restrict__ out, int accumulate) {
+  __shared__ float red[64][17];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c0 = blockIdx.x * 16 + cl * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+#pragma unroll 8
+    for (int m = rl; m < M; m += 64) s += *reinterpret_cast<const f32x4*>(x + (long)m * ld + c0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cl * 4 + e] = s[e];
+  __syncthreads();
+  // 256 threads: column = tid & 15, 16 row groups of 4 -> shuffle-free second step through LDS
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  float t = red[4 * g][c] + red[4 * g + 1][c] + red[4 * g + 2][c] + red[4 * g + 3][c];
+  __syncthreads();
+  red[g][c] = t;
+  __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x * 16 + c < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += red[r][c];
+    float* o = out + blockIdx.x * 16 + c;
+    *o = accumulate ? *o + v : v;
+  }
+}
+
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
   __shared__ float red[16];
   float s = 0.f;
@@ -524,6 +555,15 @@ extern "C" int vg_colsum_blocks(int M) {
   return b < 128 ? b : 128;
 }
 
+namespace {
+void launch_colsum_small(const float* x, int M, int N, long ld, float* out, int accumulate, hipStream_t stream) {
+  if (ld % 4 == 0 && ((uintptr_t)x % 16) == 0)
+    colsum_small_f32_kernel<<<dim3((N + 15) / 16), dim3(256), 0, stream>>>(x, M, N, ld, out, accumulate);
+  else
+    colsum_final_kernel<float><<<dim3((N + 63) / 64), dim3(64, 16), 0, stream>>>(x, M, N, ld, out, accumulate);
+}
+}  // namespace
+
 extern "C" int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, int dtype,
                          int accumulate, hipStream_t stream) {
   VG_REQUIRE(N % 4 == 0 && M > 0, "vg_colsum: N=%d must be a multiple of 4", N);
@@ -534,12 +574,12 @@ extern "C" int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, flo
     if (dtype == VG_BF16)
       colsum_final_kernel<bf16_t><<<gridf, blockf, 0, stream>>>((const bf16_t*)x, M, N, (long)ld, out, accumulate);
     else
-      colsum_final_kernel<float><<<gridf, blockf, 0, stream>>>((const float*)x, M, N, (long)ld, out, accumulate);
+      launch_colsum_small((const float*)x, M, N, (long)ld, out, accumulate, stream);
   } else {
     dim3 grid1((N + 255) / 256, nb);
     if (dtype == VG_BF16) run_colsum<bf16_t>(grid1, x, M, N, (long)ld, ws, stream);
     else run_colsum<float>(grid1, x, M, N, (long)ld, ws, stream);
-    colsum_final_kernel<float><<<gridf, blockf, 0, stream>>>(ws, nb, N, (long)N, out, accumulate);
+    launch_colsum_small(ws, nb, N, (long)N, out, accumulate, stream);
   }
   return vg_host::check_launch("vg_colsum");
 }

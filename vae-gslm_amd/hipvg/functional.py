@@ -18,10 +18,16 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import (ACT_GELU, ACT_IDS, ACT_NONE, ACT_RELU, ACT_SILU, GemmDesc, check, dtype_id, lib, ptr,
-               stream)
+from . import (ACT_GELU, ACT_IDS, ACT_NONE, ACT_RELU, ACT_SAVE_DERIV, ACT_SILU, ACT_STORED, GemmDesc, check,
+               dtype_id, lib, ptr, stream)
 
 Tensor = torch.Tensor
+
+import os as _os0
+# bias gradient inside the wgrad launch (vg_gemm colsum_out): measured 2 % slower end-to-end than separate
+# column-sum launches on MI355X (the conditional MFMA inside the K loop costs the wgrad ~8 us), so off by default
+_FUSE_BIAS_GRAD = _os0.environ.get("VG_FUSE_BIAS_GRAD", "0") != "0"
+_STORED_DERIV = _os0.environ.get("VG_STORED_DERIV", "1") != "0"       # forward stores act'(u) for the backward
 
 # ---------------------------------------------------------------- weight shadows
 
@@ -213,7 +219,8 @@ class FFNFn(torch.autograd.Function):
         F_ = w1.shape[0]
         s1, s2 = shadow(w1, x.dtype), shadow(w2, x.dtype)
         u = torch.empty((M, F_), dtype=x.dtype, device=x.device)
-        h = gemm(x, s1, M, F_, K, bias=None if b1 is None else b1.detach(), act=ACT_GELU, aux_out=u)
+        # u receives GELU'(pre-activation): the backward epilogue is then a single multiply
+        h = gemm(x, s1, M, F_, K, bias=None if b1 is None else b1.detach(), act=ACT_GELU | ACT_SAVE_DERIV, aux_out=u)
         y = gemm(h, s2, M, K, F_, bias=None if b2 is None else b2.detach(), residual=residual,
                  lengths=lengths, T=T)
         ctx.save_for_backward(x, s1, s2, u, h, lengths)
@@ -227,7 +234,7 @@ class FFNFn(torch.autograd.Function):
         M, K = x.shape
         F_ = s1.shape[0]
         dy = _as(dy, x.dtype)
-        du = gemm(dy, s2, M, F_, K, b_tr=True, dact=ACT_GELU, aux_in=u)
+        du = gemm(dy, s2, M, F_, K, b_tr=True, dact=ACT_STORED, aux_in=u)
         dW2 = gemm(dy, h, K, F_, M, a_tr=True, b_tr=True, out_f32=True,
                    split_k=wgrad_splits(K, F_, M, x.dtype)) if ctx.needs_input_grad[3] else None
         db2 = colsum(dy) if (hb2 and ctx.needs_input_grad[4]) else None
@@ -484,7 +491,7 @@ def wgrad_pair(weight, bias, g_out: Tensor, inp: Tensor):
     """(dW, db) of y = inp W^T + b for the incoming gradient ``g_out``; an entry is None where the
     gradient went straight into ``.grad`` (sink) or the parameter is absent."""
     if _sinkable(weight) and weight.is_contiguous():
-        fused = bias is not None and _sinkable(bias)
+        fused = _FUSE_BIAS_GRAD and bias is not None and _sinkable(bias)
         sink_wgrad(weight, g_out, inp, bias if fused else None)
         return None, (None if fused else vec_grad(bias, g_out))
     N = weight.shape[0]
@@ -546,7 +553,8 @@ class TransformerLayerFn(torch.autograd.Function):
         x1 = gemm(att, so, M, D, D, bias=f32(bo), residual=x, lengths=lengths, T=T)
         n3, rstd3 = rmsnorm_fwd_raw(x1, sc3, eps, lengths, T)
         u = torch.empty((M, F_), dtype=dt, device=x.device)
-        h = gemm(n3, s1, M, F_, D, bias=f32(b1), act=ACT_GELU, aux_out=u)
+        h = gemm(n3, s1, M, F_, D, bias=f32(b1), act=(ACT_GELU | ACT_SAVE_DERIV) if _STORED_DERIV else ACT_GELU,
+                 aux_out=u)     # u = GELU'(pre-activation) (or the pre-activation itself)
         y = gemm(h, s2, M, D, F_, bias=f32(b2), residual=x1, lengths=lengths, T=T)
         ctx.save_for_backward(x, n1, rstd1, qkv, att, lse, x1, n3, rstd3, u, h, sq, so, s1, s2, sc1, sc3, slopes,
                               lengths)
@@ -576,7 +584,7 @@ class TransformerLayerFn(torch.autograd.Function):
             return v
 
         # ---- FFN
-        du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_GELU, aux_in=u)
+        du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_STORED if _STORED_DERIV else ACT_GELU, aux_in=u)
         g_w2, g_b2 = wgrad_pair(w2, b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
         g_w1, g_b1 = wgrad_pair(w1, b1, du, n3)
@@ -659,8 +667,10 @@ class ConvBlockFn(torch.autograd.Function):
         if cond is not None:
             Wc = s2[:, Cc:]
             pre_add = gemm(cond, Wc, M, Hd, cond.shape[1])
+        # pre receives act'(pre-activation) (ReLU: the output itself carries it)
         pre = torch.empty((M, Hd), dtype=dt, device=x.device) if act != ACT_RELU else None
-        h = gemm(u, Wa, M, Hd, Cc, bias=c2b.detach().float(), pre_add=pre_add, act=act, aux_out=pre)
+        h = gemm(u, Wa, M, Hd, Cc, bias=c2b.detach().float(), pre_add=pre_add,
+                 act=(act | ACT_SAVE_DERIV) if pre is not None else act, aux_out=pre)
         y = gemm(h, s3, M, Cc, Hd, bias=c3b.detach().float(), residual=x)
         ctx.save_for_backward(x, u, mean, rstd, h, pre, cond, s2, s3, w1, cb, te32, gamma)
         ctx.params = (c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b)
@@ -677,7 +687,8 @@ class ConvBlockFn(torch.autograd.Function):
         dt = x.dtype
         dy = _as(dy, dt)
         Wa = s2[:, :Cc]
-        dpre = gemm(dy, s3, M, Hd, Cc, b_tr=True, dact=act, aux_in=(h if act == ACT_RELU else pre))
+        dpre = gemm(dy, s3, M, Hd, Cc, b_tr=True, dact=(ACT_RELU if act == ACT_RELU else ACT_STORED),
+                    aux_in=(h if act == ACT_RELU else pre))
 
         fused_bias = set()
 
@@ -688,7 +699,7 @@ class ConvBlockFn(torch.autograd.Function):
                 g = _grad_buffer(p).view(rows, -1)[:, col0:col0 + cols]
                 s = wgrad_splits(rows, cols, M, dt)
                 bg = None
-                if bias is not None and _sinkable(bias):
+                if _FUSE_BIAS_GRAD and bias is not None and _sinkable(bias):
                     bg = _grad_buffer(bias).view(-1)
                     fused_bias.add(id(bias))
                 gemm(g_out, inp, rows, cols, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1),
