@@ -191,6 +191,27 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
                   float* norm_part, float* w_part, int M, int C, int T, int taps, int shift, int dtype,
                   vg_stream_t stream);
 
+/* ---------------------------------------------------------------- coupling flow on the latent
+ * The conditional affine-coupling stack of the prior (modules/flow/layers.py:15-98 LinearCoupling with
+ * flip = true, :199-245 the stack; models/speech/lvtr.py:182-191 call site) as one row kernel per direction:
+ * latent dim 4, hidden 64, LayerNorm(eps) -> FiLM -> erf-GELU -> Linear(64->4), log-scale =
+ * log(sigmoid(.) * (hi - lo) + lo).  All tensors fp32.
+ *   z, u: [M][4]; wb: [M][ldw] FiLM rows, layer l uses columns l*128 .. l*128+63 (scale) and +64.. (shift);
+ *   params: [L][580] packed per layer as W1[64][2], b1[64], ln_weight[64], ln_bias[64], W2[4][64], b2[4];
+ *   logdet_sum: [M] sum of the log-scales over layers and dims (0 on frames t >= lengths[b]);
+ *   states: [M][L][4] layer inputs saved for the backward (NULL to skip, e.g. inference).
+ * Backward: dparams_partial is [vg_flow_blocks(M)][L*580] per-block sums (reduce with vg_colsum).
+ */
+int vg_flow_blocks(int M);
+int vg_flow_fwd(const float* z, const float* wb, int64_t ldw, const float* params, int L, float* u,
+                float* logdet_sum, float* states, int M, float eps, float hi, float lo,
+                const int32_t* lengths, int T, vg_stream_t stream);
+int vg_flow_reverse(const float* u, const float* wb, int64_t ldw, const float* params, int L, float* z, int M,
+                    float eps, float hi, float lo, vg_stream_t stream);
+int vg_flow_bwd(const float* states, const float* wb, int64_t ldw, const float* params, int L,
+                const float* du, const float* dlogdet_sum, float* dz, float* dwb, float* dparams_partial,
+                int M, float eps, float hi, float lo, const int32_t* lengths, int T, vg_stream_t stream);
+
 /* ---------------------------------------------------------------- measurement hooks
  * Optional HIP-event timing of the GEMM / attention launches (bench.py's roofline
  * figure).  vg_prof_enable(1) clears and starts recording, vg_prof_enable(0)

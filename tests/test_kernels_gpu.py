@@ -409,3 +409,52 @@ def test_cnnstack_hip_vs_stock(F, full_cfg, precision, monkeypatch):
     for k in g_ref:
         err = (g_hip[k].double() - g_ref[k].double()).norm().item() / (g_ref[k].double().norm().item() + 1e-9)
         assert err < (1e-3 if tight else 0.12), (k, err)   # bf16: activations and grads are stored in bf16 between kernels
+
+
+# ------------------------------------------------------------------ coupling flow (row kernel vs stock tensor ops)
+def test_coupling_flow_hip_vs_stock(F, full_cfg, monkeypatch):
+    """CouplingStack on vg_flow_fwd / vg_flow_bwd == the same module on stock tensor ops: transformed
+    latent, masked log-det, gradients of the latent, the conditioning state and every parameter; and
+    reverse(forward(z)) == z through vg_flow_reverse.  fp32 (the flow never runs in bf16)."""
+    import copy
+    import hipvg
+    from hparams.hp import Hparams
+    from modules.flow.layers import CouplingStack
+    from modules.flow.utils import TensorLogdet
+    from utils.tensormask import TensorMask
+    hipvg.set_precision("fp32")
+    torch.manual_seed(3)
+    hp = Hparams.from_dict(copy.deepcopy(full_cfg["model"]["transformer"]["flow"]))
+    net = CouplingStack(4, hp, condition_dim=256).to(dev())
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    B, T = 3, 50
+    lens = torch.tensor([50, 17, 1], device=dev())
+    z = TensorMask.fromlength(torch.randn(B, T, 4, device=dev()), lens).apply_mask()
+    c = TensorMask.fromlength(torch.randn(B, T, 256, device=dev()), lens).apply_mask()
+    gu, gl = torch.randn(B, T, 4, device=dev()), torch.randn(B, T, device=dev())
+    valid = z.mask[..., None].float()
+
+    def run(stock):
+        monkeypatch.setenv("VG_FLOW_STOCK", "1" if stock else "0")
+        net.zero_grad(set_to_none=True)
+        zin = TensorMask(z.value.clone().requires_grad_(True), z.mask)
+        cin = TensorMask(c.value.clone().requires_grad_(True), c.mask)
+        out = net(TensorLogdet(zin, 0.0), c=cin)
+        u, ld = out.tensor.value, out.logdet.sum(-1)
+        ((u * gu * valid).sum() + (ld * gl).sum()).backward()
+        g = {k: p.grad.clone() for k, p in net.named_parameters()}
+        g["__z"], g["__c"] = zin.value.grad.clone(), cin.value.grad.clone()
+        back = net.reverse(TensorMask(u.detach(), z.mask), c=c).value
+        return (u * valid).detach(), ld.detach(), g, back
+
+    u_ref, ld_ref, g_ref, back_ref = run(stock=True)
+    u_hip, ld_hip, g_hip, back_hip = run(stock=False)
+    torch.testing.assert_close(u_hip, u_ref, atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(ld_hip, ld_ref, atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(back_hip * valid, z.value * valid, atol=1e-4, rtol=1e-4)
+    for k in g_ref:
+        a, b = g_hip[k].double(), g_ref[k].double()
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-9)
+        assert err < 1e-3, (k, err)

@@ -37,6 +37,25 @@ def main():
     for i in range(accum):
         tr.training_step(batches[i], i)
     torch.cuda.synchronize()
+    # label every module two levels below the model so that forward ops can be attributed to a sub-system
+    ranges = {}
+
+    def pre(name):
+        def f(mod, args):
+            r = torch.profiler.record_function("MOD:" + name)
+            r.__enter__()
+            ranges.setdefault(name, []).append(r)
+        return f
+
+    def post(name):
+        def f(mod, args, out):
+            ranges[name].pop().__exit__(None, None, None)
+        return f
+
+    for name, mod in tr.model.named_modules():
+        if name and name.count(".") <= 1:
+            mod.register_forward_pre_hook(pre(name))
+            mod.register_forward_hook(post(name))
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         for i in range(accum, 2 * accum):
             tr.training_step(batches[i], i)
@@ -55,18 +74,41 @@ def main():
             if "vae-gslm_amd/" in fr:
                 where = fr[fr.index("vae-gslm_amd/"):]
                 break
-        if where is None:      # backward thread: no Python frames -> name the autograd node instead
+        if where is None:      # no Python frames: innermost module label (forward) or autograd node (backward)
             par, chain = ev.cpu_parent, []
             while par is not None:
                 chain.append(par.name)
                 par = par.cpu_parent
-            where = " < ".join(c.replace("autograd::engine::evaluate_function: ", "") for c in chain[-2:]) or None
+            mods = [c[4:] for c in chain if c.startswith("MOD:")]
+            if mods:
+                where = "fwd " + mods[0]
+            else:
+                where = " < ".join(c.replace("autograd::engine::evaluate_function: ", "") for c in chain[-2:]) or None
         for k in ks:
             for p in pats:
                 if p.lower() in k.name.lower():
                     key = f"{where or '<outside repo>'}  [{ev.name}]"
                     by_pat[p][key] += 1
                     time_pat[p][key] += k.duration
+    mod_n, mod_t = collections.Counter(), collections.Counter()
+    for ev in events:
+        ks = getattr(ev, "kernels", None)
+        if not ks or ev.cpu_parent is not None and getattr(ev.cpu_parent, "kernels", None):
+            continue
+        par, chain = ev.cpu_parent, []
+        while par is not None:
+            chain.append(par.name)
+            par = par.cpu_parent
+        mods = [c[4:] for c in chain if c.startswith("MOD:")]
+        key = ("fwd " + mods[0]) if mods else ("bwd " + (chain[-1].replace("autograd::engine::evaluate_function: ", "") if chain else ev.name))
+        for k in ks:
+            if "GLOBAL__N" in k.name or "anonymous namespace)::gemm" in k.name or "dwnorm" in k.name:
+                continue        # this library's kernels
+            mod_n[key] += 1
+            mod_t[key] += k.duration
+    print(f"=== stock kernels by forward module / backward node: {sum(mod_n.values()) / accum:.0f} launches, {sum(mod_t.values()) / accum / 1e3:.3f} ms per micro-batch")
+    for key, n in mod_n.most_common(40):
+        print(f"  {n / accum:6.1f} x {mod_t[key] / accum / 1e3:7.3f} ms  {key}")
     for p in pats:
         tot = sum(by_pat[p].values())
         print(f"\n=== kernels matching '{p}': {tot / accum:.0f} launches, {sum(time_pat[p].values()) / accum / 1e3:.3f} ms per micro-batch")

@@ -766,3 +766,80 @@ class ChannelNormFn(torch.autograd.Function):
 
 def channel_norm(x, weight, bias, *, T, eps):
     return ChannelNormFn.apply(x, weight, bias, T, eps)
+
+
+# ---------------------------------------------------------------- coupling flow on the latent (row kernel)
+FLOW_PARAMS_PER_LAYER = 580     # W1[64][2] b1[64] ln_w[64] ln_b[64] W2[4][64] b2[4]
+
+
+class FlowFn(torch.autograd.Function):
+    """The conditional coupling stack (reference modules/flow/layers.py:15-98,199-245) as one forward and
+    one backward row kernel; ``params`` = per layer (linear1.weight, linear1.bias, norm.weight, norm.bias,
+    linear2.weight, linear2.bias).  Returns (u [M,4], logdet_sum [M])."""
+
+    @staticmethod
+    def forward(ctx, z, wb, lengths, T, eps, hi, lo, *params):
+        M = z.shape[0]
+        L = len(params) // 6
+        assert z.dtype == torch.float32 and wb.dtype == torch.float32 and z.shape[1] == 4 and wb.stride(1) == 1
+        z = z.contiguous()
+        packed = torch.cat([p.detach().reshape(-1).float() for p in params])
+        assert packed.numel() == L * FLOW_PARAMS_PER_LAYER
+        u = torch.empty_like(z)
+        logdet = torch.empty((M,), dtype=torch.float32, device=z.device)
+        states = torch.empty((M, L, 4), dtype=torch.float32, device=z.device)
+        check(lib().vg_flow_fwd(ptr(z), ptr(wb), wb.stride(0), ptr(packed), L, ptr(u), ptr(logdet), ptr(states), M,
+                                float(eps), float(hi), float(lo), ptr(lengths), int(T), stream()), "vg_flow_fwd")
+        ctx.save_for_backward(states, wb, packed, lengths)
+        ctx.meta = (int(T), float(eps), float(hi), float(lo), L)
+        ctx.params = params
+        return u, logdet
+
+    @staticmethod
+    def backward(ctx, du, dlogdet):
+        states, wb, packed, lengths = ctx.saved_tensors
+        T, eps, hi, lo, L = ctx.meta
+        M = states.shape[0]
+        du = du.contiguous().float()
+        dlogdet = dlogdet.contiguous().float()
+        dz = torch.empty((M, 4), dtype=torch.float32, device=du.device)
+        dwb = torch.empty_like(wb) if wb.shape[1] == 128 * L else torch.zeros_like(wb)
+        nb = lib().vg_flow_blocks(M)
+        part = torch.empty((nb, L * FLOW_PARAMS_PER_LAYER), dtype=torch.float32, device=du.device)
+        check(lib().vg_flow_bwd(ptr(states), ptr(wb), wb.stride(0), ptr(packed), L, ptr(du), ptr(dlogdet), ptr(dz),
+                                ptr(dwb), ptr(part), M, eps, hi, lo, ptr(lengths), T, stream()), "vg_flow_bwd")
+        g = colsum(part)
+        grads, sunk_g, sunk_v, off = [], [], [], 0
+        for i, p in enumerate(ctx.params):
+            n = p.numel()
+            piece = g[off: off + n].view_as(p)
+            off += n
+            if not ctx.needs_input_grad[7 + i]:
+                grads.append(None)
+            elif _sinkable(p):
+                sunk_g.append(_grad_buffer(p))
+                sunk_v.append(piece)
+                grads.append(None)
+            else:
+                grads.append(piece)
+        if sunk_g:
+            torch._foreach_add_(sunk_g, sunk_v)      # one multi-tensor launch for the 6 L small parameters
+            for p in ctx.params:
+                if _sinkable(p):
+                    _fire(p)
+        return (dz, dwb, None, None, None, None, None, *grads)
+
+
+def coupling_flow(z, wb, params, *, eps, hi, lo, lengths=None, T=0):
+    return FlowFn.apply(z, wb, lengths, T, eps, hi, lo, *params)
+
+
+def coupling_flow_reverse(u, wb, params, *, eps, hi, lo):
+    M = u.shape[0]
+    L = len(params) // 6
+    u = u.contiguous().float()
+    packed = torch.cat([p.detach().reshape(-1).float() for p in params])
+    z = torch.empty_like(u)
+    check(lib().vg_flow_reverse(ptr(u), ptr(wb), wb.stride(0), ptr(packed), L, ptr(z), M, float(eps), float(hi),
+                                float(lo), stream()), "vg_flow_reverse")
+    return z

@@ -9,6 +9,7 @@ its slice.  The 2->64->4 coupling nets are tiny tensor ops.
 """
 from __future__ import annotations
 
+import os as _os
 from typing import Optional
 
 import torch
@@ -97,12 +98,51 @@ class CouplingStack(nn.Module):
         wb = dense_2d(cv, W, Bv, out_f32=True)
         return [tuple(part.chunk(2, -1)) for part in wb.chunk(len(self.layers), -1)]
 
+    # ---- HIP row-kernel path (hipvg vg_flow_*): the vae-gslm.yaml shape of the stack
+    def _hip_ok(self, value: torch.Tensor, c) -> bool:
+        if _os.environ.get("VG_FLOW_STOCK", "0") == "1" or c is None or self.condition_dim is None:
+            return False
+        if not value.is_cuda or self.dim != 4 or len(self.layers) > 8:
+            return False
+        l0 = self.layers[0]
+        return (l0.linear1.out_features == 64 and not l0.mean_only and l0.scale_range is not None
+                and isinstance(l0.norm, nn.LayerNorm) and l0.norm.elementwise_affine
+                and isinstance(l0.activation, nn.GELU) and getattr(l0.activation, "approximate", "none") == "none"
+                and not l0.detach_coupling and l0.linear1.bias is not None and l0.linear2.bias is not None
+                and all(l.flip for l in self.layers))
+
+    def _hip_args(self, c):
+        cv = c.value if isinstance(c, TensorMask) else c
+        W = torch.cat([l.film.linear.weight for l in self.layers], 0)
+        Bv = torch.cat([l.film.linear.bias for l in self.layers], 0)
+        wb = dense_2d(cv, W, Bv, out_f32=True).reshape(-1, 128 * len(self.layers))
+        params = []
+        for l in self.layers:
+            params += [l.linear1.weight, l.linear1.bias, l.norm.weight, l.norm.bias, l.linear2.weight, l.linear2.bias]
+        hi, lo = self.layers[0].scale_range
+        return wb, params, dict(eps=self.layers[0].norm.eps, hi=float(hi), lo=float(lo))
+
     def forward(self, x: TensorLogdet, c: Optional[TensorMask] = None) -> TensorLogdet:
+        tm = x.tensor
+        if isinstance(tm, TensorMask) and tm.axis == 1 and self._hip_ok(tm.value, c):
+            from hipvg import functional as HF
+            B, T = tm.value.shape[:2]
+            wb, params, kw = self._hip_args(c)
+            u, logdet = HF.coupling_flow(tm.value.reshape(-1, self.dim).float(), wb, params,
+                                         lengths=tm.lengths32, T=T, **kw)
+            return TensorLogdet(TensorMask(u.view(B, T, self.dim), tm.mask, axis=tm.axis),
+                                x.logdet + logdet.view(B, T, 1))
         for layer, wb in zip(self.layers, self.film_all(c)):
             x = layer(x, c=c, film_wb=wb)
         return x
 
     def reverse(self, x: TensorMask, c: Optional[TensorMask] = None) -> TensorMask:
+        if isinstance(x, TensorMask) and x.axis == 1 and self._hip_ok(x.value, c):
+            from hipvg import functional as HF
+            B, T = x.value.shape[:2]
+            wb, params, kw = self._hip_args(c)
+            z = HF.coupling_flow_reverse(x.value.reshape(-1, self.dim), wb, params, **kw)
+            return TensorMask(z.view(B, T, self.dim).to(x.value.dtype), x.mask, axis=x.axis)
         for layer, wb in zip(reversed(self.layers), reversed(self.film_all(c))):
             x = layer.reverse(x, c=c, film_wb=wb)
         return x
