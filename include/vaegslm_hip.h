@@ -191,6 +191,21 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
                   float* norm_part, float* w_part, int M, int C, int T, int taps, int shift, int dtype,
                   vg_stream_t stream);
 
+/* ---------------------------------------------------------------- optimizer
+ * AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias correction; reference
+ * training_lib/optimizer.py:18-25, stepped at trainers/speech/lvtr.py:150-157) over one flat gradient
+ * bucket: param / grad / exp_avg / exp_avg_sq are fp32 [n] with the SAME layout, n a multiple of 256 and
+ * every parameter starting on a 256-element boundary; group_of_chunk[n/256] selects the parameter group
+ * (lr[g], weight_decay[g], host arrays, ngroups <= 4) of each chunk.  In the same pass: shadow_bf16 (or
+ * NULL) receives the bf16 copy of the updated parameters, grad is multiplied by *grad_scale (device
+ * scalar, e.g. a clipping coefficient, or NULL) before use and cleared afterwards if zero_grad.
+ * step is the 1-based optimizer step (bias corrections are computed on the host).
+ */
+int vg_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+             const uint8_t* group_of_chunk, int64_t n, const float* lr, const float* weight_decay, int ngroups,
+             float beta1, float beta2, float eps, int step, const float* grad_scale, int zero_grad,
+             vg_stream_t stream);
+
 /* ---------------------------------------------------------------- coupling flow on the latent
  * The conditional affine-coupling stack of the prior (modules/flow/layers.py:15-98 LinearCoupling with
  * flip = true, :199-245 the stack; models/speech/lvtr.py:182-191 call site) as one row kernel per direction:

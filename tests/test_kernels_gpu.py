@@ -458,3 +458,44 @@ def test_coupling_flow_hip_vs_stock(F, full_cfg, monkeypatch):
         a, b = g_hip[k].double(), g_ref[k].double()
         err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-9)
         assert err < 1e-3, (k, err)
+
+
+# ------------------------------------------------------------------ flat AdamW (one launch per gradient bucket)
+def test_flat_adamw_matches_torch(F):
+    """FlatAdamW bound to the reducer's buckets == torch.optim.AdamW (two parameter groups, decoupled
+    weight decay, bias correction) over several steps; the bf16 weight copies follow the parameters
+    and the gradient buckets come back zeroed."""
+    import copy
+    import torch.nn as nn
+    from training_lib.dp import GradReducer
+    from training_lib.optimizer import FlatAdamW
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(300, 129), nn.LayerNorm(129), nn.Linear(129, 7)).to(dev())
+    ref = copy.deepcopy(net)
+
+    def groups(m):
+        ps = list(m.parameters())
+        return [{"params": [p for p in ps if p.ndim != 1]}, {"params": [p for p in ps if p.ndim == 1], "weight_decay": 0}]
+
+    kw = dict(lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    opt = FlatAdamW(groups(net), fused=True, **kw)
+    opt_ref = torch.optim.AdamW(groups(ref), **kw)
+    red = GradReducer(net.parameters(), bucket_mb=0.05)      # several small buckets
+    assert len(red.buckets) > 1
+    opt.bind(red)
+    for step in range(4):
+        x = torch.randn(16, 300, device=dev())
+        for m in (net, ref):
+            m(x).square().sum().backward()
+        for g in opt.param_groups + opt_ref.param_groups:     # a schedule: per-step learning rate
+            g["lr"] = 3e-3 / (step + 1)
+        opt.step()
+        opt_ref.step()
+        opt_ref.zero_grad(set_to_none=True)
+        for b in red.buckets:
+            assert float(b["flat"].abs().max()) == 0.0
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            torch.testing.assert_close(p.data, q.data, atol=2e-6, rtol=2e-5, msg=lambda m: f"{k} step {step}: {m}")
+            assert torch.equal(p._vg_flat_shadow, p.data.bfloat16())
+    sd = opt.state_dict()
+    assert len(sd["state"]) == len(list(net.parameters())) and float(sd["state"][0]["step"]) == 4.0

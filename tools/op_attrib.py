@@ -53,7 +53,7 @@ def main():
         return f
 
     for name, mod in tr.model.named_modules():
-        if name and name.count(".") <= 1:
+        if name and name.count(".") <= int(os.environ.get("DEPTH", "1")):
             mod.register_forward_pre_hook(pre(name))
             mod.register_forward_hook(post(name))
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:

@@ -1,0 +1,85 @@
+// AdamW over a flat gradient bucket in one launch (reference
+// training_lib/optimizer.py:18-25 builds torch.optim.AdamW with two parameter groups,
+// call site trainers/speech/lvtr.py:150-157).
+//
+// Parameters, both moments and the gradient bucket share one layout (training_lib/dp.py):
+// every parameter starts on a 256-element boundary, so a wave owns one 256-element chunk
+// (4 floats per lane, 16-byte accesses on all seven streams) and the chunk's parameter-group
+// id selects lr / weight decay.  The same pass writes the bf16 copy of the updated weights
+// that the MFMA GEMMs consume and clears the gradient for the next accumulation window:
+// 28 B read+written per parameter instead of the separate optimizer, cast and zero passes.
+#include "vg_common.h"
+#include "../../include/vaegslm_hip.h"
+
+using namespace vg;
+
+namespace {
+
+struct AdamGroups {
+  float lr[4];
+  float wd[4];
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow,
+                                                    const unsigned char* __restrict__ group_of_chunk, long nchunks,
+                                                    AdamGroups G, float beta1, float beta2, float eps, float inv_bc1,
+                                                    float inv_sqrt_bc2, const float* __restrict__ grad_scale,
+                                                    int zero_grad) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  const float gs = grad_scale ? *grad_scale : 1.0f;
+  for (long c = wave; c < nchunks; c += nwaves) {
+    const int gi = group_of_chunk[c] & 3;
+    const float lr = G.lr[gi], decay = 1.0f - lr * G.wd[gi], step = lr * inv_bc1;
+    const long i = c * 256 + lane * 4;
+    f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + i);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gv[e] * gs;
+      mv[e] = fmaf(beta1, mv[e], (1.0f - beta1) * ge);
+      vv[e] = fmaf(beta2, vv[e], (1.0f - beta2) * ge * ge);
+      const float denom = fmaf(sqrtf(vv[e]), inv_sqrt_bc2, eps);
+      pv[e] = fmaf(-step, mv[e] / denom, pv[e] * decay);
+    }
+    *reinterpret_cast<f32x4*>(p + i) = pv;
+    *reinterpret_cast<f32x4*>(m + i) = mv;
+    *reinterpret_cast<f32x4*>(v + i) = vv;
+    if (shadow) {
+      bf16x4 sv = {(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
+      *reinterpret_cast<bf16x4*>(shadow + i) = sv;
+    }
+    if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+}  // namespace
+
+extern "C" int vg_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                        const uint8_t* group_of_chunk, int64_t n, const float* lr, const float* weight_decay,
+                        int ngroups, float beta1, float beta2, float eps, int step, const float* grad_scale,
+                        int zero_grad, hipStream_t stream) {
+  VG_REQUIRE(n > 0 && n % 256 == 0, "vg_adamw: n=%ld must be a positive multiple of 256", (long)n);
+  VG_REQUIRE(ngroups >= 1 && ngroups <= 4 && step >= 1, "vg_adamw: ngroups=%d step=%d", ngroups, step);
+  VG_REQUIRE(((uintptr_t)param % 16) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
+                 ((uintptr_t)exp_avg_sq % 16) == 0 && ((uintptr_t)shadow_bf16 % 8) == 0,
+             "vg_adamw: unaligned buffers");
+  AdamGroups G;
+  for (int i = 0; i < 4; ++i) {
+    G.lr[i] = i < ngroups ? lr[i] : 0.f;
+    G.wd[i] = i < ngroups ? weight_decay[i] : 0.f;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const long nchunks = n / 256;
+  long blocks = (nchunks + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  adamw_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16,
+                                                                group_of_chunk, nchunks, G, beta1, beta2, eps,
+                                                                (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale,
+                                                                zero_grad);
+  return vg_host::check_launch("vg_adamw");
+}

@@ -60,6 +60,8 @@ SIGNATURES = {
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "vg_mask_rows": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "vg_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _f, _f, _f, _i,
+                 _vp, _i, _vp],
     "vg_flow_blocks": [_i],
     "vg_flow_fwd": [_vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _i, _vp],
     "vg_flow_reverse": [_vp, _vp, _i64, _vp, _i, _vp, _i, _f, _f, _f, _vp],

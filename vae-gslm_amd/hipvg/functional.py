@@ -35,6 +35,9 @@ def shadow(weight: Tensor, dtype: torch.dtype) -> Tensor:
     """fp32 master parameter -> tensor in the compute dtype (cached by version)."""
     if weight.dtype == dtype:
         return weight.detach()
+    flat = getattr(weight, "_vg_flat_shadow", None)      # kept current by the flat optimizer step (vg_adamw)
+    if flat is not None and flat.dtype == dtype:
+        return flat
     ent = getattr(weight, "_vg_shadow", None)
     ver = weight._version
     if ent is not None and ent[0] == ver and ent[1].dtype == dtype:
@@ -43,10 +46,23 @@ def shadow(weight: Tensor, dtype: torch.dtype) -> Tensor:
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
-    out = torch.empty(w.shape, dtype=dtype, device=w.device)
+    # re-cast into the SAME tensor when the parameter changed: launches captured in a hipGraph keep
+    # reading a valid, current copy (see refresh_shadows)
+    out = ent[1] if ent is not None and ent[1].shape == w.shape and ent[1].dtype == dtype \
+        else torch.empty(w.shape, dtype=dtype, device=w.device)
     check(lib().vg_cast_f32_to_bf16(ptr(w), ptr(out), w.numel(), stream()), "vg_cast_f32_to_bf16")
     weight._vg_shadow = (ver, out)
     return out
+
+
+def refresh_shadows(params) -> None:
+    """Re-cast, in place, every cached bf16 weight copy whose master parameter has changed.  Call after an
+    optimizer step that is not the flat one when micro-steps are replayed from a hipGraph: the captured
+    GEMMs read the cached copies by address and never run the lazy cast of :func:`shadow`."""
+    for p in params:
+        ent = getattr(p, "_vg_shadow", None)
+        if ent is not None and ent[0] != p._version:
+            shadow(p, ent[1].dtype)
 
 
 # ---------------------------------------------------------------- raw ops

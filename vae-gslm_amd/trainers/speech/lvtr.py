@@ -75,6 +75,9 @@ class LVTRTrainer(BaseTrainer):
         bucket = hip.get("bucket_mb", 50) if hip is not None else 50
         overlap = hip.get("overlap", True) if hip is not None else True
         self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group)
+        bind = getattr(self.optimizer, "bind", None)
+        if callable(bind) and next(self.model.parameters()).is_cuda:
+            bind(self.reducer)                 # AdamW + bf16 weight refresh + gradient clear: one launch per bucket
         return self.reducer
 
     def current_kld_weight(self) -> float:
@@ -133,10 +136,15 @@ class LVTRTrainer(BaseTrainer):
             if clip is not None:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
             self.optimizer.step()
-            if self.reducer is not None:
+            if getattr(self.optimizer, "clears_gradients", False):
+                pass                                   # vg_adamw zeroed the buckets in the same pass
+            elif self.reducer is not None:
                 self.reducer.zero_grad()
             else:
                 self.optimizer.zero_grad(set_to_none=True)
+            if self.use_graph and not getattr(self.optimizer, "clears_gradients", False):
+                from hipvg import functional as HF
+                HF.refresh_shadows(self.model.parameters())   # captured GEMMs read the bf16 copies by address
             n = out["length"]
             self.log("train/kld", out["kld"] / n)
             self.log("train/rec_loss", out["rec_loss"] / n)

@@ -40,11 +40,13 @@ class GradReducer:
         dev = self.params[0].device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         limit = int(bucket_mb * (1 << 20) / 4)
-        # reverse order: the last-registered parameters receive gradients first
+        # reverse order: the last-registered parameters receive gradients first.  Every parameter starts
+        # on a 256-element boundary of its bucket (1 KiB): the flat optimizer kernel (vg_adamw) works on
+        # 256-element chunks that must not straddle two parameters (per-group lr / weight decay).
         self.buckets: List[dict] = []
         cur, cur_n = [], 0
         for p in reversed(self.params):
-            n = p.numel()
+            n = self._padded(p.numel())
             if cur and cur_n + n > limit:
                 self._close(cur, cur_n, dev)
                 cur, cur_n = [], 0
@@ -59,13 +61,20 @@ class GradReducer:
                 p.register_post_accumulate_grad_hook(hook)
                 p._vg_grad_hooks = [hook]      # fired by hipvg's gradient sink (bypasses AccumulateGrad)
 
+    ALIGN = 256
+
+    @classmethod
+    def _padded(cls, n: int) -> int:
+        return (n + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+
     def _close(self, plist, n, dev):
         flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        off, offsets = 0, []
         for p in plist:
             p.grad = flat[off: off + p.numel()].view_as(p)
-            off += p.numel()
-        self.buckets.append(dict(params=plist, flat=flat, pending=len(plist), need=len(plist)))
+            offsets.append(off)
+            off += self._padded(p.numel())
+        self.buckets.append(dict(params=plist, offsets=offsets, flat=flat, pending=len(plist), need=len(plist)))
 
     def _make_hook(self, bi: int):
         def hook(param):

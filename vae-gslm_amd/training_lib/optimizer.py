@@ -24,6 +24,93 @@ def _is_cuda(groups) -> bool:
     return False
 
 
+class FlatAdamW(optim.AdamW):
+    """``torch.optim.AdamW`` whose step is ONE HIP launch per gradient bucket (``vg_adamw``).
+
+    Until :meth:`bind` is called it behaves exactly like the stock (fused multi-tensor) optimizer.
+    ``bind(reducer)`` moves parameters, both moments and a bf16 copy of the weights into flat buffers
+    laid out like the reducer's gradient buckets (``training_lib/dp.py``); ``param.data`` and the
+    ``state[param]`` entries become views, so ``state_dict`` / LR schedulers / checkpoints see the usual
+    structure.  The launch also refreshes the bf16 weights the MFMA GEMMs read and clears the gradient
+    bucket, which replaces the per-parameter casts and the separate zero pass."""
+
+    def __init__(self, params, **kw):
+        super().__init__(params, **kw)
+        self._flat = None
+        self._steps = 0
+
+    # ---- layout
+    def bind(self, reducer) -> None:
+        import ctypes as C
+        import hipvg
+        group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            assert not g.get("amsgrad", False) and not g.get("maximize", False)
+            for p in g["params"]:
+                group_of[p] = gi
+        assert len(self.param_groups) <= 4, "vg_adamw supports up to 4 parameter groups"
+        self._flat = []
+        for b in reducer.buckets:
+            grad = b["flat"]
+            n, dev = grad.numel(), grad.device
+            P = torch.zeros(n, dtype=torch.float32, device=dev)
+            M, V = torch.zeros_like(P), torch.zeros_like(P)
+            S = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+            chunk_group = torch.zeros(n // 256, dtype=torch.uint8)
+            for p, off in zip(b["params"], b["offsets"]):
+                k = p.numel()
+                P[off: off + k].copy_(p.data.reshape(-1))
+                p.data = P[off: off + k].view(p.shape)
+                p._vg_flat_shadow = S[off: off + k].view(p.shape)
+                chunk_group[off // 256: (off + k + 255) // 256] = group_of[p]
+                self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": M[off: off + k].view(p.shape),
+                                 "exp_avg_sq": V[off: off + k].view(p.shape)}
+            S.copy_(P)
+            self._flat.append(dict(P=P, G=grad, M=M, V=V, S=S, groups=chunk_group.to(dev)))
+        self._ctypes = (C, hipvg)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=None):
+        if self._flat is None:
+            return super().step(closure)
+        C, hipvg = self._ctypes
+        self._steps += 1
+        ng = len(self.param_groups)
+        lr = (C.c_float * 4)(*[float(g["lr"]) for g in self.param_groups] + [0.0] * (4 - ng))
+        wd = (C.c_float * 4)(*[float(g["weight_decay"]) for g in self.param_groups] + [0.0] * (4 - ng))
+        b1, b2 = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        for f in self._flat:
+            hipvg.check(hipvg.lib().vg_adamw(hipvg.ptr(f["P"]), hipvg.ptr(f["G"]), hipvg.ptr(f["M"]), hipvg.ptr(f["V"]),
+                                             hipvg.ptr(f["S"]), hipvg.ptr(f["groups"]), f["P"].numel(), lr, wd, ng,
+                                             float(b1), float(b2), float(eps), self._steps, hipvg.ptr(grad_scale), 1,
+                                             hipvg.stream()), "vg_adamw")
+        return None
+
+    @property
+    def clears_gradients(self) -> bool:
+        """True once bound: ``step`` leaves the gradient buckets zeroed."""
+        return self._flat is not None
+
+    def state_dict(self):
+        if self._flat is not None:
+            for st in self.state.values():
+                st["step"] = torch.tensor(float(self._steps))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        if self._flat is None:
+            return super().load_state_dict(state_dict)
+        views = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items()}
+        super().load_state_dict(state_dict)
+        for p, (m, v) in views.items():          # keep the flat storage: copy the loaded moments into it
+            st = self.state[p]
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            self._steps = int(float(st["step"]))
+            st["exp_avg"], st["exp_avg_sq"] = m, v
+
+
 def optimizer_map(hp: Hparams, parameters) -> optim.Optimizer:
     hp.check_arg_in_hparams("identifier")
     if hp.identifier not in ("Adam", "AdamW"):
@@ -35,6 +122,8 @@ def optimizer_map(hp: Hparams, parameters) -> optim.Optimizer:
         kw["fused"] = True
     if hp.identifier == "Adam":
         return optim.Adam(parameters, weight_decay=hp.get("weight_decay", 0), **kw)
+    if kw.get("fused"):
+        return FlatAdamW(parameters, weight_decay=hp.get("weight_decay", 0.01), **kw)
     return optim.AdamW(parameters, weight_decay=hp.get("weight_decay", 0.01), **kw)
 
 
