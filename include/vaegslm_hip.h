@@ -191,6 +191,24 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
                   float* norm_part, float* w_part, int M, int C, int T, int taps, int shift, int dtype,
                   vg_stream_t stream);
 
+/* ---------------------------------------------------------------- autoregressive decode step
+ * LVTR.step (models/speech/lvtr.py:227-286): one new frame per sequence.
+ * vg_gemm_rows: y[M][N] = act(x[M][K] W[N][K]^T + bias) + residual for M <= 16 rows (HBM-bound on W; exact
+ *   fp32 accumulation; replaces nn.Linear at modules/attention/attention.py:52,79,
+ *   modules/transformer/layers.py:82, modules/linear/layers.py:192 on the decode path).
+ *   x, W, residual in dtype; y in dtype or fp32 (out_f32); K, ldx, ldw multiples of 8.
+ * vg_attn_decode_append: qkv [B][3*H*64] of the new frame; the key/value rows are written into the
+ *   pre-allocated caches [B][Tmax][H*64] at index pos[b], then the query attends over pos[b]+1 frames with
+ *   the ALiBi bias of modules/position/alibi.py:9-33 (query position = last; attention.py:56-73).
+ * vg_advance: pos[i] += by (device-side frame counter; keeps the step replayable from a hipGraph).
+ */
+int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* residual,
+                 int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act, int out_f32, int dtype,
+                 vg_stream_t stream);
+int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,
+                          const int32_t* pos, int B, int Tmax, int H, int dtype, vg_stream_t stream);
+int vg_advance(int32_t* pos, int n, int by, vg_stream_t stream);
+
 /* ---------------------------------------------------------------- optimizer
  * AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias correction; reference
  * training_lib/optimizer.py:18-25, stepped at trainers/speech/lvtr.py:150-157) over one flat gradient

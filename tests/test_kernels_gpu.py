@@ -499,3 +499,45 @@ def test_flat_adamw_matches_torch(F):
             assert torch.equal(p._vg_flat_shadow, p.data.bfloat16())
     sd = opt.state_dict()
     assert len(sd["state"]) == len(list(net.parameters())) and float(sd["state"][0]["step"]) == 4.0
+
+
+# ------------------------------------------------------------------ decode-step kernels
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 200, 1024), (3, 8, 1024), (8, 3072, 1024), (8, 1024, 4096), (16, 136, 64),
+                                   (5, 24, 8192)])
+def test_gemm_rows(F, dtype, shape):
+    """vg_gemm_rows (the Linear of the autoregressive step) vs fp64: row counts 1..16, column counts that are
+    not multiples of 8, reduction lengths from 64 to 8192, bias / GELU / residual epilogue, fp32 output."""
+    M, N, K = shape
+    x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=K ** -0.5)
+    bias, res = rnd(N, scale=0.1), rnd(M, N, dtype=dtype, seed=2)
+    ref = x.double() @ w.double().T + bias.double()
+    y = F.rows_linear(x, w, bias, out_f32=True)
+    torch.testing.assert_close(y.double(), ref, atol=2e-5 if dtype == torch.float32 else 2e-3, rtol=1e-4)
+    y = F.rows_linear(x, w, bias, act=2, residual=res)
+    assert y.dtype == dtype
+    torch.testing.assert_close(y.double(), torch.nn.functional.gelu(ref) + res.double(), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_decode_append(F, dtype):
+    """Cache append + single-query attention == dense softmax over the grown cache, per-sequence positions."""
+    B, H, Tmax = 3, 4, 300
+    D = H * 64
+    kc, vc = rnd(B, Tmax, D, dtype=dtype), rnd(B, Tmax, D, dtype=dtype, seed=1)
+    qkv = rnd(B, 3 * D, dtype=dtype, seed=2)
+    pos = torch.tensor([0, 129, 298], dtype=torch.int32, device=dev())
+    slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
+    kref, vref = kc.clone(), vc.clone()
+    out = F.attention_decode_append(qkv, kc, vc, slopes, pos, H)
+    for b in range(B):
+        n = int(pos[b]) + 1
+        kref[b, n - 1], vref[b, n - 1] = qkv[b, D:2 * D], qkv[b, 2 * D:]
+        assert torch.equal(kc[b, n - 1], kref[b, n - 1]) and torch.equal(vc[b, n - 1], vref[b, n - 1])
+        q = qkv[b, :D].double().view(H, 1, 64)
+        k = kref[b, :n].double().view(n, H, 64).transpose(0, 1)
+        v = vref[b, :n].double().view(n, H, 64).transpose(0, 1)
+        s = q @ k.transpose(1, 2) / 8.0 - slopes.double()[:, None, None] * torch.arange(n - 1, -1, -1, device=dev())[None, None]
+        ref = (torch.softmax(s, -1) @ v).reshape(D)
+        torch.testing.assert_close(out[b].double(), ref, **tol(dtype))
+    assert torch.equal(kc[:, 299], kref[:, 299])          # untouched rows stay untouched

@@ -1,0 +1,246 @@
+// Kernels of the autoregressive decode step: one new frame per sequence.
+//
+//  * vg_gemm_rows: y[M<=16][N] = epi(x[M][K] W[N][K]^T) -- the Linear layers of LVTR.step
+//    (reference models/speech/lvtr.py:227-286 -> modules/transformer/layers.py:41-93,
+//    modules/attention/attention.py:52,79, modules/linear/layers.py:192) when only a handful of
+//    rows exist.  The product is bound by streaming W once from HBM (403 MB of bf16 weights per step at
+//    the full config), not by arithmetic, so there is no MFMA and no LDS tile: a block owns 16 output
+//    columns, its 16 waves split K, every lane streams 16-byte pieces of one weight row and keeps one
+//    fp32 accumulator per input row; partial sums meet in LDS.  Exact fp32 accumulation in both dtypes
+//    (the fp32 build of this kernel is the parity path).
+//  * vg_attn_decode_append: writes this step's key/value rows into the pre-allocated cache at pos[b]
+//    and attends over the pos[b]+1 cached frames (replaces the per-step torch.cat and mask rebuild of
+//    modules/attention/attention.py:56-73).
+//  * vg_advance: pos[b] += 1 (device-side step counter, so a captured hipGraph can be replayed).
+#include "vg_common.h"
+#include "../../include/vaegslm_hip.h"
+
+using namespace vg;
+
+namespace {
+
+constexpr int RC = 8;           // output columns per block
+constexpr int RCHUNK = 512;     // k range of one wave (64 lanes x 8 elements: 1 KiB of a bf16 weight row per load)
+constexpr int RMAXW = 8;        // waves per block = min(8, ceil(K / 512)); longer K: a wave walks several ranges
+constexpr int RMAXM = 16;
+
+template <typename T> struct Ld8;     // 8 consecutive elements as floats
+template <> struct Ld8<bf16_t> {
+  static VG_DEVICE void get(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+};
+template <> struct Ld8<float> {
+  static VG_DEVICE void get(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+    o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  }
+};
+
+// Block = 8 output columns x all of K; wave w owns k in [512 w, 512 w + 512), lane l the 8 elements at
+// 512 w + 8 l: every load is a fully coalesced 16-byte-per-lane row segment, the 8 weight rows of the
+// block are requested back to back (8 KiB in flight per wave) and the x rows are read once per lane.
+// Each lane then holds MM x 8 partial dot products; a recursive-halving exchange (xor 32, 16, .. 1; 63
+// shuffles for 64 values instead of 64 full reductions) leaves lane l with the wave-wide sum of value
+// index l (= row l / 8, column l % 8); the waves' sums meet in LDS and wave 0 applies the epilogue.
+template <typename T, int MM>
+__global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restrict__ x, long ldx,
+                                                               const T* __restrict__ w, long ldw,
+                                                               const float* __restrict__ bias,
+                                                               const T* __restrict__ residual, long ldr,
+                                                               void* __restrict__ y, long ldy, int M, int N, int K,
+                                                               int act, int out_f32) {
+  constexpr int V = MM * RC;            // values per lane before the exchange
+  constexpr int PER = V / 64;           // values per lane after it (1 for MM = 8, 2 for MM = 16)
+  __shared__ float red[RMAXW][V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int n0 = blockIdx.x * RC;
+  float v[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) v[i] = 0.f;
+  for (int k0 = wave * RCHUNK + lane * 8; k0 < K; k0 += nwaves * RCHUNK) {
+    float wv[RC][8];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      const int n = min(n0 + c, N - 1);
+      Ld8<T>::get(w + (long)n * ldw + k0, wv[c]);
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      if (m < M) {
+        float xv[8];
+        Ld8<T>::get(x + (long)m * ldx + k0, xv);
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+          float a = v[m * RC + c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a = fmaf(xv[e], wv[c][e], a);
+          v[m * RC + c] = a;
+        }
+      }
+    }
+  }
+  // recursive halving: after the stage with offset o a lane keeps the half selected by its bit o
+#pragma unroll
+  for (int o = 32, cur = V; o >= 1; o >>= 1, cur >>= 1) {
+    const int half = cur >> 1;
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < V / 2; ++i) {
+      if (i < half) {
+        const float send = up ? v[i] : v[i + half];
+        const float keep = up ? v[i + half] : v[i];
+        v[i] = keep + __shfl_xor(send, o, 64);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) red[wave][lane * PER + j] = v[j];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int idx = lane * PER + j, m = idx / RC, n = n0 + idx % RC;
+      if (m < M && n < N) {
+        float r = 0.f;
+        for (int ww = 0; ww < nwaves; ++ww) r += red[ww][idx];
+        if (bias) r += bias[n];
+        if (act == VG_ACT_RELU) r = fmaxf(r, 0.f);
+        else if (act == VG_ACT_GELU) r = gelu_erf(r);
+        else if (act == VG_ACT_SILU) r = silu(r);
+        if (residual) r += to_f32<T>(residual[(long)m * ldr + n]);
+        if (out_f32) reinterpret_cast<float*>(y)[(long)m * ldy + n] = r;
+        else reinterpret_cast<T*>(y)[(long)m * ldy + n] = from_f32<T>(r);
+      }
+    }
+  }
+}
+
+// one block of 4 waves per (b, h): append this step's k/v, then softmax(q.k/8 - slope (n-1-j)) v over
+// the cache; the 256 lanes stride over the cached frames (few dependent iterations per lane), partial
+// (max, sum, weighted value) triples meet in LDS
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
+                                                                 T* __restrict__ vc, T* __restrict__ out,
+                                                                 const float* __restrict__ slopes,
+                                                                 const int* __restrict__ pos, int Tmax, int H) {
+  constexpr int DH = 64;
+  __shared__ float red[4][DH][65];      // [wave][d][lane] (+1: conflict-free column sums)
+  __shared__ float wl[4], wm[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x, b = blockIdx.y;
+  const int D = H * DH;
+  const int p0 = min(pos[b], Tmax - 1);
+  const T* __restrict__ row = qkv + (long)b * 3 * D + h * DH;
+  const long cbase = ((long)b * Tmax) * D + h * DH;
+  if (wave == 0) {
+    kc[cbase + (long)p0 * D + lane] = row[D + lane];
+    vc[cbase + (long)p0 * D + lane] = row[2 * D + lane];
+  }
+  __syncthreads();                                  // the new cache rows are visible to the whole block
+  const int n = p0 + 1;
+  float qv[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) qv[d] = to_f32<T>(row[d]);
+  const float slope = slopes[h];
+  float m = -INFINITY, l = 0.f, acc[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+  for (int j = tid; j < n; j += 256) {
+    const T* kr = kc + cbase + (long)j * D;
+    const T* vr = vc + cbase + (long)j * D;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) s += qv[d] * to_f32<T>(kr[d]);
+    s = s * 0.125f - slope * (float)(n - 1 - j);
+    const float mn = fmaxf(m, s);
+    const float a = expf(m - mn), pw = expf(s - mn);
+    l = l * a + pw;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = acc[d] * a + pw * to_f32<T>(vr[d]);
+    m = mn;
+  }
+  const float mg = wave_max(m);
+  const float wgt = (m == -INFINITY) ? 0.f : expf(m - mg);
+  const float lg = wave_sum(l * wgt);
+#pragma unroll
+  for (int d = 0; d < DH; ++d) red[wave][d][lane] = acc[d] * wgt;
+  if (lane == 0) {
+    wl[wave] = lg;
+    wm[wave] = mg;
+  }
+  __syncthreads();
+  // thread (wave, lane = d): sum its wave's 64 partial values of dimension d, then merge the 4 waves
+  float o = 0.f;
+  for (int r = 0; r < 64; ++r) o += red[wave][lane][r];
+  __syncthreads();
+  red[wave][0][lane] = o;
+  __syncthreads();
+  if (wave == 0) {
+    const float M4 = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = (wm[w] == -INFINITY) ? 0.f : expf(wm[w] - M4);
+      num += red[w][0][lane] * f;
+      den += wl[w] * f;
+    }
+    out[(long)b * D + h * DH + lane] = from_f32<T>(num / den);
+  }
+}
+
+__global__ void advance_kernel(int* __restrict__ pos, int n, int by) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[i] += by;
+}
+
+template <typename T>
+int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* bias, const void* res, long ldr, void* y,
+                long ldy, int M, int N, int K, int act, int out_f32, hipStream_t stream) {
+  int nwaves = (K + RCHUNK - 1) / RCHUNK;
+  if (nwaves > RMAXW) nwaves = RMAXW;
+  dim3 grid((N + RC - 1) / RC), block(nwaves * 64);
+  if (M <= 8)
+    gemm_rows_kernel<T, 8><<<grid, block, 0, stream>>>((const T*)x, ldx, (const T*)w, ldw, bias, (const T*)res, ldr, y,
+                                                      ldy, M, N, K, act, out_f32);
+  else
+    gemm_rows_kernel<T, 16><<<grid, block, 0, stream>>>((const T*)x, ldx, (const T*)w, ldw, bias, (const T*)res, ldr, y,
+                                                       ldy, M, N, K, act, out_f32);
+  return vg_host::check_launch("vg_gemm_rows");
+}
+
+}  // namespace
+
+extern "C" int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                            const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act,
+                            int out_f32, int dtype, hipStream_t stream) {
+  VG_REQUIRE(M >= 1 && M <= RMAXM && N >= 1 && K >= 8, "vg_gemm_rows: M=%d (1..%d) N=%d K=%d", M, RMAXM, N, K);
+  VG_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "vg_gemm_rows: K, ldx, ldw must be multiples of 8");
+  VG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "vg_gemm_rows: x / w must be 16-byte aligned");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_gemm_rows: bad dtype %d", dtype);
+  if (dtype == VG_BF16)
+    return launch_rows<bf16_t>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, stream);
+  return launch_rows<float>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, stream);
+}
+
+extern "C" int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,
+                                     const int32_t* pos, int B, int Tmax, int H, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && Tmax > 0 && H > 0, "vg_attn_decode_append: empty problem");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_decode_append: bad dtype %d", dtype);
+  dim3 grid(H, B);
+  if (dtype == VG_BF16)
+    attn_decode_append_kernel<bf16_t><<<grid, dim3(256), 0, stream>>>((const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+                                                                    (bf16_t*)out, slopes, pos, Tmax, H);
+  else
+    attn_decode_append_kernel<float><<<grid, dim3(256), 0, stream>>>((const float*)qkv, (float*)kcache, (float*)vcache,
+                                                                   (float*)out, slopes, pos, Tmax, H);
+  return vg_host::check_launch("vg_attn_decode_append");
+}
+
+extern "C" int vg_advance(int32_t* pos, int n, int by, hipStream_t stream) {
+  VG_REQUIRE(n > 0, "vg_advance: empty");
+  advance_kernel<<<dim3((n + 63) / 64), dim3(64), 0, stream>>>(pos, n, by);
+  return vg_host::check_launch("vg_advance");
+}

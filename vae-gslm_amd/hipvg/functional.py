@@ -75,6 +75,10 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
          colsum_out: Optional[Tensor] = None) -> Tensor:
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
+    if A.data_ptr() % 16:      # e.g. a channel slice of a single frame: the kernels need 16-byte aligned operands
+        A = A.clone()
+    if B.data_ptr() % 16:
+        B = B.clone()
     if out is None:
         odt = torch.float32 if out_f32 else A.dtype
         out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=odt, device=A.device)
@@ -850,12 +854,47 @@ def coupling_flow(z, wb, params, *, eps, hi, lo, lengths=None, T=0):
     return FlowFn.apply(z, wb, lengths, T, eps, hi, lo, *params)
 
 
-def coupling_flow_reverse(u, wb, params, *, eps, hi, lo):
+def pack_flow_params(params) -> Tensor:
+    return torch.cat([p.detach().reshape(-1).float() for p in params])
+
+
+def coupling_flow_reverse(u, wb, params, *, eps, hi, lo, packed: Optional[Tensor] = None):
     M = u.shape[0]
     L = len(params) // 6
     u = u.contiguous().float()
-    packed = torch.cat([p.detach().reshape(-1).float() for p in params])
+    if packed is None:
+        packed = pack_flow_params(params)
     z = torch.empty_like(u)
     check(lib().vg_flow_reverse(ptr(u), ptr(wb), wb.stride(0), ptr(packed), L, ptr(z), M, float(eps), float(hi),
                                 float(lo), stream()), "vg_flow_reverse")
     return z
+
+
+# ---------------------------------------------------------------- decode step (no autograd: inference only)
+def rows_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
+                residual: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
+    """y = act(x W^T + b) + residual for a handful of rows (M <= 16): the HBM-bound Linear of the
+    autoregressive step (vg_gemm_rows).  ``weight`` must already be in x's dtype (see :func:`shadow`)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    assert x.dtype == weight.dtype and x.stride(1) == 1 and weight.stride(1) == 1 and weight.shape[1] == K
+    y = torch.empty((M, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    b = None if bias is None else bias.detach().float()
+    check(lib().vg_gemm_rows(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(b), ptr(residual),
+                             0 if residual is None else residual.stride(0), ptr(y), y.stride(0), M, N, K, int(act),
+                             int(out_f32), dtype_id(x.dtype), stream()), "vg_gemm_rows")
+    return y
+
+
+def attention_decode_append(qkv: Tensor, kcache: Tensor, vcache: Tensor, slopes: Tensor, pos: Tensor, H: int) -> Tensor:
+    """qkv [B, 3*H*64] of the new frame; caches [B, Tmax, H*64] (updated in place at pos[b])."""
+    B = qkv.shape[0]
+    Tmax = kcache.shape[1]
+    out = torch.empty((B, H * 64), dtype=qkv.dtype, device=qkv.device)
+    check(lib().vg_attn_decode_append(ptr(qkv), ptr(kcache), ptr(vcache), ptr(out), ptr(slopes), ptr(pos), B, Tmax, H,
+                                      dtype_id(qkv.dtype), stream()), "vg_attn_decode_append")
+    return out
+
+
+def advance(pos: Tensor, by: int = 1) -> None:
+    check(lib().vg_advance(ptr(pos), pos.numel(), int(by), stream()), "vg_advance")

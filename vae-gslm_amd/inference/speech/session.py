@@ -1,0 +1,184 @@
+"""Autoregressive decode session for ``LVTR`` on the MI355X.
+
+``LVTR.step`` (reference models/speech/lvtr.py:227-286) keeps the reference's call contract: it returns
+the grown key/value tensors and the caller (``ARTRSampler``, trainers/speech/sampler.py:17-72) feeds them
+back, which costs a ``torch.cat`` of every layer's cache and ~150 small launches from Python per frame.
+This session produces the same frames from a different machine model:
+
+* the key/value caches are allocated once, ``[layers][B, Tmax, d]`` in the compute dtype; the attention
+  kernel of the step writes the new row at ``pos[b]`` itself (``vg_attn_decode_append``);
+* the prompt is consumed by ONE pass of the training-path kernels (flash attention over the whole prompt),
+  whose per-layer key/value projections are copied into the caches;
+* every Linear of the step is ``vg_gemm_rows`` (HBM-bound: the step streams the 403 MB of bf16 weights
+  once), norms / flow reverse / Gaussian sample are the row kernels of the training path;
+* the whole step -- embedding of the previous output, 16 layers, prior head, reverse flow, token
+  soft-max and draw, write-back of the new frame into the step's own input buffer, ``pos += 1`` -- is
+  captured once into a hipGraph and replayed per frame; the random draws use the graph-safe generator.
+
+Only the token + flow model of ``vae-gslm.yaml`` is covered (the same scope as ``LVTR.forward``).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+import hipvg
+from hipvg import functional as HF
+from utils.tensormask import TensorMask
+
+
+class DecodeSession:
+    def __init__(self, model, batch_size: int, max_frames: int, *, temperature: float = 1.0,
+                 token_temperature: float = 1.0, use_graph: bool = True, device=None):
+        if not model.use_tokens or model.transformer_flow is None:
+            raise NotImplementedError("DecodeSession implements the token + flow model of vae-gslm.yaml")
+        self.model = model
+        self.B, self.Tmax = int(batch_size), int(max_frames)
+        self.temperature, self.token_temperature = float(temperature), float(token_temperature)
+        self.use_graph = bool(use_graph)
+        stack = model.transformer[0]
+        self.stack = stack
+        self.L = len(stack.layers)
+        self.D = stack.hp.layer.dim
+        self.H = stack.layers[0].self_attn.nheads
+        dev = device if device is not None else next(model.parameters()).device
+        self.dev = torch.device(dev)
+        self.dt = hipvg.compute_dtype()
+        if self.B > 16:
+            raise NotImplementedError("vg_gemm_rows handles up to 16 sequences per session")
+        head = model.transformer[1]
+        if not head.plain:
+            raise NotImplementedError("DecodeSession needs the plain (mean, logstd) prior head")
+        if stack.first_norm is not None or stack.out is not None or stack.final_norm is None:
+            raise NotImplementedError("DecodeSession: stack layout differs from vae-gslm.yaml")
+        self.kc = [torch.zeros(self.B, self.Tmax, self.D, dtype=self.dt, device=self.dev) for _ in range(self.L)]
+        self.vc = [torch.zeros(self.B, self.Tmax, self.D, dtype=self.dt, device=self.dev) for _ in range(self.L)]
+        self.pos = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.frame = torch.zeros(self.B, 1, 1 + model.hp.latent_dim, dtype=torch.float32, device=self.dev)
+        from modules.attention.attention import _slopes_from
+        self.slopes = _slopes_from((stack.rpe_id, stack.rpe), None, self.dev).slopes
+        # per-session constants of the heads (concatenated projections, packed flow parameters)
+        flow = model.transformer_flow
+        if not flow._hip_ok(self.frame, c=True):
+            raise NotImplementedError("DecodeSession needs the vae-gslm.yaml coupling stack (vg_flow_reverse)")
+        with torch.no_grad():
+            self._head_w = torch.cat([head.mean.weight, head.logstd.weight], 0).to(self.dt).contiguous()
+            self._head_b = torch.cat([head.mean.bias, head.logstd.bias], 0).float().contiguous()
+            self._film_w = torch.cat([l.film.linear.weight for l in flow.layers], 0).to(self.dt).contiguous()
+            self._film_b = torch.cat([l.film.linear.bias for l in flow.layers], 0).float().contiguous()
+            self._flow_params = []
+            for l in flow.layers:
+                self._flow_params += [l.linear1.weight, l.linear1.bias, l.norm.weight, l.norm.bias,
+                                      l.linear2.weight, l.linear2.bias]
+            self._flow_packed = HF.pack_flow_params(self._flow_params)
+            hi, lo = flow.layers[0].scale_range
+            self._flow_kw = dict(eps=flow.layers[0].norm.eps, hi=float(hi), lo=float(lo))
+        self._graph = None
+        self._last = {}
+
+    # ------------------------------------------------------------------ weights in the compute dtype
+    def _w(self, weight):
+        return HF.shadow(weight, self.dt)
+
+    # ------------------------------------------------------------------ prompt
+    @torch.no_grad()
+    def prefill(self, prior: torch.Tensor, init_state: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """prior: (B, Tp, 1 + latent) -- token ids (as float) and posterior latents of the prompt.
+        Runs the first ``LVTR.step`` of the reference sampler (``push_init_state=True``), fills the
+        caches with its Tp + 1 frames and returns the first sampled frame (B, 1, 1 + latent)."""
+        B, Tp = prior.shape[:2]
+        assert B == self.B and Tp + 1 <= self.Tmax
+        out = self.model.step(prior, push_init_state=True, temperature=self.temperature,
+                              token_temperature=self.token_temperature, init_state=init_state, noise=noise)
+        for l, kv in enumerate(out["kv"]):
+            self.kc[l][:, :Tp + 1].copy_(kv["key"])
+            self.vc[l][:, :Tp + 1].copy_(kv["value"])
+        self.pos.fill_(Tp + 1)
+        first = out["output"][:, -1:].float()
+        self.frame.copy_(first)
+        self._last = {"transformer_latent": out["transformer_latent"].value[:, -1:], "logits": out["logits"][:, -1:],
+                      "prior": out["prior"]}
+        return first.clone()
+
+    # ------------------------------------------------------------------ one frame
+    def _step_body(self, noise: Optional[torch.Tensor] = None) -> None:
+        m, dt, B = self.model, self.dt, self.B
+        lat_dim = m.hp.latent_dim
+        ids = self.frame[:, 0, 0].long()
+        z_prev = self.frame[:, 0, 1:]
+        tok = m.token_embedding.weight[ids]                                        # (B, 64)
+        fuser = m.token_fuser.linear
+        h = tok + torch.relu(torch.nn.functional.linear(z_prev, fuser.weight, fuser.bias))
+        x = h.to(dt)
+        st = self.stack
+        if st.linear is not None:
+            x = HF.rows_linear(x, self._w(st.linear.weight), st.linear.bias)
+        for l, layer in enumerate(st.layers):
+            att = layer.self_attn
+            n1, _ = HF.rmsnorm_fwd_raw(x, layer.norm1.scale.detach().float(), layer.norm1.eps, None, 0)
+            qkv = HF.rows_linear(n1, self._w(att.in_proj.weight), att.in_proj.bias)
+            ctx = HF.attention_decode_append(qkv, self.kc[l], self.vc[l], self.slopes, self.pos, self.H)
+            x1 = HF.rows_linear(ctx, self._w(att.out_proj.weight), att.out_proj.bias, residual=x)
+            n3, _ = HF.rmsnorm_fwd_raw(x1, layer.norm3.scale.detach().float(), layer.norm3.eps, None, 0)
+            mid = HF.rows_linear(n3, self._w(layer.linear1.weight), layer.linear1.bias, act=hipvg.ACT_GELU)
+            x = HF.rows_linear(mid, self._w(layer.linear2.weight), layer.linear2.bias, residual=x1)
+        lat, _ = HF.rmsnorm_fwd_raw(x, st.final_norm.scale.detach().float(), st.final_norm.eps, None, 0)
+        qs = m.q_spliter.linear
+        cond = HF.rows_linear(lat, self._w(qs.weight), qs.bias, act=hipvg.ACT_RELU)
+        mu_ls = HF.rows_linear(cond, self._head_w, self._head_b, out_f32=True)      # (B, 2 latent)
+        eps = noise if noise is not None else torch.randn(B, lat_dim, device=self.dev)
+        z, _ = HF.reparameterize(mu_ls[:, :lat_dim].contiguous(), mu_ls[:, lat_dim:].contiguous(),
+                                 eps.reshape(B, lat_dim).contiguous(), self.temperature)
+        wb = HF.rows_linear(cond, self._film_w, self._film_b, out_f32=True)        # FiLM rows of the 4 coupling layers
+        z = HF.coupling_flow_reverse(z, wb, self._flow_params, packed=self._flow_packed, **self._flow_kw)
+        ts, tp = m.token_spliter.linear, m.token_predictor.linear
+        hid = HF.rows_linear(lat, self._w(ts.weight), ts.bias, act=hipvg.ACT_RELU)
+        logits = HF.rows_linear(hid, self._w(tp.weight), tp.bias, out_f32=True)      # (B, vocab)
+        probs = torch.softmax(logits / self.token_temperature, dim=-1)
+        picked = torch.multinomial(probs, 1).float()
+        self.frame[:, 0, :1] = picked
+        self.frame[:, 0, 1:] = z.float()
+        HF.advance(self.pos, 1)
+        self._last = {"transformer_latent": lat.view(B, 1, -1), "logits": logits.view(B, 1, -1),
+                      "mu_ls": mu_ls.view(B, 1, -1)}
+
+    @torch.no_grad()
+    def step(self, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Consumes the frame produced by the previous call (or by :meth:`prefill`) and returns the next
+        one, (B, 1, 1 + latent).  With ``noise`` (teacher-forced tests) the step runs eagerly."""
+        if noise is not None or not self.use_graph:
+            self._step_body(noise)
+            return self.frame.clone()
+        if self._graph is None:
+            # lazy initialisations (weight casts, allocator) happen on the first, eager, frame; the
+            # second frame is captured and every later one replays it
+            self._step_body()
+            out, eager_last = self.frame.clone(), self._last
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    self._step_body()
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph, self._graph_last = graph, self._last     # the capture's output buffers
+            self._last = eager_last
+            return out
+        self._graph.replay()
+        self._last = self._graph_last
+        return self.frame.clone()
+
+    def force_frame(self, frame: torch.Tensor) -> None:
+        """Overwrite the frame the next :meth:`step` consumes (teacher forcing)."""
+        self.frame.copy_(frame.reshape(self.frame.shape))
+
+    @torch.no_grad()
+    def generate(self, length: int) -> torch.Tensor:
+        """``length`` further frames after :meth:`prefill`'s first one -> (B, length, 1 + latent)."""
+        assert int(self.pos.max()) + length <= self.Tmax, "cache too small for the requested continuation"
+        out = torch.empty(self.B, length, self.frame.shape[-1], dtype=torch.float32, device=self.dev)
+        for t in range(length):
+            out[:, t:t + 1] = self.step()
+        return out
