@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--graph", type=int, default=1, help="replay each micro-step as a hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--seq-len", type=int, default=SEQ_LEN, help="frames per sequence (BASELINE config 5: 2000)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,7 +125,8 @@ def main():
     B = hp.data.train.batch_size
     accum = trainer.gradient_update_step
     n_micro = (args.steps + args.warmup) * accum
-    batches = [make_batch(B, SEQ_LEN, device, seed=1234 + rank * 1000 + i) for i in range(n_micro)]
+    T_SEQ = args.seq_len
+    batches = [make_batch(B, T_SEQ, device, seed=1234 + rank * 1000 + i) for i in range(n_micro)]
     torch.cuda.synchronize()
 
     def sync():
@@ -149,7 +151,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    tokens = args.steps * accum * B * SEQ_LEN * world
+    tokens = args.steps * accum * B * T_SEQ * world
     value = tokens / elapsed
     if args.graph:
         # kernels inside a replayed hipGraph cannot be bracketed by host-recorded events: measure the
@@ -172,22 +174,33 @@ def main():
                 tot_work += work
         hipvg.prof_enable(False)
         achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
+        # HBM-side bytes per launch of the same kernel family: bench.py cannot collect PMC counters itself, so
+        # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
+        # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v3.json), valid for the default workload only
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v3.json")
+        if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16":
+            with open(pmc) as f:
+                traffic = json.load(f)["bf16_gemm_family"]["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01/pmc_traffic_v3.json (separate --pmc passes over the same command)"
+        # 25,165,824 GEMM + 2*2*1024*(T+1)/2 attention FLOP per layer, 16 layers, + heads; x3
+        flop_per_token = 3.0 * (16 * (25165824 + 2 * 2 * 1024 * (T_SEQ + 1) / 2) + 131072 + 5671936)
         line = {
-            "metric": "train tokens/sec (50 Hz frames) at seq_len=1000",
+            "metric": f"train tokens/sec (50 Hz frames) at seq_len={T_SEQ}",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "vae-gslm.yaml full config (L=16, d=1024, H=16, ffd=4096, 227M params), "
-                                   "fwd+bwd+AdamW, micro-batch 8 x grad-accum 2 per step, seq_len 1000",
-                       "micro_batch": B, "grad_accum": accum, "seq_len": SEQ_LEN,
+                                   f"fwd+bwd+AdamW, micro-batch {B} x grad-accum {accum} per step, seq_len {T_SEQ}",
+                       "micro_batch": B, "grad_accum": accum, "seq_len": T_SEQ,
                        "parallelism": f"dp{world}", "loss": float(out["loss"])},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
+                         "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_source": traffic_src,
                          "measured_on": ("one eager optimizer step right after the timed hipGraph replays"
                                          if args.graph else "the timed region"),
-                         "step_model_tflops": value / world * TRAIN_FLOP_PER_TOKEN / 1e12,
-                         "step_model_frac": value / world * TRAIN_FLOP_PER_TOKEN / PEAK_BF16,
+                         "step_model_tflops": value / world * flop_per_token / 1e12,
+                         "step_model_frac": value / world * flop_per_token / PEAK_BF16,
                          "kernels": kinds},
         }
         if world == 1 and not args.no_cpu_baseline:
