@@ -196,18 +196,27 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
  * vg_gemm_rows: y[M][N] = act(x[M][K] W[N][K]^T + bias) + residual for M <= 16 rows (HBM-bound on W; exact
  *   fp32 accumulation; replaces nn.Linear at modules/attention/attention.py:52,79,
  *   modules/transformer/layers.py:82, modules/linear/layers.py:192 on the decode path).
- *   x, W, residual in dtype; y in dtype or fp32 (out_f32); K, ldx, ldw multiples of 8.
+ *   x, W, residual in dtype; y in dtype or fp32 (out_f32); K, ldx, ldw multiples of 8.  norm_scale (fp32 [K]
+ *   or NULL): fuse the preceding RMSNorm (modules/norm.py:28-32), y = act(rmsnorm(x; scale, eps) W^T + b) + r.
+ * vg_embed_fuse: frame [B][ldf] = (token id as float, latent z); out[b] = E[id] + relu(Wf z + bf) in dtype
+ *   (token_embedding + token_fuser, models/speech/lvtr.py:161-168).
+ * vg_sample_token: categorical draw from softmax(logits / temperature) by inverse CDF with uniform[b] in
+ *   [0,1); writes the id to frame[b][0] and, if pos != NULL, pos[b] += 1 (lvtr.py:276-284).
  * vg_attn_decode_append: qkv [B][3*H*64] of the new frame; the key/value rows are written into the
  *   pre-allocated caches [B][Tmax][H*64] at index pos[b], then the query attends over pos[b]+1 frames with
  *   the ALiBi bias of modules/position/alibi.py:9-33 (query position = last; attention.py:56-73).
  * vg_advance: pos[i] += by (device-side frame counter; keeps the step replayable from a hipGraph).
  */
 int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* residual,
-                 int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act, int out_f32, int dtype,
-                 vg_stream_t stream);
+                 int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act, int out_f32,
+                 const float* norm_scale, float norm_eps, int dtype, vg_stream_t stream);
 int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,
                           const int32_t* pos, int B, int Tmax, int H, int dtype, vg_stream_t stream);
 int vg_advance(int32_t* pos, int n, int by, vg_stream_t stream);
+int vg_embed_fuse(const float* frame, int ldf, const float* emb, int vocab, int E, const float* wf, const float* bf,
+                  int latent, void* out, int B, int dtype, vg_stream_t stream);
+int vg_sample_token(const float* logits, int V, float temperature, const float* uniform, float* frame, int ldf,
+                    int32_t* pos, int B, vg_stream_t stream);
 
 /* ---------------------------------------------------------------- optimizer
  * AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias correction; reference
@@ -239,8 +248,11 @@ int vg_flow_blocks(int M);
 int vg_flow_fwd(const float* z, const float* wb, int64_t ldw, const float* params, int L, float* u,
                 float* logdet_sum, float* states, int M, float eps, float hi, float lo,
                 const int32_t* lengths, int T, vg_stream_t stream);
-int vg_flow_reverse(const float* u, const float* wb, int64_t ldw, const float* params, int L, float* z, int M,
-                    float eps, float hi, float lo, vg_stream_t stream);
+/* reverse: z rows are written with stride ldz (>= 4); with mu_ls != NULL (rows [mean(4) | logstd(4)], stride
+ * ld_mu_ls) u is unit noise and the kernel first draws mean + temperature * exp(logstd) * u. */
+int vg_flow_reverse(const float* u, const float* wb, int64_t ldw, const float* params, int L, float* z, int64_t ldz,
+                    int M, float eps, float hi, float lo, const float* mu_ls, int64_t ld_mu_ls, float temperature,
+                    vg_stream_t stream);
 int vg_flow_bwd(const float* states, const float* wb, int64_t ldw, const float* params, int L,
                 const float* du, const float* dlogdet_sum, float* dz, float* dwb, float* dparams_partial,
                 int M, float eps, float hi, float lo, const int32_t* lengths, int T, vg_stream_t stream);

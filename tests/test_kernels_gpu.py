@@ -517,6 +517,45 @@ def test_gemm_rows(F, dtype, shape):
     y = F.rows_linear(x, w, bias, act=2, residual=res)
     assert y.dtype == dtype
     torch.testing.assert_close(y.double(), torch.nn.functional.gelu(ref) + res.double(), **tol(dtype))
+    # fused RMSNorm prologue
+    g = 1 + 0.1 * rnd(K, seed=5)
+    xn = x.double() * torch.rsqrt(x.double().square().mean(-1, keepdim=True) + 1e-6) * g.double()
+    y = F.rows_linear(x, w, bias, out_f32=True, norm_scale=g, norm_eps=1e-6)
+    torch.testing.assert_close(y.double(), xn @ w.double().T + bias.double(),
+                               atol=5e-5 if dtype == torch.float32 else 5e-3, rtol=2e-4)
+
+
+def test_decode_sampling_kernels(F):
+    """vg_embed_fuse == embedding + relu(Linear); vg_sample_token draws by inverse CDF (exact index for given
+    uniforms, frame counter advanced, empirical frequencies follow softmax(logits / T))."""
+    B, V, E, Lz = 5, 200, 64, 4
+    emb, wf, bf = rnd(V, E), rnd(E, Lz, seed=1), rnd(E, seed=2)
+    frame = torch.cat([torch.tensor([[3.], [199.], [0.], [77.], [12.]], device=dev()), rnd(B, Lz, seed=3)], 1)
+    out = F.embed_fuse(frame, emb, wf, bf, torch.float32)
+    ref = emb[frame[:, 0].long()] + torch.relu(frame[:, 1:] @ wf.T + bf)
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-5)
+    logits = rnd(B, V, scale=2.0, seed=4)
+    T = 0.7
+    probs = torch.softmax(logits.double() / T, -1)
+    cdf = probs.cumsum(-1)
+    u = torch.tensor([0.0, 0.25, 0.5, 0.75, 0.999], device=dev())
+    pos = torch.zeros(B, dtype=torch.int32, device=dev())
+    fr = frame.clone()
+    F.sample_token(logits, T, u, fr, pos)
+    want = (cdf > u.double()[:, None]).float().argmax(-1)
+    got = fr[:, 0].long()
+    # allow the neighbouring id where u falls within rounding of a CDF step
+    for b in range(B):
+        assert got[b] == want[b] or abs(float(cdf[b, got[b]]) - float(u[b])) < 1e-5 or \
+            (got[b] > 0 and abs(float(cdf[b, got[b] - 1]) - float(u[b])) < 1e-5), (b, got[b], want[b])
+    assert torch.equal(pos, torch.ones_like(pos)) and torch.equal(fr[:, 1:], frame[:, 1:])
+    # distribution check on one row
+    n = 20000
+    lg = logits[:1].expand(n, V).contiguous()
+    frn = torch.zeros(n, 5, device=dev())
+    F.sample_token(lg, T, torch.rand(n, device=dev()), frn, None)
+    freq = torch.bincount(frn[:, 0].long(), minlength=V).double() / n
+    assert (freq - probs[0]).abs().max() < 0.015
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -55,6 +55,20 @@ def main():
                      ("dgrad to the hidden width (* stored GELU')", dgrad_u), ("wgrad W1 (split-K 2, atomics)", wgrad1)):
         run(name + " | same operands", [mk(0)])
         run(name + f" | rotating over {R} sets", [mk(i) for i in range(R)])
+    # tile configurations on cold operands (the heuristic in vg_gemm.hip was tuned on warm ones)
+    for cfg in (1, 2, 3, 4, 5):
+        run(f"FFN-out fwd cold, tile_cfg {cfg}", [(lambda i=i: F.gemm(hs[i], w2[i], M, D, Fd, bias=b2, residual=xs[i], out=ys[i], tile_cfg=cfg)) for i in range(R)])
+    for cfg in (1, 2, 3, 4, 5):
+        run(f"FFN-in fwd cold, tile_cfg {cfg}", [(lambda i=i: F.gemm(xs[i], w1[i], M, Fd, D, bias=b1, act=2 | 16, aux_out=us[i], out=hs[i], tile_cfg=cfg)) for i in range(R)])
+    for cfg in (1, 2, 3, 4):
+        run(f"dgrad->hidden cold, tile_cfg {cfg}", [(lambda i=i: F.gemm(ys[i], w2[i], M, Fd, D, b_tr=True, dact=4, aux_in=us[i], out=hs[i], tile_cfg=cfg)) for i in range(R)])
+    for cfg in (1, 2, 3, 4):
+        run(f"dgrad->model (K=4096) cold, tile_cfg {cfg}", [(lambda i=i: F.gemm(hs[i], w1[i], M, D, Fd, b_tr=True, out=ys[i], tile_cfg=cfg)) for i in range(R)])
+    # the same question for hipBLASLt (through torch): is the cold-operand penalty a property of this kernel?
+    run("hipBLASLt FFN-out (h @ W2^T) | same operands", [lambda: torch.matmul(hs[0], w2[0].t())])
+    run(f"hipBLASLt FFN-out (h @ W2^T) | rotating over {R} sets", [(lambda i=i: torch.matmul(hs[i], w2[i].t())) for i in range(R)])
+    run("hipBLASLt wgrad W1 (h^T @ x) | same operands", [lambda: torch.matmul(hs[0].t(), xs[0])])
+    run(f"hipBLASLt wgrad W1 (h^T @ x) | rotating over {R} sets", [(lambda i=i: torch.matmul(hs[i].t(), xs[i])) for i in range(R)])
     seq = []
     for i in range(R):
         seq += [ffn_in(i), ffn_out(i)]

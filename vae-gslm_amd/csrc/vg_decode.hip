@@ -52,15 +52,22 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
                                                                const float* __restrict__ bias,
                                                                const T* __restrict__ residual, long ldr,
                                                                void* __restrict__ y, long ldy, int M, int N, int K,
-                                                               int act, int out_f32) {
+                                                               int act, int out_f32,
+                                                               const float* __restrict__ norm_scale, float norm_eps) {
   constexpr int V = MM * RC;            // values per lane before the exchange
   constexpr int PER = V / 64;           // values per lane after it (1 for MM = 8, 2 for MM = 16)
   __shared__ float red[RMAXW][V];
+  __shared__ float ssq[RMAXW][MM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int n0 = blockIdx.x * RC;
   float v[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) v[i] = 0.f;
+  // fused RMSNorm prologue (norm_scale != null): y = act((x * rstd * g) W^T + b).  rstd is a per-row factor,
+  // so the products use x * g and rstd multiplies the finished sums; every block recomputes sum(x^2).
+  float sq[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) sq[m] = 0.f;
   for (int k0 = wave * RCHUNK + lane * 8; k0 < K; k0 += nwaves * RCHUNK) {
     float wv[RC][8];
 #pragma unroll
@@ -68,11 +75,20 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
       const int n = min(n0 + c, N - 1);
       Ld8<T>::get(w + (long)n * ldw + k0, wv[c]);
     }
+    float gv[8];
+    if (norm_scale) Ld8<float>::get(norm_scale + k0, gv);
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
       if (m < M) {
         float xv[8];
         Ld8<T>::get(x + (long)m * ldx + k0, xv);
+        if (norm_scale) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            sq[m] = fmaf(xv[e], xv[e], sq[m]);
+            xv[e] *= gv[e];
+          }
+        }
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
           float a = v[m * RC + c];
@@ -99,6 +115,13 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
   }
 #pragma unroll
   for (int j = 0; j < PER; ++j) red[wave][lane * PER + j] = v[j];
+  if (norm_scale) {
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      const float t = wave_sum(sq[m]);
+      if (lane == 0) ssq[wave][m] = t;
+    }
+  }
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
@@ -107,6 +130,11 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
       if (m < M && n < N) {
         float r = 0.f;
         for (int ww = 0; ww < nwaves; ++ww) r += red[ww][idx];
+        if (norm_scale) {
+          float ss = 0.f;
+          for (int ww = 0; ww < nwaves; ++ww) ss += ssq[ww][m];
+          r *= rsqrtf(ss / (float)K + norm_eps);
+        }
         if (bias) r += bias[n];
         if (act == VG_ACT_RELU) r = fmaxf(r, 0.f);
         else if (act == VG_ACT_GELU) r = gelu_erf(r);
@@ -191,6 +219,66 @@ __global__ __launch_bounds__(256) void attn_decode_append_kernel(const T* __rest
   }
 }
 
+// frame embedding of the step: out[b][c] = E[id_b][c] + relu(Wf[c][:] . z_b + bf[c])   (one wave per
+// sequence, lane-strided over the embedding width; models/speech/lvtr.py:161-168 fuse_inputs)
+template <typename T>
+__global__ __launch_bounds__(64) void embed_fuse_kernel(const float* __restrict__ frame, int ldf,
+                                                        const float* __restrict__ emb, int vocab, int E,
+                                                        const float* __restrict__ wf, const float* __restrict__ bf,
+                                                        int latent, T* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* fr = frame + (long)b * ldf;
+  int id = (int)fr[0];
+  id = min(max(id, 0), vocab - 1);
+  for (int c = lane; c < E; c += 64) {
+    float a = bf ? bf[c] : 0.f;
+    for (int j = 0; j < latent; ++j) a = fmaf(wf[(long)c * latent + j], fr[1 + j], a);
+    out[(long)b * E + c] = from_f32<T>(emb[(long)id * E + c] + fmaxf(a, 0.f));
+  }
+}
+
+// token draw of the step: categorical sample from softmax(logits / temperature) by inverse CDF with a
+// supplied uniform number per sequence; writes the id (as float) to frame[b][0] and advances pos[b].
+// One wave per sequence (models/speech/lvtr.py:276-284: softmax + multinomial + cat).
+__global__ __launch_bounds__(64) void sample_token_kernel(const float* __restrict__ logits, int V, float inv_temp,
+                                                          const float* __restrict__ uniform, float* __restrict__ frame,
+                                                          int ldf, int* __restrict__ pos) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* lg = logits + (long)b * V;
+  float mx = -INFINITY;
+  for (int i = lane; i < V; i += 64) mx = fmaxf(mx, lg[i] * inv_temp);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int i = lane; i < V; i += 64) sum += expf(lg[i] * inv_temp - mx);
+  sum = wave_sum(sum);
+  const float target = uniform[b] * sum;
+  // ids are visited in order in chunks of 64: inclusive prefix sums inside the chunk, running total across chunks
+  float run = 0.f;
+  int pick = V - 1;
+  bool done = false;
+  for (int base = 0; base < V && !done; base += 64) {
+    const int i = base + lane;
+    const float p = i < V ? expf(lg[i] * inv_temp - mx) : 0.f;
+    float c = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float t = __shfl_up(c, o, 64);
+      if (lane >= o) c += t;
+    }
+    const bool hit = i < V && run + c > target;
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      pick = base + __builtin_ctzll(mask);
+      done = true;
+    }
+    run += __shfl(c, 63, 64);
+  }
+  if (lane == 0) {
+    frame[(long)b * ldf] = (float)pick;
+    if (pos) pos[b] += 1;
+  }
+}
+
 __global__ void advance_kernel(int* __restrict__ pos, int n, int by) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) pos[i] += by;
@@ -198,16 +286,17 @@ __global__ void advance_kernel(int* __restrict__ pos, int n, int by) {
 
 template <typename T>
 int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* bias, const void* res, long ldr, void* y,
-                long ldy, int M, int N, int K, int act, int out_f32, hipStream_t stream) {
+                long ldy, int M, int N, int K, int act, int out_f32, const float* norm_scale, float norm_eps,
+                hipStream_t stream) {
   int nwaves = (K + RCHUNK - 1) / RCHUNK;
   if (nwaves > RMAXW) nwaves = RMAXW;
   dim3 grid((N + RC - 1) / RC), block(nwaves * 64);
   if (M <= 8)
     gemm_rows_kernel<T, 8><<<grid, block, 0, stream>>>((const T*)x, ldx, (const T*)w, ldw, bias, (const T*)res, ldr, y,
-                                                      ldy, M, N, K, act, out_f32);
+                                                      ldy, M, N, K, act, out_f32, norm_scale, norm_eps);
   else
     gemm_rows_kernel<T, 16><<<grid, block, 0, stream>>>((const T*)x, ldx, (const T*)w, ldw, bias, (const T*)res, ldr, y,
-                                                       ldy, M, N, K, act, out_f32);
+                                                       ldy, M, N, K, act, out_f32, norm_scale, norm_eps);
   return vg_host::check_launch("vg_gemm_rows");
 }
 
@@ -215,14 +304,16 @@ int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* b
 
 extern "C" int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
                             const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act,
-                            int out_f32, int dtype, hipStream_t stream) {
+                            int out_f32, const float* norm_scale, float norm_eps, int dtype, hipStream_t stream) {
   VG_REQUIRE(M >= 1 && M <= RMAXM && N >= 1 && K >= 8, "vg_gemm_rows: M=%d (1..%d) N=%d K=%d", M, RMAXM, N, K);
   VG_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "vg_gemm_rows: K, ldx, ldw must be multiples of 8");
   VG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "vg_gemm_rows: x / w must be 16-byte aligned");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_gemm_rows: bad dtype %d", dtype);
   if (dtype == VG_BF16)
-    return launch_rows<bf16_t>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, stream);
-  return launch_rows<float>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, stream);
+    return launch_rows<bf16_t>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps,
+                               stream);
+  return launch_rows<float>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps,
+                            stream);
 }
 
 extern "C" int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,
@@ -243,4 +334,22 @@ extern "C" int vg_advance(int32_t* pos, int n, int by, hipStream_t stream) {
   VG_REQUIRE(n > 0, "vg_advance: empty");
   advance_kernel<<<dim3((n + 63) / 64), dim3(64), 0, stream>>>(pos, n, by);
   return vg_host::check_launch("vg_advance");
+}
+
+extern "C" int vg_embed_fuse(const float* frame, int ldf, const float* emb, int vocab, int E, const float* wf,
+                             const float* bf, int latent, void* out, int B, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && E > 0 && vocab > 0 && latent >= 0, "vg_embed_fuse: empty problem");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_embed_fuse: bad dtype %d", dtype);
+  if (dtype == VG_BF16)
+    embed_fuse_kernel<bf16_t><<<dim3(B), dim3(64), 0, stream>>>(frame, ldf, emb, vocab, E, wf, bf, latent, (bf16_t*)out);
+  else
+    embed_fuse_kernel<float><<<dim3(B), dim3(64), 0, stream>>>(frame, ldf, emb, vocab, E, wf, bf, latent, (float*)out);
+  return vg_host::check_launch("vg_embed_fuse");
+}
+
+extern "C" int vg_sample_token(const float* logits, int V, float temperature, const float* uniform, float* frame,
+                               int ldf, int32_t* pos, int B, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && V > 0 && temperature > 0.f, "vg_sample_token: B=%d V=%d temperature=%g", B, V, temperature);
+  sample_token_kernel<<<dim3(B), dim3(64), 0, stream>>>(logits, V, 1.0f / temperature, uniform, frame, ldf, pos);
+  return vg_host::check_launch("vg_sample_token");
 }

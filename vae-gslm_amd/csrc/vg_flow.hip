@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(const float* __restrict__
 template <int LMAX>
 __global__ __launch_bounds__(256) void flow_rev_kernel(const float* __restrict__ u, const float* __restrict__ wb,
                                                        long ldw, const float* __restrict__ params, int L,
-                                                       float* __restrict__ z, int M, float eps, float hi, float lo) {
+                                                       float* __restrict__ z, long ldz, int M, float eps, float hi,
+                                                       float lo, const float* __restrict__ mu_ls, long ldm,
+                                                       float temperature) {
   const int lane = threadIdx.x & 63;
   const int stride = gridDim.x * 4;
   LaneParams q[LMAX];
@@ -122,6 +124,10 @@ __global__ __launch_bounds__(256) void flow_rev_kernel(const float* __restrict__
   for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += stride) {
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(u + 4L * m);
     float x[4] = {x0[0], x0[1], x0[2], x0[3]};
+    if (mu_ls) {      // u holds unit noise: draw from the prior head first (linear/layers.py:110-128)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) x[d] = fmaf(x[d] * temperature, expf(mu_ls[m * ldm + 4 + d]), mu_ls[m * ldm + d]);
+    }
 #pragma unroll
     for (int l = LMAX - 1; l >= 0; --l) {
       if (l < L) {
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void flow_rev_kernel(const float* __restrict__
         x[1] = o1;
       }
     }
-    if (lane == 0) *reinterpret_cast<f32x4*>(z + 4L * m) = f32x4{x[0], x[1], x[2], x[3]};
+    if (lane < 4) z[m * ldz + lane] = x[lane];
   }
 }
 
@@ -264,13 +270,15 @@ extern "C" int vg_flow_fwd(const float* z, const float* wb, int64_t ldw, const f
   return vg_host::check_launch("vg_flow_fwd");
 }
 
-extern "C" int vg_flow_reverse(const float* u, const float* wb, int64_t ldw, const float* params, int L, float* z, int M,
-                               float eps, float hi, float lo, hipStream_t stream) {
+extern "C" int vg_flow_reverse(const float* u, const float* wb, int64_t ldw, const float* params, int L, float* z,
+                               int64_t ldz, int M, float eps, float hi, float lo, const float* mu_ls, int64_t ld_mu_ls,
+                               float temperature, hipStream_t stream) {
   VG_REQUIRE(M > 0 && L > 0 && L <= FMAXL, "vg_flow_reverse: M=%d L=%d (L <= %d)", M, L, FMAXL);
   VG_REQUIRE(ldw >= 2L * FH * L, "vg_flow_reverse: FiLM row stride %ld < %d", (long)ldw, 2 * FH * L);
-  VG_REQUIRE(((uintptr_t)z % 16) == 0 && ((uintptr_t)u % 16) == 0, "vg_flow_reverse: unaligned");
+  VG_REQUIRE(((uintptr_t)u % 16) == 0 && ldz >= 4, "vg_flow_reverse: u must be 16-byte aligned, ldz >= 4");
   auto k = L <= 4 ? flow_rev_kernel<4> : flow_rev_kernel<8>;
-  k<<<dim3(flow_blocks(M)), dim3(256), 0, stream>>>(u, wb, (long)ldw, params, L, z, M, eps, hi, lo);
+  k<<<dim3(flow_blocks(M)), dim3(256), 0, stream>>>(u, wb, (long)ldw, params, L, z, (long)ldz, M, eps, hi, lo, mu_ls,
+                                                   (long)ld_mu_ls, temperature);
   return vg_host::check_launch("vg_flow_reverse");
 }
 

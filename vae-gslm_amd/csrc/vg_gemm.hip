@@ -278,10 +278,11 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
     if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048) cfg = 4;
     if (!d->a_tr && d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
     if (!d->a_tr && !d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
-    // long-K, narrow-N products (FFN down-projection, dgrad of the wide projections): their operands
-    // optional 256x128 tile with a 3-stage ring (VG_CFG_LONGK=5); measured neutral-to-slower in the full step, so off
-    static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 0; }();
-    if (!d->a_tr && d->N <= 1024 && d->K >= 2048 && d->M >= 2048 && longk > 0) cfg = longk;
+    // long-K / narrow-N forward product (FFN down-projection): 256x128 tiles with a 3-stage ring -- the
+    // deeper prefetch pays when the operands come from HBM (77 vs 86 us on cold operands,
+    // tools/gemm_rotate.py); VG_CFG_LONGK overrides (0 = keep 128x256)
+    static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
+    if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
   }
   if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, cfg, stream);
   return launch<float>(p, d->a_tr, d->b_tr, splits, -1, stream);

@@ -62,12 +62,14 @@ SIGNATURES = {
     "vg_mask_rows": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "vg_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _f, _f, _f, _i,
                  _vp, _i, _vp],
-    "vg_gemm_rows": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "vg_gemm_rows": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _f, _i, _vp],
+    "vg_embed_fuse": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "vg_sample_token": [_vp, _i, _f, _vp, _vp, _i, _vp, _i, _vp],
     "vg_attn_decode_append": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vg_advance": [_vp, _i, _i, _vp],
     "vg_flow_blocks": [_i],
     "vg_flow_fwd": [_vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _i, _vp],
-    "vg_flow_reverse": [_vp, _vp, _i64, _vp, _i, _vp, _i, _f, _f, _f, _vp],
+    "vg_flow_reverse": [_vp, _vp, _i64, _vp, _i, _vp, _i64, _i, _f, _f, _f, _vp, _i64, _f, _vp],
     "vg_flow_bwd": [_vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _i, _vp],
     "vg_dwnorm_blocks": [_i],
     "vg_dwnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],

@@ -858,21 +858,28 @@ def pack_flow_params(params) -> Tensor:
     return torch.cat([p.detach().reshape(-1).float() for p in params])
 
 
-def coupling_flow_reverse(u, wb, params, *, eps, hi, lo, packed: Optional[Tensor] = None):
+def coupling_flow_reverse(u, wb, params, *, eps, hi, lo, packed: Optional[Tensor] = None,
+                          mu_ls: Optional[Tensor] = None, temperature: float = 1.0, out: Optional[Tensor] = None):
+    """Reverse pass of the coupling stack.  With ``mu_ls`` ([M, 8] rows = mean | logstd of the prior head) ``u``
+    is unit noise and the kernel draws the Gaussian sample first; ``out`` may be a strided [M, 4] view (e.g. the
+    latent columns of the decode session's frame buffer)."""
     M = u.shape[0]
     L = len(params) // 6
     u = u.contiguous().float()
     if packed is None:
         packed = pack_flow_params(params)
-    z = torch.empty_like(u)
-    check(lib().vg_flow_reverse(ptr(u), ptr(wb), wb.stride(0), ptr(packed), L, ptr(z), M, float(eps), float(hi),
-                                float(lo), stream()), "vg_flow_reverse")
+    z = out if out is not None else torch.empty_like(u)
+    assert z.shape == (M, 4) and z.dtype == torch.float32 and z.stride(1) == 1
+    check(lib().vg_flow_reverse(ptr(u), ptr(wb), wb.stride(0), ptr(packed), L, ptr(z), z.stride(0), M, float(eps),
+                                float(hi), float(lo), ptr(mu_ls), 0 if mu_ls is None else mu_ls.stride(0),
+                                float(temperature), stream()), "vg_flow_reverse")
     return z
 
 
 # ---------------------------------------------------------------- decode step (no autograd: inference only)
 def rows_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
-                residual: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
+                residual: Optional[Tensor] = None, out_f32: bool = False, norm_scale: Optional[Tensor] = None,
+                norm_eps: float = 0.0) -> Tensor:
     """y = act(x W^T + b) + residual for a handful of rows (M <= 16): the HBM-bound Linear of the
     autoregressive step (vg_gemm_rows).  ``weight`` must already be in x's dtype (see :func:`shadow`)."""
     M, K = x.shape
@@ -882,8 +889,28 @@ def rows_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act
     b = None if bias is None else bias.detach().float()
     check(lib().vg_gemm_rows(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(b), ptr(residual),
                              0 if residual is None else residual.stride(0), ptr(y), y.stride(0), M, N, K, int(act),
-                             int(out_f32), dtype_id(x.dtype), stream()), "vg_gemm_rows")
+                             int(out_f32), ptr(norm_scale), float(norm_eps), dtype_id(x.dtype), stream()),
+          "vg_gemm_rows")
     return y
+
+
+def embed_fuse(frame: Tensor, emb: Tensor, wf: Tensor, bf: Optional[Tensor], dtype: torch.dtype) -> Tensor:
+    """frame [B, 1 + latent] fp32 (token id, z) -> E[id] + relu(Wf z + bf) as [B, E] in ``dtype``."""
+    B, E = frame.shape[0], emb.shape[1]
+    assert frame.dtype == torch.float32 and frame.stride(-1) == 1 and emb.is_contiguous() and wf.is_contiguous()
+    out = torch.empty((B, E), dtype=dtype, device=frame.device)
+    check(lib().vg_embed_fuse(ptr(frame), frame.stride(0), ptr(emb), emb.shape[0], E, ptr(wf), ptr(bf), wf.shape[1],
+                              ptr(out), B, dtype_id(dtype), stream()), "vg_embed_fuse")
+    return out
+
+
+def sample_token(logits: Tensor, temperature: float, uniform: Tensor, frame: Tensor, pos: Optional[Tensor]) -> None:
+    """frame[b, 0] <- categorical draw from softmax(logits[b] / temperature) (inverse CDF with uniform[b]);
+    pos[b] += 1 when ``pos`` is given."""
+    B, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and frame.dtype == torch.float32
+    check(lib().vg_sample_token(ptr(logits), V, float(temperature), ptr(uniform), ptr(frame), frame.stride(0), ptr(pos),
+                                B, stream()), "vg_sample_token")
 
 
 def attention_decode_append(qkv: Tensor, kcache: Tensor, vcache: Tensor, slopes: Tensor, pos: Tensor, H: int) -> Tensor:

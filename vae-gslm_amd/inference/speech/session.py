@@ -30,13 +30,14 @@ from utils.tensormask import TensorMask
 
 class DecodeSession:
     def __init__(self, model, batch_size: int, max_frames: int, *, temperature: float = 1.0,
-                 token_temperature: float = 1.0, use_graph: bool = True, device=None):
+                 token_temperature: float = 1.0, use_graph: bool = True, device=None, keep_latent: bool = False):
         if not model.use_tokens or model.transformer_flow is None:
             raise NotImplementedError("DecodeSession implements the token + flow model of vae-gslm.yaml")
         self.model = model
         self.B, self.Tmax = int(batch_size), int(max_frames)
         self.temperature, self.token_temperature = float(temperature), float(token_temperature)
         self.use_graph = bool(use_graph)
+        self.keep_latent = bool(keep_latent)
         stack = model.transformer[0]
         self.stack = stack
         self.L = len(stack.layers)
@@ -63,10 +64,11 @@ class DecodeSession:
         if not flow._hip_ok(self.frame, c=True):
             raise NotImplementedError("DecodeSession needs the vae-gslm.yaml coupling stack (vg_flow_reverse)")
         with torch.no_grad():
-            self._head_w = torch.cat([head.mean.weight, head.logstd.weight], 0).to(self.dt).contiguous()
-            self._head_b = torch.cat([head.mean.bias, head.logstd.bias], 0).float().contiguous()
-            self._film_w = torch.cat([l.film.linear.weight for l in flow.layers], 0).to(self.dt).contiguous()
-            self._film_b = torch.cat([l.film.linear.bias for l in flow.layers], 0).float().contiguous()
+            # prior head (mean | logstd) and the FiLM projections of the 4 coupling layers as ONE product
+            self._heads_w = torch.cat([head.mean.weight, head.logstd.weight] +
+                                      [l.film.linear.weight for l in flow.layers], 0).to(self.dt).contiguous()
+            self._heads_b = torch.cat([head.mean.bias, head.logstd.bias] +
+                                      [l.film.linear.bias for l in flow.layers], 0).float().contiguous()
             self._flow_params = []
             for l in flow.layers:
                 self._flow_params += [l.linear1.weight, l.linear1.bias, l.norm.weight, l.norm.bias,
@@ -103,46 +105,43 @@ class DecodeSession:
         return first.clone()
 
     # ------------------------------------------------------------------ one frame
-    def _step_body(self, noise: Optional[torch.Tensor] = None) -> None:
+    def _step_body(self, noise: Optional[torch.Tensor] = None, uniform: Optional[torch.Tensor] = None) -> None:
+        """~90 launches: frame embedding, 16 x (qkv, attention+cache append, out-proj, FFN-in, FFN-out) with the
+        RMSNorms folded into the following projection, heads, Gaussian draw + reverse flow, token draw."""
         m, dt, B = self.model, self.dt, self.B
         lat_dim = m.hp.latent_dim
-        ids = self.frame[:, 0, 0].long()
-        z_prev = self.frame[:, 0, 1:]
-        tok = m.token_embedding.weight[ids]                                        # (B, 64)
         fuser = m.token_fuser.linear
-        h = tok + torch.relu(torch.nn.functional.linear(z_prev, fuser.weight, fuser.bias))
-        x = h.to(dt)
+        frame2d = self.frame.view(B, -1)
+        x = HF.embed_fuse(frame2d, m.token_embedding.weight.detach(), fuser.weight.detach(),
+                          None if fuser.bias is None else fuser.bias.detach(), dt)
         st = self.stack
         if st.linear is not None:
             x = HF.rows_linear(x, self._w(st.linear.weight), st.linear.bias)
         for l, layer in enumerate(st.layers):
             att = layer.self_attn
-            n1, _ = HF.rmsnorm_fwd_raw(x, layer.norm1.scale.detach().float(), layer.norm1.eps, None, 0)
-            qkv = HF.rows_linear(n1, self._w(att.in_proj.weight), att.in_proj.bias)
+            qkv = HF.rows_linear(x, self._w(att.in_proj.weight), att.in_proj.bias,
+                                 norm_scale=layer.norm1.scale.detach(), norm_eps=layer.norm1.eps)
             ctx = HF.attention_decode_append(qkv, self.kc[l], self.vc[l], self.slopes, self.pos, self.H)
             x1 = HF.rows_linear(ctx, self._w(att.out_proj.weight), att.out_proj.bias, residual=x)
-            n3, _ = HF.rmsnorm_fwd_raw(x1, layer.norm3.scale.detach().float(), layer.norm3.eps, None, 0)
-            mid = HF.rows_linear(n3, self._w(layer.linear1.weight), layer.linear1.bias, act=hipvg.ACT_GELU)
+            mid = HF.rows_linear(x1, self._w(layer.linear1.weight), layer.linear1.bias, act=hipvg.ACT_GELU,
+                                 norm_scale=layer.norm3.scale.detach(), norm_eps=layer.norm3.eps)
             x = HF.rows_linear(mid, self._w(layer.linear2.weight), layer.linear2.bias, residual=x1)
-        lat, _ = HF.rmsnorm_fwd_raw(x, st.final_norm.scale.detach().float(), st.final_norm.eps, None, 0)
-        qs = m.q_spliter.linear
-        cond = HF.rows_linear(lat, self._w(qs.weight), qs.bias, act=hipvg.ACT_RELU)
-        mu_ls = HF.rows_linear(cond, self._head_w, self._head_b, out_f32=True)      # (B, 2 latent)
+        fn = dict(norm_scale=st.final_norm.scale.detach(), norm_eps=st.final_norm.eps)
+        qs, ts, tp = m.q_spliter.linear, m.token_spliter.linear, m.token_predictor.linear
+        cond = HF.rows_linear(x, self._w(qs.weight), qs.bias, act=hipvg.ACT_RELU, **fn)
+        heads = HF.rows_linear(cond, self._heads_w, self._heads_b, out_f32=True)    # (B, 2 latent + L*128): prior | FiLM
+        mu_ls, wb = heads[:, :2 * lat_dim], heads[:, 2 * lat_dim:]
         eps = noise if noise is not None else torch.randn(B, lat_dim, device=self.dev)
-        z, _ = HF.reparameterize(mu_ls[:, :lat_dim].contiguous(), mu_ls[:, lat_dim:].contiguous(),
-                                 eps.reshape(B, lat_dim).contiguous(), self.temperature)
-        wb = HF.rows_linear(cond, self._film_w, self._film_b, out_f32=True)        # FiLM rows of the 4 coupling layers
-        z = HF.coupling_flow_reverse(z, wb, self._flow_params, packed=self._flow_packed, **self._flow_kw)
-        ts, tp = m.token_spliter.linear, m.token_predictor.linear
-        hid = HF.rows_linear(lat, self._w(ts.weight), ts.bias, act=hipvg.ACT_RELU)
+        HF.coupling_flow_reverse(eps.reshape(B, lat_dim), wb, self._flow_params, packed=self._flow_packed,
+                                 mu_ls=mu_ls, temperature=self.temperature, out=frame2d[:, 1:], **self._flow_kw)
+        hid = HF.rows_linear(x, self._w(ts.weight), ts.bias, act=hipvg.ACT_RELU, **fn)
         logits = HF.rows_linear(hid, self._w(tp.weight), tp.bias, out_f32=True)      # (B, vocab)
-        probs = torch.softmax(logits / self.token_temperature, dim=-1)
-        picked = torch.multinomial(probs, 1).float()
-        self.frame[:, 0, :1] = picked
-        self.frame[:, 0, 1:] = z.float()
-        HF.advance(self.pos, 1)
-        self._last = {"transformer_latent": lat.view(B, 1, -1), "logits": logits.view(B, 1, -1),
-                      "mu_ls": mu_ls.view(B, 1, -1)}
+        u01 = uniform if uniform is not None else torch.rand(B, device=self.dev)
+        HF.sample_token(logits, self.token_temperature, u01, frame2d, self.pos)      # also pos += 1
+        self._last = {"logits": logits.view(B, 1, -1), "mu_ls": heads[:, None, :2 * lat_dim], "hidden": x}
+        if self.keep_latent:      # the normalised state itself is only needed by tests / callers that ask for it
+            lat, _ = HF.rmsnorm_fwd_raw(x, st.final_norm.scale.detach().float(), st.final_norm.eps, None, 0)
+            self._last["transformer_latent"] = lat.view(B, 1, -1)
 
     @torch.no_grad()
     def step(self, noise: Optional[torch.Tensor] = None) -> torch.Tensor:

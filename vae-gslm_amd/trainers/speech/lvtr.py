@@ -192,8 +192,18 @@ class LVTRTrainer(BaseTrainer):
                 import hipvg
                 hipvg.prof_enable(True)                # event-record nodes become part of the graph
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
+            try:
+                with torch.cuda.graph(graph):
+                    out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
+            except Exception as exc:      # e.g. another library touching the device mid-capture: run eagerly instead
+                import warnings
+                warnings.warn(f"hipGraph capture of the micro-step failed ({exc!r}); continuing with eager launches")
+                self.use_graph = False
+                torch.cuda.synchronize()
+                if self.reducer is not None:
+                    self.reducer.zero_grad()
+                    self.reducer.sync_now = last
+                return self._training_loop(batch, batch_idx, None)
             if self.reducer is not None:
                 self.reducer.zero_grad()               # capture does not execute; start from clean buckets
             ent = self._graphs[key] = (graph, static, out)
