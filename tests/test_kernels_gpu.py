@@ -43,10 +43,11 @@ def row_mask(lengths, T):
 # ------------------------------------------------------------------ MFMA operand maps (exact integers)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
-def test_gemm_exact_small_integers(F, dtype, mode):
+@pytest.mark.parametrize("K", [192, 80, 200])      # reduction length: whole 64-tiles, shorter than one, a ragged tail
+def test_gemm_exact_small_integers(F, dtype, mode, K):
     """Asymmetric small-integer operands: any row/col or k-permutation error in
-    the fragment maps changes the (exactly representable) result."""
-    M, N, K = 200, 136, 192
+    the fragment maps (or a K tail that is not zero-filled) changes the exactly representable result."""
+    M, N = 200, 136
     g = torch.Generator().manual_seed(5)
     A = torch.randint(-3, 4, (M, K), generator=g).float()
     B = torch.randint(-3, 4, (N, K), generator=g).float()

@@ -266,10 +266,11 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   p.k_per_split = kps;
   // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
   int cfg = d->tile_cfg;
-  // K tails: fine when both operands are k-major (rows past K are zero-filled by the buffer range check)
-  const bool dma_ok = d->dtype == VG_BF16 && (d->K % 64 == 0 || (d->a_tr && d->b_tr)) && !(d->a_tr && !d->b_tr) &&
-                      (long)(d->a_tr ? d->K : d->M) * d->lda * 2 < 0x7fffffffL &&
-                      (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7fffffffL;
+  // K tails are zero-filled by the DMA (rows past K of a k-major operand, 16-byte chunks past the row end of a
+  // k-contiguous one), so any K that keeps the 16-byte chunks whole qualifies
+  const bool dma_ok = d->dtype == VG_BF16 && (d->K % 8 == 0 || (d->a_tr && d->b_tr)) && !(d->a_tr && !d->b_tr) &&
+                      (long)(d->a_tr ? d->K : d->M) * d->lda * 2 < 0x7ffffff0L &&
+                      (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7ffffff0L;
   if (!dma_ok) cfg = -1;
   else if (cfg == 0) {
     // measured on MI355X at M = 8000 (tools/gemm_bench.py): 128x128 wins or ties everywhere except

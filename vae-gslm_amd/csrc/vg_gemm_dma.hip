@@ -25,7 +25,8 @@ constexpr int BK = 64;
 //  TR  image: R/128 sub-images of [64 krows][256 B]; 64-B granule position g of krow k holds
 //             source granule g ^ (k & 3), its 32-B halves swapped when bit 3 of k is set
 template <bool TR, int R, int NW>
-VG_DEVICE void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, long ld_bytes, int rc0, int k0, int wave, int lane) {
+VG_DEVICE void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, long ld_bytes, int rc0, int k0, int wave, int lane,
+                        int klim) {
   constexpr int PER_WAVE = (R / 8) / NW;
   static_assert(PER_WAVE >= 1, "tile too small for the wave count");
 #pragma unroll
@@ -36,6 +37,9 @@ VG_DEVICE void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, long ld_bytes, 
       const int row = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       voff = (unsigned)((long)(rc0 + row) * ld_bytes + (long)(k0 + chunk * 8) * 2);
+      // K tail of a k-contiguous operand: chunks past the end of the row would read the next row, so they
+      // are pointed past the end of the buffer instead (the range check writes zeros into LDS)
+      if (k0 + chunk * 8 >= klim) voff = 0x7ffffff0u;
     } else {
       const int sub = piece >> 4;              // 128-column sub-image
       const int krow = (piece & 15) * 4 + (lane >> 4);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
 
   const int kbeg = blockIdx.z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nkt = (kend - kbeg + BK - 1) / BK;   // a K tail only occurs with both operands k-major (zero-filled rows)
+  const int nkt = (kend - kbeg + BK - 1) / BK;   // K tails are zero-filled (rows past K, or chunks past a row's end)
 
   // buffer descriptors: the hardware range check zero-fills rows past the end of each operand
   const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   // ring of STAGES LDS stages: tiles kt .. kt+STAGES-2 are in flight while tile kt is consumed
   auto issue = [&](int kt) {
     char* st = smem + (kt % STAGES) * STAGE;
-    dma_tile<A_TR, BM, NW>(ra, st, lda_b, m0, kbeg + kt * BK, wave, lane);
-    dma_tile<B_TR, BN, NW>(rb, st + A_BYTES, ldb_b, n0, kbeg + kt * BK, wave, lane);
+    dma_tile<A_TR, BM, NW>(ra, st, lda_b, m0, kbeg + kt * BK, wave, lane, kend);
+    dma_tile<B_TR, BN, NW>(rb, st + A_BYTES, ldb_b, n0, kbeg + kt * BK, wave, lane, kend);
   };
 #pragma unroll
   for (int s0 = 0; s0 < STAGES - 1; ++s0)
