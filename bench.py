@@ -121,7 +121,8 @@ def main():
     trainer.configure_optimizers()
     trainer.attach_reducer()
     trainer.global_step = hp.training.scheduler.warmup_kld      # past the KL warm-up
-    trainer.profile_in_graph = bool(args.graph)                 # HIP-event pairs captured with the kernels
+    # event pairs captured into the graph do not report on replay (and cost graph nodes): off unless asked for
+    trainer.profile_in_graph = bool(args.graph) and os.environ.get("VG_PROF_IN_GRAPH", "0") == "1"
     B = hp.data.train.batch_size
     accum = trainer.gradient_update_step
     n_micro = (args.steps + args.warmup) * accum

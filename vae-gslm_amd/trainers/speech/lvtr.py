@@ -162,6 +162,26 @@ class LVTRTrainer(BaseTrainer):
         return out
 
     # ------------------------------------------------------------ hipGraph replay of a micro-step
+    def _pad_for_graph(self, batch: Mapping) -> Mapping:
+        """Real batches have a different number of frames every step; one graph per length would mean a capture
+        per step.  Ragged batches are therefore right-padded (masked frames, which every kernel already skips)
+        to the next multiple of ``hip.graph_pad_frames`` (default 64), so at most maxT/64 graphs exist; they share
+        one memory pool because only one replays at a time."""
+        hip = self.hp.get("hip", None)
+        mult = int(hip.get("graph_pad_frames", 64)) if hip is not None else 64
+        from utils.tensormask import TensorMask
+        out = dict(batch)
+        for k in ("tokens", "mel"):
+            v = batch.get(k)
+            if v is None or getattr(v.mask, "_vg_full", False) or mult <= 1:
+                continue
+            T = v.value.shape[1]
+            pad = (-T) % mult
+            if pad:
+                val = torch.nn.functional.pad(v.value, (0, 0) * (v.value.dim() - 2) + (0, pad))
+                out[k] = TensorMask(val, torch.nn.functional.pad(v.mask, (0, pad)))
+        return out
+
     def _graphed_micro_step(self, batch: Mapping, batch_idx: int, last: bool):
         """Forward + backward of one micro-batch captured once per input shape into a hipGraph
         and replayed afterwards: ~2,700 kernel launches per micro-batch become one graph launch,
@@ -169,6 +189,7 @@ class LVTRTrainer(BaseTrainer):
         during warm-up), inputs are copied into static buffers, gradients accumulate into the
         reducer's static buckets.  With N > 1 ranks the bucket all-reduces are issued after the
         last replay of the window (bulk, not overlapped with backward)."""
+        batch = self._pad_for_graph(batch)
         key = tuple((k, tuple(v.value.shape), getattr(v.mask, "_vg_full", False)) for k, v in sorted(batch.items()))
         dev = batch["mel"].value.device
         if self._kw_dev is None:
@@ -192,8 +213,10 @@ class LVTRTrainer(BaseTrainer):
                 import hipvg
                 hipvg.prof_enable(True)                # event-record nodes become part of the graph
             graph = torch.cuda.CUDAGraph()
+            if getattr(self, "_graph_pool", None) is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, pool=self._graph_pool):
                     out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
             except Exception as exc:      # e.g. another library touching the device mid-capture: run eagerly instead
                 import warnings
