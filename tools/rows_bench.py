@@ -58,6 +58,23 @@ def main():
         report(f"colsum partial [{nb}x{C}] f32", t, nb * C * 4)
         t = timeit(lambda: L.vg_colsum(p(dy), M, C, C, p(ws), p(out), 1, 1, st))
         report(f"colsum [{M}x{C}] bf16", t, M * C * 2)
+    # depthwise conv (7 taps, causal) + channel norm of the posterior encoder / UNet blocks, C = 512
+    C, taps = 512, 7
+    x = torch.randn(M, C, device=dev).bfloat16()
+    dy = torch.randn(M, C, device=dev).bfloat16()
+    w = torch.randn(C, taps, device=dev) * 0.3
+    cb, gamma, beta = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+    te = torch.randn(8, C, device=dev) * 0.1
+    y, du, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    nbk = L.vg_dwnorm_blocks(M)
+    npart, wpart = torch.empty(nbk, 2 * C, device=dev), torch.empty(nbk, C * taps, device=dev)
+    t = timeit(lambda: L.vg_dwnorm_fwd(p(x), p(w), p(cb), p(te), p(gamma), p(beta), p(y), p(mean), p(rstd), M, C, T,
+                                       taps, taps - 1, 1e-5, 1, st))
+    report("dwnorm_fwd C=512 k=7", t, 2 * M * C * 2)
+    t = timeit(lambda: L.vg_dwnorm_bwd(p(dy), p(x), p(w), p(cb), p(te), p(gamma), p(mean), p(rstd), p(x), p(du), p(dx),
+                                       p(npart), p(wpart), M, C, T, taps, taps - 1, 1, st))
+    report("dwnorm_bwd (norm + conv) C=512 k=7", t, 7 * M * C * 2)
     C = 4096
     dy = torch.randn(M, C, device=dev).bfloat16()
     out = torch.zeros(C, dtype=torch.float32, device=dev)

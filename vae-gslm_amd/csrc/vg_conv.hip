@@ -33,6 +33,12 @@ template <> struct V8<float> {
     f32x4 v = {o[0], o[1], o[2], o[3]};
     *reinterpret_cast<f32x4*>(p) = v;
   }
+  // the 16 bytes as loaded (kept packed while several rows are in flight) and their expansion
+  static VG_DEVICE uint4 raw(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+  static VG_DEVICE void expand(const uint4& r, float (&o)[8]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(&r);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
 };
 template <> struct V8<bf16_t> {
   static constexpr int N = 8;
@@ -47,6 +53,12 @@ template <> struct V8<bf16_t> {
     for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
     *reinterpret_cast<bf16x8*>(p) = v;
   }
+  static VG_DEVICE uint4 raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static VG_DEVICE void expand(const uint4& r, float (&o)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
 };
 
 struct DwArgs {
@@ -54,55 +66,114 @@ struct DwArgs {
   float eps;
 };
 
+// The frame-invariant parameters (taps x C weights, conv bias, norm affine) reach the lanes through LDS: one
+// coalesced copy per block instead of ~80 strided scalar loads per lane (which cost more L2 traffic than the
+// activations themselves once a launch has a thousand blocks).
+constexpr int MAXC = 1024;
+struct ParamLds {
+  float w[MAXC * MAXTAPS];
+  float cb[MAXC], gamma[MAXC], beta[MAXC];
+};
+VG_DEVICE void stage_params(ParamLds& P, const float* __restrict__ w, const float* __restrict__ cbias,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, const DwArgs& a) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < a.C * a.taps; i += nt) P.w[i] = w[i];
+  for (int i = tid; i < a.C; i += nt) {
+    P.cb[i] = (cbias && a.taps > 0) ? cbias[i] : 0.f;
+    P.gamma[i] = gamma ? gamma[i] : 1.f;
+    P.beta[i] = beta ? beta[i] : 0.f;
+  }
+  __syncthreads();
+}
+
 // frame-invariant per-lane parameters (NV 16-byte channel vectors per lane)
 template <typename T, int NV> struct LaneParams {
   float w[NV][MAXTAPS][V8<T>::N];
   float cb[NV][V8<T>::N];
-  VG_DEVICE void load(const float* __restrict__ wsrc, const float* __restrict__ cbias, const DwArgs& a, int lane) {
+  VG_DEVICE void load(const ParamLds& P, const DwArgs& a, int lane) {
     constexpr int N = V8<T>::N;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
 #pragma unroll
       for (int e = 0; e < N; ++e) {
-        cb[i][e] = (cbias && a.taps > 0) ? cbias[c * N + e] : 0.f;
+        cb[i][e] = P.cb[c * N + e];
 #pragma unroll
-        for (int k = 0; k < MAXTAPS; ++k) w[i][k][e] = (k < a.taps) ? wsrc[(c * N + e) * a.taps + k] : 0.f;
+        for (int k = 0; k < MAXTAPS; ++k) w[i][k][e] = (k < a.taps) ? P.w[(c * N + e) * a.taps + k] : 0.f;
       }
     }
   }
 };
 
-// v = conv(x)[row] + cbias + temb[b]   for this lane's channels (taps == 0: v = x[row])
+// v = conv(x)[row] + cbias + temb[b]   for this lane's channels (taps == 0: v = x[row]), in two phases so that
+// a kernel can request the rows of its NEXT frame before it reduces the current one:
+//   conv_row_issue : all tap rows as packed 16-byte registers (clamped addresses: one memory latency per
+//                    frame, not one per tap) + the time-embedding vector
+//   conv_row_finish: expansion, 0/1 masks for taps outside the sequence, FMAs
+template <typename T, int NV> struct RowRaw {
+  uint4 x[NV][MAXTAPS];
+  float te[NV][8];
+};
+
 template <typename T, int NV>
-VG_DEVICE void conv_row(const T* __restrict__ x, const LaneParams<T, NV>& lp, const float* __restrict__ temb,
-                        const DwArgs& a, int row, int lane, float (&v)[NV][8]) {
+VG_DEVICE void conv_row_issue(const T* __restrict__ x, const float* __restrict__ temb, const DwArgs& a, int row,
+                              int lane, RowRaw<T, NV>& r) {
   constexpr int N = V8<T>::N;
   const int b = row / a.Tn, t = row - b * a.Tn;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (a.taps == 0) {
-      V8<T>::load(x + (long)row * a.C + c * N, v[i]);
+      r.x[i][0] = V8<T>::raw(x + (long)row * a.C + c * N);
       continue;
     }
 #pragma unroll
-    for (int e = 0; e < N; ++e) v[i][e] = lp.cb[i][e];
+    for (int k = 0; k < MAXTAPS; ++k) {
+      if (k < a.taps) {
+        const int ts = min(max(t + k - a.shift, 0), a.Tn - 1);
+        r.x[i][k] = V8<T>::raw(x + ((long)b * a.Tn + ts) * a.C + c * N);
+      }
+    }
     if (temb) {
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[i][e] += temb[(long)b * a.C + c * N + e];
+      for (int e = 0; e < N; ++e) r.te[i][e] = temb[(long)b * a.C + c * N + e];
+    }
+  }
+}
+
+template <typename T, int NV>
+VG_DEVICE void conv_row_finish(const RowRaw<T, NV>& r, const LaneParams<T, NV>& lp, bool has_temb, const DwArgs& a,
+                               int row, float (&v)[NV][8]) {
+  constexpr int N = V8<T>::N;
+  const int b = row / a.Tn, t = row - b * a.Tn;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (a.taps == 0) {
+      V8<T>::expand(r.x[i][0], v[i]);
+      continue;
     }
 #pragma unroll
-    for (int k = 0; k < MAXTAPS; ++k) {
-      const int ts = t + k - a.shift;
-      if (k < a.taps && ts >= 0 && ts < a.Tn) {
-        float xv[8];
-        V8<T>::load(x + ((long)b * a.Tn + ts) * a.C + c * N, xv);
+    for (int e = 0; e < N; ++e) v[i][e] = lp.cb[i][e] + (has_temb ? r.te[i][e] : 0.f);
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[i][e] = fmaf(lp.w[i][k][e], xv[e], v[i][e]);
+    for (int k = 0; k < MAXTAPS; ++k) {
+      if (k < a.taps) {
+        const int ts = t + k - a.shift;
+        const float on = (ts >= 0 && ts < a.Tn) ? 1.f : 0.f;
+        float xv[8];
+        V8<T>::expand(r.x[i][k], xv);
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[i][e] = fmaf(lp.w[i][k][e] * on, xv[e], v[i][e]);
       }
     }
   }
+}
+
+template <typename T, int NV>
+VG_DEVICE void conv_row(const T* __restrict__ x, const LaneParams<T, NV>& lp, const float* __restrict__ temb,
+                        const DwArgs& a, int row, int lane, float (&v)[NV][8]) {
+  RowRaw<T, NV> r;
+  conv_row_issue<T, NV>(x, temb, a, row, lane, r);
+  conv_row_finish<T, NV>(r, lp, temb != nullptr, a, row, v);
 }
 
 template <typename T, int NV>
@@ -115,19 +186,27 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_kernel(const T* __restrict__ x
                                                          DwArgs a) {
   constexpr int N = V8<T>::N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ ParamLds P;
+  stage_params(P, w, cbias, gamma, beta, a);
   LaneParams<T, NV> lp;
-  lp.load(w, cbias, a, lane);
+  lp.load(P, a, lane);
   float gm[NV][N], bt[NV][N];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      gm[i][e] = gamma[(lane + 64 * i) * N + e];
-      bt[i][e] = beta[(lane + 64 * i) * N + e];
+      gm[i][e] = P.gamma[(lane + 64 * i) * N + e];
+      bt[i][e] = P.beta[(lane + 64 * i) * N + e];
     }
-  for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  RowRaw<T, NV> cur, nxt;
+  if (row < a.M) conv_row_issue<T, NV>(x, temb, a, row, lane, cur);
+  for (; row < a.M; row += stride) {
+    if (row + stride < a.M) conv_row_issue<T, NV>(x, temb, a, row + stride, lane, nxt);   // next frame's rows in flight
     float v[NV][8];
-    conv_row<T, NV>(x, lp, temb, a, row, lane, v);
+    conv_row_finish<T, NV>(cur, lp, temb != nullptr, a, row, v);
+    cur = nxt;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -165,14 +244,16 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_kernel(const T* __restric
   constexpr int N = V8<T>::N;
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ ParamLds P;
+  stage_params(P, w, cbias, gamma, nullptr, a);
   LaneParams<T, NV> lp;
-  lp.load(w, cbias, a, lane);
+  lp.load(P, a, lane);
   float gm[NV][N], sg[NV][N], sb[NV][N];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      gm[i][e] = gamma[(lane + 64 * i) * N + e];
+      gm[i][e] = P.gamma[(lane + 64 * i) * N + e];
       sg[i][e] = sb[i][e] = 0.f;
     }
   for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
@@ -235,8 +316,10 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_kernel(const T* __restric
   constexpr int N = V8<T>::N;
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ ParamLds P;
+  stage_params(P, w, nullptr, nullptr, nullptr, a);
   LaneParams<T, NV> lp;
-  lp.load(w, nullptr, a, lane);
+  lp.load(P, a, lane);
   float gw[NV][MAXTAPS][N];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -256,21 +339,30 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_kernel(const T* __restric
         for (int e = 0; e < N; ++e) o[e] = 0.f;
       }
       V8<T>::load(du + (long)row * a.C + c * N, duv);
+      // request every neighbour row first (clamped addresses), then accumulate with 0/1 masks
+      uint4 dr[MAXTAPS], xr[MAXTAPS];
 #pragma unroll
       for (int k = 0; k < MAXTAPS; ++k) {
-        const int td = t - (k - a.shift);     // output frame whose tap k read input frame t
-        if (k < a.taps && td >= 0 && td < a.Tn) {
-          float dv[8];
-          V8<T>::load(du + ((long)b * a.Tn + td) * a.C + c * N, dv);
-#pragma unroll
-          for (int e = 0; e < N; ++e) o[e] = fmaf(lp.w[i][k][e], dv[e], o[e]);
+        if (k < a.taps) {
+          const int td = min(max(t - (k - a.shift), 0), a.Tn - 1);   // output frame whose tap k read input frame t
+          const int ts = min(max(t + k - a.shift, 0), a.Tn - 1);     // input frame tap k of output frame t reads
+          dr[k] = V8<T>::raw(du + ((long)b * a.Tn + td) * a.C + c * N);
+          xr[k] = V8<T>::raw(x + ((long)b * a.Tn + ts) * a.C + c * N);
         }
-        const int ts = t + k - a.shift;       // input frame tap k of output frame t reads
-        if (k < a.taps && ts >= 0 && ts < a.Tn) {
-          float xv[8];
-          V8<T>::load(x + ((long)b * a.Tn + ts) * a.C + c * N, xv);
+      }
 #pragma unroll
-          for (int e = 0; e < N; ++e) gw[i][k][e] = fmaf(duv[e], xv[e], gw[i][k][e]);
+      for (int k = 0; k < MAXTAPS; ++k) {
+        if (k < a.taps) {
+          const int td = t - (k - a.shift), ts = t + k - a.shift;
+          const float on_d = (td >= 0 && td < a.Tn) ? 1.f : 0.f, on_s = (ts >= 0 && ts < a.Tn) ? 1.f : 0.f;
+          float dv[8], xv[8];
+          V8<T>::expand(dr[k], dv);
+          V8<T>::expand(xr[k], xv);
+#pragma unroll
+          for (int e = 0; e < N; ++e) {
+            o[e] = fmaf(lp.w[i][k][e] * on_d, dv[e], o[e]);
+            gw[i][k][e] = fmaf(duv[e] * on_s, xv[e], gw[i][k][e]);
+          }
         }
       }
       V8<T>::store(dx + (long)row * a.C + c * N, o);
@@ -302,7 +394,7 @@ int check_shape(const char* who, int M, int C, int T, int taps, int dtype) {
   const int n = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "%s: bad dtype %d", who, dtype);
   VG_REQUIRE(M > 0 && T > 0 && M % T == 0, "%s: M=%d must be a multiple of T=%d", who, M, T);
-  VG_REQUIRE(C % (64 * n) == 0 && C / (64 * n) <= 2, "%s: C=%d unsupported (multiple of %d, at most %d)", who, C,
+  VG_REQUIRE(C <= MAXC && C % (64 * n) == 0 && C / (64 * n) <= 2, "%s: C=%d unsupported (multiple of %d, at most %d)", who, C,
              64 * n, 128 * n);
   VG_REQUIRE(taps >= 0 && taps <= MAXTAPS, "%s: taps=%d unsupported", who, taps);
   return 0;
@@ -337,7 +429,8 @@ extern "C" int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, 
                              int T, int taps, int shift, float eps, int dtype, hipStream_t stream) {
   if (int e = check_shape("vg_dwnorm_fwd", M, C, T, taps, dtype)) return e;
   DwArgs a{M, C, T, taps, shift, eps};
-  const int nb = min((M + 3) / 4, 1024);
+  static const int nb_env = [] { const char* e = getenv("VG_DW_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int nb = min((M + 3) / 4, nb_env > 0 ? nb_env : 1024);
   const int nv = C / (64 * (dtype == VG_BF16 ? 8 : 4));
   if (dtype == VG_BF16) {
     if (nv == 1) launch_fwd<bf16_t, 1>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
