@@ -81,8 +81,13 @@ typedef struct vg_gemm_desc {
   int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..5 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 / 256x128 with a 3-stage ring */
   float* colsum_out;    /* a_tr = b_tr = 1 only (weight gradient dY^T X): colsum_out[m] += sum_k A(m,k), i.e. the bias
                            gradient of the same Linear (modules/linear/layers.py:192) from the tiles already in LDS; NULL = off */
+  float* colpart;       /* [ceil(M / vg_gemm_tile_rows(desc))][N] fp32 or NULL: per-row-tile column sums of the stored result
+                           (the dgrad that writes a Linear's input gradient also reduces it for the bias gradient of
+                           the layer below); bf16 LDS-DMA path, split_k == 1 only */
 } vg_gemm_desc;
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
+/* rows per output tile the launch for `desc` will use (128 or 256), 0 if it takes the register-staged kernel */
+int vg_gemm_tile_rows(const vg_gemm_desc* desc);
 
 /* ---------------------------------------------------------------- RMSNorm
  * modules/norm.py:28-32 fused with the re-mask of

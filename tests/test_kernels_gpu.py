@@ -99,6 +99,16 @@ def test_gemm_epilogues(F, dtype):
         torch.testing.assert_close(deriv.double(), ud.grad, **tol(dtype))
         dx = F.gemm(dy, w, M, K, N, b_tr=True, dact=4, aux_in=wide)
         torch.testing.assert_close(dx.double(), (dy.double() @ w.double()) * wide.double(), **tol(dtype))
+    # per-row-tile column sums of the stored result from the same launch (bf16 LDS-DMA path only)
+    parts = []
+    dx = F.gemm(dy, w, M, K, N, b_tr=True, dact=4, aux_in=wide, lengths=lens, T=T, colpart=parts)
+    if dtype == torch.bfloat16:
+        assert parts[0] is not None and parts[0].shape[1] == K
+        torch.testing.assert_close(parts[0].sum(0).double(), torch.where(mask, (dy.double() @ w.double()) * wide.double(), 0.0).sum(0),
+                                   atol=0.15, rtol=2e-2)
+        torch.testing.assert_close(parts[0].sum(0), dx.float().sum(0), atol=0.15, rtol=2e-2)
+    else:
+        assert parts == [None]
     # wgrad, split-K (atomic) and single pass agree with the reference
     for s in (1, 3):
         dW = F.gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=s)

@@ -234,6 +234,39 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
 
 }  // namespace
 
+namespace {
+// tile configuration the bf16 LDS-DMA path will use for this problem (-1: register-staged kernel)
+int pick_cfg(const vg_gemm_desc* d) {
+  int cfg = d->tile_cfg;
+  // K tails are zero-filled by the DMA (rows past K of a k-major operand, 16-byte chunks past the row end of a
+  // k-contiguous one), so any K that keeps the 16-byte chunks whole qualifies
+  const bool dma_ok = d->dtype == VG_BF16 && (d->K % 8 == 0 || (d->a_tr && d->b_tr)) && !(d->a_tr && !d->b_tr) &&
+                      (long)(d->a_tr ? d->K : d->M) * d->lda * 2 < 0x7ffffff0L &&
+                      (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7ffffff0L;
+  if (!dma_ok) return -1;
+  if (cfg != 0) return cfg;
+  // measured on MI355X at M = 8000 (tools/gemm_bench.py, tools/gemm_rotate.py): 128x128 wins or ties
+  // everywhere except the wide-N forward / dgrad products (256x256) and the long-K / narrow-N forward
+  // product (FFN down-projection: 256x128 with a 3-stage ring, whose deeper prefetch pays on operands that
+  // come from HBM; VG_CFG_LONGK overrides, 0 = 128x256)
+  cfg = 1;
+  if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048) cfg = 4;
+  if (!d->a_tr && d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
+  if (!d->a_tr && !d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
+  static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
+  if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
+  if (d->a_tr && d->b_tr && d->colsum_out) cfg = 1;
+  return cfg;
+}
+int cfg_tile_rows(int cfg) { return (cfg == 2 || cfg == 3 || cfg == 5) ? 256 : 128; }
+}  // namespace
+
+extern "C" int vg_gemm_tile_rows(const vg_gemm_desc* d) {
+  if (d == nullptr) return 0;
+  const int cfg = pick_cfg(d);
+  return cfg > 0 ? cfg_tile_rows(cfg) : 0;
+}
+
 extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   VG_REQUIRE(d != nullptr, "vg_gemm: null descriptor");
   VG_REQUIRE(d->dtype == VG_F32 || d->dtype == VG_BF16, "vg_gemm: bad dtype %d", d->dtype);
@@ -265,26 +298,10 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   splits = (d->K + kps - 1) / kps;
   p.k_per_split = kps;
   // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
-  int cfg = d->tile_cfg;
-  // K tails are zero-filled by the DMA (rows past K of a k-major operand, 16-byte chunks past the row end of a
-  // k-contiguous one), so any K that keeps the 16-byte chunks whole qualifies
-  const bool dma_ok = d->dtype == VG_BF16 && (d->K % 8 == 0 || (d->a_tr && d->b_tr)) && !(d->a_tr && !d->b_tr) &&
-                      (long)(d->a_tr ? d->K : d->M) * d->lda * 2 < 0x7ffffff0L &&
-                      (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7ffffff0L;
-  if (!dma_ok) cfg = -1;
-  else if (cfg == 0) {
-    // measured on MI355X at M = 8000 (tools/gemm_bench.py): 128x128 wins or ties everywhere except
-    // the long-K / narrow-N forward GEMM (128x256) and the wide-N dgrad (256x256)
-    cfg = 1;
-    if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048) cfg = 4;
-    if (!d->a_tr && d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
-    if (!d->a_tr && !d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
-    // long-K / narrow-N forward product (FFN down-projection): 256x128 tiles with a 3-stage ring -- the
-    // deeper prefetch pays when the operands come from HBM (77 vs 86 us on cold operands,
-    // tools/gemm_rotate.py); VG_CFG_LONGK overrides (0 = keep 128x256)
-    static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
-    if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
-  }
+  const int cfg = pick_cfg(d);
+  p.colpart = d->colpart;
+  VG_REQUIRE(d->colpart == nullptr || (cfg > 0 && splits == 1),
+             "vg_gemm: colpart needs the bf16 LDS-DMA path without split-K (ask vg_gemm_tile_rows first)");
   if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, cfg, stream);
   return launch<float>(p, d->a_tr, d->b_tr, splits, -1, stream);
 }

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   }
   __syncthreads();                         // every wave is done reading the last stage
   float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
+  float cp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of this lane's 8 columns (colpart)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -330,6 +331,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
         if (m >= p.M || n >= p.N) continue;
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         epilogue_emit(p, false, m, n, v);
+        if (p.colpart) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cp[e] += v[e];
+        }
+      }
+    }
+  }
+  // colpart: column sums of the tile's stored values -> colpart[m-tile][n].  Lanes that share a column
+  // chunk are folded by shuffles, the WM waves of a column panel through LDS (the strips are free now).
+  if (p.colpart && !split) {
+    constexpr int CPR = WCOLS / 8;
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cp[e] += __shfl_xor(cp[e], o, 64);
+    __syncthreads();
+    float* cred = reinterpret_cast<float*>(smem);          // [NW][WCOLS]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cred[wave * WCOLS + lane * 8 + e] = cp[e];
+    }
+    __syncthreads();
+    if (wm == 0 && lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WM; ++w2) t += cred[(w2 * WN + wn) * WCOLS + lane * 8 + e];
+        const int n = n0 + bcol + lane * 8 + e;
+        if (n < p.N) p.colpart[(long)(m0 / BM) * p.N + n] = t;
       }
     }
   }

@@ -19,6 +19,8 @@ struct GemmParams {
   int k_per_split;          // K range handled by one blockIdx.z (multiple of BK)
   float alpha;
   float* colsum_out;        // TN mode: [M] fp32, += sum_k A(m,k) (unscaled), or null
+  float* colpart;           // [tiles_m][N] fp32: per-m-tile column sums of the stored result (bias gradient of the
+                            // NEXT layer's Linear produced by the dgrad that writes its input gradient), or null
   int colsum_rr;            // 1: deal the row-sum MFMAs round-robin over the blocks of an m-panel
 };
 

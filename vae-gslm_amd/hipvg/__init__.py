@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp), ("aux_in", _vp), ("aux_out", _vp),
                 ("lengths", _vp), ("T", _i),
                 ("act", _i), ("dact", _i), ("out_f32", _i), ("accumulate", _i),
-                ("split_k", _i), ("alpha", _f), ("pre_add", _vp), ("tile_cfg", _i), ("colsum_out", _vp)]
+                ("split_k", _i), ("alpha", _f), ("pre_add", _vp), ("tile_cfg", _i), ("colsum_out", _vp), ("colpart", _vp)]
 
 
 # name -> argtypes (restype is always int); must list EVERY symbol of the header
@@ -42,6 +42,7 @@ SIGNATURES = {
     "vg_version": [],
     "vg_last_error": [C.c_char_p, _i],
     "vg_gemm": [C.POINTER(GemmDesc), _vp],
+    "vg_gemm_tile_rows": [C.POINTER(GemmDesc)],
     "vg_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp],
     "vg_rmsnorm_bwd_blocks": [_i],
     "vg_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],

@@ -72,7 +72,7 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
          aux_out: Optional[Tensor] = None, lengths: Optional[Tensor] = None, T: int = 0,
          act: int = ACT_NONE, dact: int = ACT_NONE, accumulate=False, split_k: int = 1,
          alpha: float = 1.0, tile_cfg: int = 0, pre_add: Optional[Tensor] = None,
-         colsum_out: Optional[Tensor] = None) -> Tensor:
+         colsum_out: Optional[Tensor] = None, colpart: Optional[list] = None) -> Tensor:
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
     if A.data_ptr() % 16:      # e.g. a channel slice of a single frame: the kernels need 16-byte aligned operands
@@ -96,6 +96,16 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
     d.tile_cfg = int(tile_cfg)
     d.pre_add = ptr(pre_add)
     d.colsum_out = ptr(colsum_out)     # fp32 [M], += row sums of A (bias gradient of a wgrad launch)
+    part = None
+    if colpart is not None and split_k <= 1:
+        # per-row-tile column sums of the result from the same launch (the caller reduces the few rows): only
+        # on the LDS-DMA path, whose tile height the library reports for this descriptor
+        rows = lib().vg_gemm_tile_rows(C.byref(d))
+        if rows > 0:
+            part = torch.empty(((M + rows - 1) // rows, N), dtype=torch.float32, device=A.device)
+            d.colpart = ptr(part)
+    if colpart is not None:
+        colpart.append(part)
     check(lib().vg_gemm(C.byref(d), stream()), "vg_gemm")
     return out
 
@@ -604,10 +614,17 @@ class TransformerLayerFn(torch.autograd.Function):
             return v
 
         # ---- FFN
-        du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_STORED if _STORED_DERIV else ACT_GELU, aux_in=u)
+        want_part = b1 is not None and ctx.needs_input_grad[8] and _os0.environ.get("VG_COLPART", "1") != "0"
+        parts = [] if want_part else None
+        du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_STORED if _STORED_DERIV else ACT_GELU, aux_in=u,
+                  colpart=parts)                 # + column sums of du per row tile (b1's gradient) for free
         g_w2, g_b2 = wgrad_pair(w2, b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
-        g_w1, g_b1 = wgrad_pair(w1, b1, du, n3)
+        if want_part and parts[0] is not None:
+            g_w1, _ = wgrad_pair(w1, None, du, n3)
+            g_b1 = vec_grad(b1, parts[0])
+        else:
+            g_w1, g_b1 = wgrad_pair(w1, b1, du, n3)
         dx1, ds3 = rmsnorm_bwd_raw(dn3, x1, sc3, rstd3, dy, lengths, T)
         g_n3 = vec_grad(n3s, ds3)
         # ---- attention
@@ -707,8 +724,9 @@ class ConvBlockFn(torch.autograd.Function):
         dt = x.dtype
         dy = _as(dy, dt)
         Wa = s2[:, :Cc]
+        parts = [] if _os0.environ.get("VG_COLPART", "1") != "0" else None
         dpre = gemm(dy, s3, M, Hd, Cc, b_tr=True, dact=(ACT_RELU if act == ACT_RELU else ACT_STORED),
-                    aux_in=(h if act == ACT_RELU else pre))
+                    aux_in=(h if act == ACT_RELU else pre), colpart=parts)   # + column sums of dpre (c2b's gradient)
 
         fused_bias = set()
 
@@ -749,7 +767,7 @@ class ConvBlockFn(torch.autograd.Function):
             _fire(c3w)
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
-        g_c2b = None if id(c2b) in fused_bias else vec_grad(c2b, dpre)
+        g_c2b = None if id(c2b) in fused_bias else vec_grad(c2b, parts[0] if parts and parts[0] is not None else dpre)
         dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
         dte = dv.view(-1, T, Cc).float().sum(1)
         g_c1w = vec_grad(c1w, pw)
