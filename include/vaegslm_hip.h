@@ -84,6 +84,10 @@ typedef struct vg_gemm_desc {
   float* colpart;       /* [ceil(M / vg_gemm_tile_rows(desc))][N] fp32 or NULL: per-row-tile column sums of the stored result
                            (the dgrad that writes a Linear's input gradient also reduces it for the bias gradient of
                            the layer below); bf16 LDS-DMA path, split_k == 1 only */
+  float* split_ws;      /* optional workspace for split_k > 1 on the LDS-DMA path: the K slices meet through fp32 slabs and */
+  int32_t* split_cnt;   /* one arrival counter per output tile (wait-free in-launch reduction, plain 16-byte traffic) */
+  int64_t split_ws_floats; /* instead of fp32 atomics; used when split_k * tiles * tile size <= split_ws_floats (4096 counters
+                           suffice for every tile grid of <= 4096 tiles), otherwise the launch falls back to atomics */
 } vg_gemm_desc;
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 /* rows per output tile the launch for `desc` will use (128 or 256), 0 if it takes the register-staged kernel */

@@ -300,6 +300,22 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
   const int cfg = pick_cfg(d);
   p.colpart = d->colpart;
+  p.split_ws = nullptr;
+  p.split_cnt = nullptr;
+  if (splits > 1 && cfg > 0 && d->split_ws != nullptr && d->split_cnt != nullptr) {
+    // in-launch reduction of the K slices through fp32 slabs: needs splits * tiles * tile floats of workspace
+    const int rows = cfg_tile_rows(cfg), cols = (cfg == 3 || cfg == 4) ? 256 : 128;
+    const long tiles = (long)((d->M + rows - 1) / rows) * ((d->N + cols - 1) / cols);
+    if (tiles <= 4096 && tiles * rows * cols * (long)splits <= d->split_ws_floats && d->ldc % 4 == 0 &&
+        ((uintptr_t)d->C % 16) == 0) {
+      p.split_ws = d->split_ws;
+      p.split_cnt = d->split_cnt;
+      if (hipMemsetAsync(d->split_cnt, 0, (size_t)tiles * sizeof(int), stream) != hipSuccess) {
+        vg_host::set_error("vg_gemm: could not zero the split-K counters");
+        return 2;
+      }
+    }
+  }
   VG_REQUIRE(d->colpart == nullptr || (cfg > 0 && splits == 1),
              "vg_gemm: colpart needs the bf16 LDS-DMA path without split-K (ask vg_gemm_tile_rows first)");
   if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, cfg, stream);

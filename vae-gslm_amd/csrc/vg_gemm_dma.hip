@@ -310,7 +310,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
       for (int rr = 0; rr < 4; ++rr)
         strip[(4 * (lane >> 4) + rr) * SW + j * 16 + (lane & 15)] = acc[i][j][rr] * p.alpha;
     const int mband = m0 + arow + i * 16;
-    if (split) {
+    if (split && p.split_ws) {
+      // in-launch split-K reduction, step 1: this K-slice's partial tile goes to its fp32 slab with plain
+      // 16-byte stores (tile-local [BM][BN] layout, no bounds: the slab is padded)
+      float* __restrict__ slab = p.split_ws + ((long)blockIdx.z * nwg + wg) * (BM * BN);
+      constexpr int CPR = WCOLS / 8, RPP = 64 / CPR;
+      const int crow = lane / CPR, cch = lane % CPR;
+      for (int ps = 0; ps < (16 + RPP - 1) / RPP; ++ps) {
+        const int rloc = ps * RPP + crow;
+        if (rloc >= 16) continue;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
+        f32x4* dst = reinterpret_cast<f32x4*>(slab + (long)(arow + i * 16 + rloc) * BN + bcol + cch * 8);
+        dst[0] = lo;
+        dst[1] = hi;
+      }
+    } else if (split) {
       float* __restrict__ c = reinterpret_cast<float*>(p.C);
       constexpr int SEGS = WCOLS / 32;     // 32-float segments per strip row
       for (int it = lane >> 5; it < 16 * SEGS; it += 2) {
@@ -337,6 +352,52 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
         }
       }
     }
+  }
+  // in-launch split-K reduction, steps 2 and 3 (wait-free; cdna_hip_programming.md section 4, item 2): every
+  // slice publishes its slab (all waves drain their stores, barrier, ONE agent-scope release, ticket); the
+  // slice that draws the last ticket acquires once and adds the sum of all slabs to C with plain 16-byte
+  // accesses -- 1.3 TB/s of memory-side atomics become ~6 TB/s streams, and nobody ever waits.
+  if (split && p.split_ws) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* bcast = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bcast[0] = __hip_atomic_fetch_add(p.split_cnt + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int ticket = bcast[0];
+    if (ticket != (int)gridDim.z - 1) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    constexpr int CPR = WCOLS / 8, RPP = 64 / CPR;
+    const int crow = lane / CPR, cch = lane % CPR;
+    float* __restrict__ c = reinterpret_cast<float*>(p.C);
+    const long slab_stride = (long)nwg * (BM * BN);
+    const float* __restrict__ slab0 = p.split_ws + (long)wg * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      for (int ps = 0; ps < (16 + RPP - 1) / RPP; ++ps) {
+        const int rloc = ps * RPP + crow;
+        if (rloc >= 16) continue;
+        const int m = m0 + arow + i * 16 + rloc, n = n0 + bcol + cch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        const long off = (long)(arow + i * 16 + rloc) * BN + bcol + cch * 8;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < (int)gridDim.z; ++z) {
+          const f32x4* src = reinterpret_cast<const f32x4*>(slab0 + z * slab_stride + off);
+          lo += src[0];
+          hi += src[1];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(c + (long)m * p.ldc + n);
+        dst[0] += lo;
+        dst[1] += hi;
+      }
+    return;
   }
   // colpart: column sums of the tile's stored values -> colpart[m-tile][n].  Lanes that share a column
   // chunk are folded by shuffles, the WM waves of a column panel through LDS (the strips are free now).

@@ -21,6 +21,8 @@ struct GemmParams {
   float* colsum_out;        // TN mode: [M] fp32, += sum_k A(m,k) (unscaled), or null
   float* colpart;           // [tiles_m][N] fp32: per-m-tile column sums of the stored result (bias gradient of the
                             // NEXT layer's Linear produced by the dgrad that writes its input gradient), or null
+  float* split_ws;          // split-K slabs [splits][tiles][BM*BN] fp32 (in-launch reduction), or null: fp32 atomics
+  int* split_cnt;           // [tiles] arrival counters, zeroed ahead of the launch
   int colsum_rr;            // 1: deal the row-sum MFMAs round-robin over the blocks of an m-panel
 };
 

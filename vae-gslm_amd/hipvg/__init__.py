@@ -34,7 +34,8 @@ class GemmDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp), ("aux_in", _vp), ("aux_out", _vp),
                 ("lengths", _vp), ("T", _i),
                 ("act", _i), ("dact", _i), ("out_f32", _i), ("accumulate", _i),
-                ("split_k", _i), ("alpha", _f), ("pre_add", _vp), ("tile_cfg", _i), ("colsum_out", _vp), ("colpart", _vp)]
+                ("split_k", _i), ("alpha", _f), ("pre_add", _vp), ("tile_cfg", _i), ("colsum_out", _vp), ("colpart", _vp),
+                ("split_ws", _vp), ("split_cnt", _vp), ("split_ws_floats", _i64)]
 
 
 # name -> argtypes (restype is always int); must list EVERY symbol of the header

@@ -66,6 +66,23 @@ def refresh_shadows(params) -> None:
 
 
 # ---------------------------------------------------------------- raw ops
+# in-launch slab reduction of split-K weight gradients instead of fp32 atomics: measured SLOWER on these tiles
+# (64 KiB of slab per slice: 90 vs 68 us per wgrad launch, 274k vs 301k tokens/s), so off unless asked for
+_SPLIT_SLABS = _os0.environ.get("VG_SPLIT_SLABS", "0") != "0"
+_SPLIT_WS = {}
+
+
+def _split_workspace(device):
+    """Per-device scratch of the in-launch split-K reduction (fp32 slabs + tile counters).  Launches on one
+    stream serialise, so they share it; 64 MiB covers every weight gradient of the full config."""
+    ent = _SPLIT_WS.get(device)
+    if ent is None:
+        ent = (torch.empty(16 << 20, dtype=torch.float32, device=device),
+               torch.zeros(4096, dtype=torch.int32, device=device))
+        _SPLIT_WS[device] = ent
+    return ent
+
+
 def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False,
          out: Optional[Tensor] = None, out_f32=False, bias: Optional[Tensor] = None,
          residual: Optional[Tensor] = None, aux_in: Optional[Tensor] = None,
@@ -96,6 +113,9 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
     d.tile_cfg = int(tile_cfg)
     d.pre_add = ptr(pre_add)
     d.colsum_out = ptr(colsum_out)     # fp32 [M], += row sums of A (bias gradient of a wgrad launch)
+    if split_k > 1 and _SPLIT_SLABS and A.is_cuda:
+        ws, cnt = _split_workspace(A.device)
+        d.split_ws, d.split_cnt, d.split_ws_floats = ptr(ws), ptr(cnt), ws.numel()
     part = None
     if colpart is not None and split_k <= 1:
         # per-row-tile column sums of the result from the same launch (the caller reduces the few rows): only
