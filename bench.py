@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--graph", type=int, default=1, help="replay each micro-step as a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN, help="frames per sequence (BASELINE config 5: 2000)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="sequence lengths ~ U{T/2..T} (right-padded batches, SURVEY 8d): shows the cost of masking; "
+                         "tokens/s then counts valid frames only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +130,15 @@ def main():
     accum = trainer.gradient_update_step
     n_micro = (args.steps + args.warmup) * accum
     T_SEQ = args.seq_len
-    batches = [make_batch(B, T_SEQ, device, seed=1234 + rank * 1000 + i) for i in range(n_micro)]
+    def lens_for(i):
+        if not args.ragged:
+            return None
+        g = torch.Generator().manual_seed(99 + rank * 1000 + i)
+        ls = torch.randint(T_SEQ // 2, T_SEQ + 1, (B,), generator=g)
+        ls[0] = T_SEQ                      # the batch keeps its padded length
+        return ls.tolist()
+    all_lens = [lens_for(i) for i in range(n_micro)]
+    batches = [make_batch(B, T_SEQ, device, seed=1234 + rank * 1000 + i, lengths=all_lens[i]) for i in range(n_micro)]
     torch.cuda.synchronize()
 
     def sync():
@@ -153,6 +164,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tokens = args.steps * accum * B * T_SEQ * world
+    if args.ragged:     # valid frames of the timed micro-batches (this rank's draw, times the ranks)
+        tokens = world * sum(sum(l) for l in all_lens[args.warmup * accum:])
     value = tokens / elapsed
     if args.graph:
         # kernels inside a replayed hipGraph cannot be bracketed by host-recorded events: measure the
@@ -194,10 +207,13 @@ def main():
             "config": {"workload": "vae-gslm.yaml full config (L=16, d=1024, H=16, ffd=4096, 227M params), "
                                    f"fwd+bwd+AdamW, micro-batch {B} x grad-accum {accum} per step, seq_len {T_SEQ}",
                        "micro_batch": B, "grad_accum": accum, "seq_len": T_SEQ,
-                       "parallelism": f"dp{world}", "loss": float(out["loss"])},
+                       "parallelism": f"dp{world}", "loss": float(out["loss"]),
+                       "lengths": "U{T/2..T}, valid frames counted" if args.ragged else "full"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_source": traffic_src,
+                         # register-fed v_mfma_f32_32x32x16_bf16 loop on this pool's MI355X (tools/lab/peak_probe.hip)
+                         "peak_measured": 2136.0, "frac_of_measured": achieved / 2136.0,
                          "measured_on": ("one eager optimizer step right after the timed hipGraph replays"
                                          if args.graph else "the timed region"),
                          "step_model_tflops": value / world * flop_per_token / 1e12,
