@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -23,11 +24,20 @@ from . import (ACT_GELU, ACT_IDS, ACT_NONE, ACT_RELU, ACT_SAVE_DERIV, ACT_SILU, 
 
 Tensor = torch.Tensor
 
-import os as _os0
+# ---------------------------------------------------------------- switches (A/B measurements; defaults = fastest measured)
+def _flag(name: str, default: str) -> bool:
+    return os.environ.get(name, default) != "0"
+
+
 # bias gradient inside the wgrad launch (vg_gemm colsum_out): measured 2 % slower end-to-end than separate
-# column-sum launches on MI355X (the conditional MFMA inside the K loop costs the wgrad ~8 us), so off by default
-_FUSE_BIAS_GRAD = _os0.environ.get("VG_FUSE_BIAS_GRAD", "0") != "0"
-_STORED_DERIV = _os0.environ.get("VG_STORED_DERIV", "1") != "0"       # forward stores act'(u) for the backward
+# column-sum launches on MI355X (the conditional MFMA inside the K loop costs the wgrad ~8 us)
+_FUSE_BIAS_GRAD = _flag("VG_FUSE_BIAS_GRAD", "0")
+_STORED_DERIV = _flag("VG_STORED_DERIV", "1")   # forward stores act'(u): the backward epilogue is one multiply
+_COLPART = _flag("VG_COLPART", "1")             # dgrad launches also reduce their result per row tile (bias gradients)
+# in-launch slab reduction of split-K weight gradients instead of fp32 atomics: measured SLOWER on these tiles
+# (64 KiB of slab per slice: 90 vs 68 us per wgrad launch, 274k vs 301k tokens/s)
+_SPLIT_SLABS = _flag("VG_SPLIT_SLABS", "0")
+_GRAD_SINK = _flag("VG_GRAD_SINK", "1")         # wgrad / column sums write straight into param.grad
 
 # ---------------------------------------------------------------- weight shadows
 
@@ -66,9 +76,6 @@ def refresh_shadows(params) -> None:
 
 
 # ---------------------------------------------------------------- raw ops
-# in-launch slab reduction of split-K weight gradients instead of fp32 atomics: measured SLOWER on these tiles
-# (64 KiB of slab per slice: 90 vs 68 us per wgrad launch, 274k vs 301k tokens/s), so off unless asked for
-_SPLIT_SLABS = _os0.environ.get("VG_SPLIT_SLABS", "0") != "0"
 _SPLIT_WS = {}
 
 
@@ -497,8 +504,6 @@ def prior_logp_kl(mu_ls, u, logdet_sum, log_q, lengths=None, T=0):
 # pass, and under data parallelism ``param.grad`` is already a view into the flat
 # all-reduce bucket.  Hooks registered in ``param._vg_grad_hooks`` (the DP reducer) are
 # fired by hand because autograd's AccumulateGrad node never runs for these tensors.
-import os as _os
-_GRAD_SINK = _os.environ.get("VG_GRAD_SINK", "1") != "0"
 
 
 def set_grad_sink(on: bool) -> None:
@@ -634,7 +639,7 @@ class TransformerLayerFn(torch.autograd.Function):
             return v
 
         # ---- FFN
-        want_part = b1 is not None and ctx.needs_input_grad[8] and _os0.environ.get("VG_COLPART", "1") != "0"
+        want_part = b1 is not None and ctx.needs_input_grad[8] and _COLPART
         parts = [] if want_part else None
         du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_STORED if _STORED_DERIV else ACT_GELU, aux_in=u,
                   colpart=parts)                 # + column sums of du per row tile (b1's gradient) for free
@@ -744,7 +749,7 @@ class ConvBlockFn(torch.autograd.Function):
         dt = x.dtype
         dy = _as(dy, dt)
         Wa = s2[:, :Cc]
-        parts = [] if _os0.environ.get("VG_COLPART", "1") != "0" else None
+        parts = [] if _COLPART else None
         dpre = gemm(dy, s3, M, Hd, Cc, b_tr=True, dact=(ACT_RELU if act == ACT_RELU else ACT_STORED),
                     aux_in=(h if act == ACT_RELU else pre), colpart=parts)   # + column sums of dpre (c2b's gradient)
 
