@@ -130,12 +130,18 @@ class LVTRTrainer(BaseTrainer):
         else:
             out = self._training_loop(batch, batch_idx, noise)
         if last:
-            if self.reducer is not None:
-                self.reducer.finish()
             clip = self.hp.training.get("gradient_clip_val", None)
+            pipelined = (clip is None and self.reducer is not None and self.reducer.world > 1
+                         and getattr(self.optimizer, "clears_gradients", False))
+            if self.reducer is not None and not pipelined:
+                self.reducer.finish()
             if clip is not None:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
-            self.optimizer.step()
+            if pipelined:      # each bucket's AdamW launch waits for that bucket's all-reduce only
+                self.optimizer.step(bucket_wait=self.reducer.wait_bucket)
+                self.reducer.finish()
+            else:
+                self.optimizer.step()
             if getattr(self.optimizer, "clears_gradients", False):
                 pass                                   # vg_adamw zeroed the buckets in the same pass
             elif self.reducer is not None:

@@ -90,9 +90,25 @@ class GradReducer:
         if self.comm_stream is not None and self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                self._handles.append(self._allreduce(b["flat"]))
+                h = self._allreduce(b["flat"])
         else:
-            self._handles.append(self._allreduce(b["flat"]))
+            h = self._allreduce(b["flat"])
+        b["handle"], b["launched"] = h, True
+        self._handles.append(h)
+
+    def wait_bucket(self, i: int) -> None:
+        """Make the current stream wait for bucket ``i``'s all-reduce only (the optimizer can then update that
+        bucket while later buckets are still on the wire)."""
+        if self.world == 1:
+            return
+        b = self.buckets[i]
+        if not b.get("launched", False):
+            return
+        h = b.get("handle")
+        if h is not None:
+            h.wait()                       # stream-level wait for an asynchronous collective
+        elif self.comm_stream is not None and self.overlap:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def _allreduce(self, flat):
         backend = dist.get_backend(self.group)
@@ -115,6 +131,8 @@ class GradReducer:
             if h is not None:
                 h.wait()
         self._handles.clear()
+        for b in self.buckets:
+            b["handle"], b["launched"] = None, False
         if self.comm_stream is not None and self.overlap and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 

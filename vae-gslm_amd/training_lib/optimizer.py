@@ -70,7 +70,7 @@ class FlatAdamW(optim.AdamW):
         self._ctypes = (C, hipvg)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=None):
+    def step(self, closure=None, grad_scale=None, bucket_wait=None):
         if self._flat is None:
             return super().step(closure)
         C, hipvg = self._ctypes
@@ -80,7 +80,9 @@ class FlatAdamW(optim.AdamW):
         wd = (C.c_float * 4)(*[float(g["weight_decay"]) for g in self.param_groups] + [0.0] * (4 - ng))
         b1, b2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
-        for f in self._flat:
+        for i, f in enumerate(self._flat):
+            if bucket_wait is not None:
+                bucket_wait(i)        # e.g. GradReducer.wait_bucket: update bucket i while i+1.. are still reducing
             hipvg.check(hipvg.lib().vg_adamw(hipvg.ptr(f["P"]), hipvg.ptr(f["G"]), hipvg.ptr(f["M"]), hipvg.ptr(f["V"]),
                                              hipvg.ptr(f["S"]), hipvg.ptr(f["groups"]), f["P"].numel(), lr, wd, ng,
                                              float(b1), float(b2), float(eps), self._steps, hipvg.ptr(grad_scale), 1,
