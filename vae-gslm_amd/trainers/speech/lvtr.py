@@ -111,6 +111,8 @@ class LVTRTrainer(BaseTrainer):
         loss = rec * self.rec_loss_scale + kld * kld_weight
         if self.use_tokens:
             loss = loss + out["ce_loss"] * (self.token_kld_weight * kld_weight)
+        if self.reducer is not None:
+            self.reducer.new_backward()
         loss.backward()
         result = {"kld": kld.detach(), "rec_loss": rec.detach(), "log_p": -out["log_p"].mean().detach(),
                   "length": out["log_p"].length.sum(), "kld_weight": kld_weight,

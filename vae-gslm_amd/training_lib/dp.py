@@ -37,6 +37,7 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.overlap = overlap
         self.sync_now = True           # set False on non-final micro-batches
+        self._epoch = 0                # backward passes announced through new_backward()
         dev = self.params[0].device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         limit = int(bucket_mb * (1 << 20) / 4)
@@ -76,8 +77,19 @@ class GradReducer:
             off += self._padded(p.numel())
         self.buckets.append(dict(params=plist, offsets=offsets, flat=flat, pending=len(plist), need=len(plist)))
 
+    def new_backward(self) -> None:
+        """Call before every backward pass.  A parameter can report "gradient ready" twice in one pass: once from
+        hipvg's gradient sink and once from autograd, whose post-accumulate hooks also run when a custom backward
+        returned None for that parameter (torch >= 2.x).  From the first call on, only the first report of a
+        parameter per pass is counted; without it every report counts (plain autograd modules)."""
+        self._epoch += 1
+
     def _make_hook(self, bi: int):
         def hook(param):
+            if self._epoch:
+                if getattr(param, "_vg_fired_epoch", 0) == self._epoch:
+                    return
+                param._vg_fired_epoch = self._epoch
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
