@@ -100,11 +100,18 @@ def main():
         f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # functional dry run of the N > 1 path on a one-GPU box: VG_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # exchanges gradients over gloo (timings are then meaningless; the driver's runs use one GPU per rank and RCCL)
+    one_dev = os.environ.get("VG_BENCH_ONE_DEVICE", "0") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
 
     import hipvg
