@@ -313,17 +313,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
     if (split && p.split_ws) {
       // in-launch split-K reduction, step 1: this K-slice's partial tile goes to its fp32 slab with plain
       // 16-byte stores (tile-local [BM][BN] layout, no bounds: the slab is padded)
-      float* __restrict__ slab = p.split_ws + ((long)blockIdx.z * nwg + wg) * (BM * BN);
+      // write-through (sc1) stores: the slab is in memory once vmcnt drains, so publishing it needs no
+      // release fence (an agent-scope release would write back the XCD's whole L2 once per block)
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      const long slab_floats = (long)gridDim.z * nwg * (BM * BN);
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.split_ws, 0, (int)min(slab_floats * 4, 0x7fffffffL),
+                                                                    0x00020000);
+      const long slab = ((long)blockIdx.z * nwg + wg) * (BM * BN);
       constexpr int CPR = WCOLS / 8, RPP = 64 / CPR;
       const int crow = lane / CPR, cch = lane % CPR;
       for (int ps = 0; ps < (16 + RPP - 1) / RPP; ++ps) {
         const int rloc = ps * RPP + crow;
         if (rloc >= 16) continue;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
-        f32x4* dst = reinterpret_cast<f32x4*>(slab + (long)(arow + i * 16 + rloc) * BN + bcol + cch * 8);
-        dst[0] = lo;
-        dst[1] = hi;
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(strip + rloc * SW + cch * 8);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(strip + rloc * SW + cch * 8 + 4);
+        const unsigned off = (unsigned)((slab + (long)(arow + i * 16 + rloc) * BN + bcol + cch * 8) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, 16);
       }
     } else if (split) {
       float* __restrict__ c = reinterpret_cast<float*>(p.C);
@@ -361,11 +367,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* bcast = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0)      // slabs were stored write-through and drained: the ticket itself publishes them
       bcast[0] = __hip_atomic_fetch_add(p.split_cnt + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
     const int ticket = bcast[0];
     if (ticket != (int)gridDim.z - 1) return;

@@ -35,7 +35,8 @@ _FUSE_BIAS_GRAD = _flag("VG_FUSE_BIAS_GRAD", "0")
 _STORED_DERIV = _flag("VG_STORED_DERIV", "1")   # forward stores act'(u): the backward epilogue is one multiply
 _COLPART = _flag("VG_COLPART", "1")             # dgrad launches also reduce their result per row tile (bias gradients)
 # in-launch slab reduction of split-K weight gradients instead of fp32 atomics: measured SLOWER on these tiles
-# (64 KiB of slab per slice: 90 vs 68 us per wgrad launch, 274k vs 301k tokens/s)
+# (64 KiB of slab per slice; write-through slabs + ticket: 80 vs 67 us per wgrad launch, 289k vs 305k tokens/s;
+# with an agent-scope release fence per block instead of write-through stores: 90 us)
 _SPLIT_SLABS = _flag("VG_SPLIT_SLABS", "0")
 _GRAD_SINK = _flag("VG_GRAD_SINK", "1")         # wgrad / column sums write straight into param.grad
 
