@@ -39,6 +39,9 @@ _COLPART = _flag("VG_COLPART", "1")             # dgrad launches also reduce the
 # with an agent-scope release fence per block instead of write-through stores: 90 us)
 _SPLIT_SLABS = _flag("VG_SPLIT_SLABS", "0")
 _GRAD_SINK = _flag("VG_GRAD_SINK", "1")         # wgrad / column sums write straight into param.grad
+# sunk weight gradients of a layer on a second stream (parallel graph branch): measured slower, 55.4 vs 53.2 ms
+# per step -- both branches are machine-filling GEMMs and only thrash each other's L2 / LDS residency
+_WGRAD_STREAM = _flag("VG_WGRAD_STREAM", "0")
 
 # ---------------------------------------------------------------- weight shadows
 
@@ -527,7 +530,7 @@ def _fire(p: Tensor) -> None:
         h(p)
 
 
-def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor, bias: Optional[Tensor] = None) -> None:
+def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor, bias: Optional[Tensor] = None, fire: bool = True) -> None:
     """p.grad viewed as [N,K] += dy[M,N]^T x[M,K] (conv-shaped [N,K,1] weights share that memory); with
     ``bias`` also bias.grad[N] += column sums of dy, computed by the same launch from the dy tiles it
     already staged in LDS."""
@@ -538,9 +541,48 @@ def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor, bias: Optional[Tensor] = None) 
     s = wgrad_splits(N, K, M, x.dtype)
     bg = None if bias is None else _grad_buffer(bias).view(-1)
     gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1), colsum_out=bg)
-    _fire(p)
-    if bias is not None:
-        _fire(bias)
+    if fire:
+        _fire(p)
+        if bias is not None:
+            _fire(bias)
+
+
+_WGRAD_SIDE = {}
+
+
+class WgradStream:
+    """Weight gradients are off the critical path of backward (nothing consumes them before the optimizer), so a
+    layer's backward can issue them on a second HIP stream: the dgrad chain on the main stream and the wgrad
+    launches then fill each other's tails (last partial wave of blocks, the atomic-add phase of a split-K
+    epilogue, the gap between dependent launches).  Fork/join are stream waits, so the pattern is captured into a
+    hipGraph as two parallel branches.  Join before the tensors the side launches read can die."""
+
+    def __init__(self, device, enabled: bool):
+        self.enabled = bool(enabled) and device.type == "cuda"
+        self.pending = []
+        if self.enabled:
+            self.main = torch.cuda.current_stream(device)
+            side = _WGRAD_SIDE.get(device)
+            if side is None:
+                side = _WGRAD_SIDE[device] = torch.cuda.Stream(device=device)
+            self.side = side
+
+    def wgrad(self, weight, bias, g_out: Tensor, inp: Tensor):
+        """Same contract as :func:`wgrad_pair`; the weight-gradient GEMM goes to the side stream when it is sunk."""
+        if not (self.enabled and _sinkable(weight) and weight.is_contiguous()):
+            return wgrad_pair(weight, bias, g_out, inp)
+        self.side.wait_stream(self.main)             # g_out / inp were produced on the main stream
+        with torch.cuda.stream(self.side):
+            sink_wgrad(weight, g_out, inp, None, fire=False)
+        self.pending.append(weight)
+        return None, vec_grad(bias, g_out)           # column sums stay on the main stream
+
+    def join(self) -> None:
+        if self.enabled and self.pending:
+            self.main.wait_stream(self.side)
+        for p in self.pending:                       # gradient-ready reports only after the join
+            _fire(p)
+        self.pending = []
 
 
 def wgrad_pair(weight, bias, g_out: Tensor, inp: Tensor):
@@ -644,26 +686,28 @@ class TransformerLayerFn(torch.autograd.Function):
         parts = [] if want_part else None
         du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_STORED if _STORED_DERIV else ACT_GELU, aux_in=u,
                   colpart=parts)                 # + column sums of du per row tile (b1's gradient) for free
-        g_w2, g_b2 = wgrad_pair(w2, b2, dy, h)
+        ws = WgradStream(x.device, _WGRAD_STREAM)
+        g_w2, g_b2 = ws.wgrad(w2, b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
         if want_part and parts[0] is not None:
-            g_w1, _ = wgrad_pair(w1, None, du, n3)
+            g_w1, _ = ws.wgrad(w1, None, du, n3)
             g_b1 = vec_grad(b1, parts[0])
         else:
-            g_w1, g_b1 = wgrad_pair(w1, b1, du, n3)
+            g_w1, g_b1 = ws.wgrad(w1, b1, du, n3)
         dx1, ds3 = rmsnorm_bwd_raw(dn3, x1, sc3, rstd3, dy, lengths, T)
         g_n3 = vec_grad(n3s, ds3)
         # ---- attention
         datt = gemm(dx1, so, M, D, D, b_tr=True)
-        g_wo, g_bo = wgrad_pair(wo, bo, dx1, att)
+        g_wo, g_bo = ws.wgrad(wo, bo, dx1, att)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
         check(lib().vg_attn_bwd(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
                                 B, T, H, ptr(lengths), dtype_id(dt), stream()), "vg_attn_bwd")
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
-        g_wq, g_bq = wgrad_pair(wqkv, bqkv, dqkv, n1)
+        g_wq, g_bq = ws.wgrad(wqkv, bqkv, dqkv, n1)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
         g_n1 = vec_grad(n1s, ds1)
+        ws.join()                                # before qkv / att / du ... can be released
         return (dx, g_n1, g_wq, g_bq, g_wo, g_bo, g_n3, g_w1, g_b1, g_w2, g_b2,
                 None, None, None, None, None, None)
 
