@@ -200,6 +200,74 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------ thin products (latent side)
+// The model's 4-wide latent makes a few Linears extremely thin (4 -> 64, 512 -> 4, 4 -> 8): 0.01-0.07 GFLOP
+// each, for which a 128x128 MFMA tile launch costs 30-40 us (one column of tiles, exact-f32 MFMA at 2 k per
+// instruction).  They are plain dot products: one thread per output element, the reduction index walked
+// serially (<= 512 long) or, for the weight gradient (reduction over all frames), cut into chunks that meet
+// through fp32 atomics.  Element (i, j) = sum_r A[i*sai + r*sar] * B[j*sbj + r*sbr]; same epilogue subset as
+// the tile kernels (alpha, bias, ReLU/GELU/SiLU, residual, row mask, accumulate, fp32-or-T output).
+template <typename T>
+__global__ __launch_bounds__(256) void thin_gemm_kernel(GemmParams p, long sai, long sar, long sbj, long sbr, int R,
+                                                        int rchunk) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)p.M * p.N) return;
+  const int i = (int)(idx / p.N), j = (int)(idx % p.N);
+  const T* __restrict__ a = reinterpret_cast<const T*>(p.A) + i * sai;
+  const T* __restrict__ b = reinterpret_cast<const T*>(p.B) + j * sbj;
+  const int r0 = blockIdx.y * rchunk, r1 = min(R, r0 + rchunk);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc = fmaf(to_f32<T>(a[r * sar]), to_f32<T>(b[r * sbr]), acc);
+  float v = acc * p.alpha;
+  const long o = (long)i * p.ldc + j;
+  if (gridDim.y > 1) {       // partial sums of a chunked reduction: raw fp32 accumulation
+    atomicAdd(reinterpret_cast<float*>(p.C) + o, v);
+    return;
+  }
+  if (p.bias) v += p.bias[j];
+  if (p.act == VG_ACT_RELU) v = fmaxf(v, 0.f);
+  else if (p.act == VG_ACT_GELU) v = gelu_erf(v);
+  else if (p.act == VG_ACT_SILU) v = silu(v);
+  if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[o]);
+  if (!row_valid(p.lengths, p.T, i)) v = 0.f;
+  if (p.out_f32) {
+    float* c = reinterpret_cast<float*>(p.C) + o;
+    *c = p.accumulate ? (*c + v) : v;
+  } else {
+    reinterpret_cast<T*>(p.C)[o] = from_f32<T>(v);
+  }
+}
+
+// true if the launch was taken by the thin kernel
+template <typename T>
+bool launch_thin(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_t stream) {
+  if (a_tr && !b_tr) return false;
+  if (p.aux_in || p.aux_out || p.pre_add || p.dact != VG_ACT_NONE || (p.act & VG_ACT_SAVE_DERIV) || p.colsum_out ||
+      p.colpart)
+    return false;
+  const bool thin = (p.N <= 16 || p.K <= 16 || (a_tr && p.M <= 16)) && (long)p.M * p.N <= (1L << 22);
+  if (!thin) return false;
+  if (!a_tr && (long)p.K > 1024) return false;                 // serial reduction per thread: keep it short
+  if (splits > 1 && !p.out_f32) return false;
+  // strides of element (i, j) / reduction index r in A and B for the three operand modes
+  const long sai = a_tr ? 1 : p.lda, sar = a_tr ? p.lda : 1;
+  const long sbj = b_tr ? 1 : p.ldb, sbr = b_tr ? p.ldb : 1;
+  int chunks = 1, rchunk = p.K;
+  if (a_tr) {                                                   // reduction over frames: chunk + atomics
+    if (!p.out_f32) return false;
+    rchunk = 256;
+    chunks = (p.K + rchunk - 1) / rchunk;
+    if (chunks == 1 && !(splits > 1)) rchunk = p.K;
+    else if (!(splits > 1 || p.accumulate)) return false;       // atomics need a destination that already holds a value
+  }
+  GemmParams q = p;
+  if (a_tr && chunks > 1) q.accumulate = 1;
+  const long outs = (long)p.M * p.N;
+  dim3 grid((unsigned)((outs + 255) / 256), chunks);
+  thin_gemm_kernel<T><<<grid, dim3(256), 0, stream>>>(q, sai, sar, sbj, sbr, p.K, rchunk);
+  return true;
+}
+
 template <typename T>
 int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hipStream_t stream) {
   const int kind = sizeof(T) == 4 ? VG_PROF_GEMM_F32
@@ -210,6 +278,7 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
     vg_host::prof_end(tok, stream);
     if (rc == 0) return vg_host::check_launch("vg_gemm(dma)");
   }
+  if (launch_thin<T>(p, a_tr, b_tr, splits, stream)) return vg_host::check_launch("vg_gemm(thin)");
   if (p.colsum_out)   // register-staged path: the bias gradient is a separate pass over A = dY [K][lda]
     vg_host::colsum_accumulate(p.A, p.K, p.M, p.lda, p.colsum_out, sizeof(T) == 4 ? VG_F32 : VG_BF16, stream);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
