@@ -510,6 +510,22 @@ def test_flat_adamw_matches_torch(F):
             assert torch.equal(p._vg_flat_shadow, p.data.bfloat16())
     sd = opt.state_dict()
     assert len(sd["state"]) == len(list(net.parameters())) and float(sd["state"][0]["step"]) == 4.0
+    # resume: a fresh optimizer bound to a copy of the model, loaded from that state dict, continues identically
+    net2 = copy.deepcopy(net)
+    with torch.no_grad():
+        for p2, p in zip(net2.parameters(), net.parameters()):
+            p2.data = p.data.clone()              # deepcopy kept views into net's flat storage: detach them
+    opt2 = FlatAdamW(groups(net2), fused=True, **kw)
+    red2 = GradReducer(net2.parameters(), bucket_mb=0.05)
+    opt2.bind(red2)
+    opt2.load_state_dict(copy.deepcopy(sd))
+    x = torch.randn(16, 300, device=dev())
+    for m in (net, net2):
+        m(x).square().sum().backward()
+    opt.step()
+    opt2.step()
+    for (k, p), q in zip(net.named_parameters(), net2.parameters()):
+        assert torch.equal(p.data, q.data), k
 
 
 # ------------------------------------------------------------------ decode-step kernels
