@@ -40,5 +40,11 @@ class ConditionalBottleNeckUNet(nn.Module):
 
     def forward(self, noise: TensorMask, t: torch.Tensor, cond: TensorMask) -> TensorMask:
         """noise, cond: (B, T, C) TensorMasks; t: (B,) integer diffusion steps."""
-        c = TensorMask(self.cond_net(cond.value), cond.mask).apply_mask()
+        if cond.value.is_cuda and cond.value.dim() == 3:
+            # conditioning projection (cond_dim -> 32) through the HIP GEMM: the mask is its epilogue's row predicate
+            from modules.linear.layers import dense_2d
+            c = TensorMask(dense_2d(cond.value, self.cond_net.weight, self.cond_net.bias, lengths=cond.lengths32,
+                                    T=cond.value.shape[1]), cond.mask)
+        else:
+            c = TensorMask(self.cond_net(cond.value), cond.mask).apply_mask()
         return self.unet(noise, c, self.time_embedding(t))
