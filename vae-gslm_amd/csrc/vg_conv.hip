@@ -77,11 +77,42 @@ struct ParamLds {
 VG_DEVICE void stage_params(ParamLds& P, const float* __restrict__ w, const float* __restrict__ cbias,
                             const float* __restrict__ gamma, const float* __restrict__ beta, const DwArgs& a) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int i = tid; i < a.C * a.taps; i += nt) P.w[i] = w[i];
-  for (int i = tid; i < a.C; i += nt) {
-    P.cb[i] = (cbias && a.taps > 0) ? cbias[i] : 0.f;
-    P.gamma[i] = gamma ? gamma[i] : 1.f;
-    P.beta[i] = beta ? beta[i] : 0.f;
+  // batches of independent loads first, LDS stores afterwards: a load -> store loop would pay one L2 round
+  // trip per iteration (14 of them for 512 channels x 7 taps), i.e. ~10 us of set-up per block
+  constexpr int PF = 8;
+  const int nw = a.C * a.taps;
+  for (int base = 0; base < nw; base += nt * PF) {
+    float r[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = base + j * nt + tid;
+      r[j] = i < nw ? w[i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = base + j * nt + tid;
+      if (i < nw) P.w[(i % a.taps) * a.C + i / a.taps] = r[j];   // [tap][C]: lanes read 8 channels contiguously
+    }
+  }
+  for (int base = 0; base < a.C; base += nt * 2) {
+    float rc[2], rg[2], rb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = base + j * nt + tid;
+      const bool in = i < a.C;
+      rc[j] = (in && cbias && a.taps > 0) ? cbias[i] : 0.f;
+      rg[j] = (in && gamma) ? gamma[i] : 1.f;
+      rb[j] = (in && beta) ? beta[i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = base + j * nt + tid;
+      if (i < a.C) {
+        P.cb[i] = rc[j];
+        P.gamma[i] = rg[j];
+        P.beta[i] = rb[j];
+      }
+    }
   }
   __syncthreads();
 }
@@ -92,7 +123,8 @@ VG_DEVICE void stage_params(ParamLds& P, const float* __restrict__ w, const floa
 constexpr int RUN = 4;
 struct RowWalk {
   int chunk, r, cstride, M;
-  VG_DEVICE RowWalk(int M_) : chunk(blockIdx.x * 4 + (threadIdx.x >> 6)), r(0), cstride(gridDim.x * 4), M(M_) {}
+  VG_DEVICE RowWalk(int M_)
+      : chunk(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), r(0), cstride(gridDim.x * (blockDim.x >> 6)), M(M_) {}
   VG_DEVICE int row() const { return chunk * RUN + r; }
   VG_DEVICE bool valid() const { return row() < M; }
   VG_DEVICE void next() {
@@ -113,11 +145,11 @@ template <typename T, int NV> struct LaneParams {
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
 #pragma unroll
-      for (int e = 0; e < N; ++e) {
-        cb[i][e] = P.cb[c * N + e];
+      for (int e = 0; e < N; ++e) cb[i][e] = P.cb[c * N + e];
 #pragma unroll
-        for (int k = 0; k < MAXTAPS; ++k) w[i][k][e] = (k < a.taps) ? P.w[(c * N + e) * a.taps + k] : 0.f;
-      }
+      for (int k = 0; k < MAXTAPS; ++k)
+#pragma unroll
+        for (int e = 0; e < N; ++e) w[i][k][e] = (k < a.taps) ? P.w[k * a.C + c * N + e] : 0.f;
     }
   }
 };
@@ -194,7 +226,7 @@ VG_DEVICE void conv_row(const T* __restrict__ x, const LaneParams<T, NV>& lp, co
 }
 
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void dwnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void dwnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ cbias,
                                                          const float* __restrict__ temb,
                                                          const float* __restrict__ gamma,
@@ -424,7 +456,8 @@ int check_shape(const char* who, int M, int C, int T, int taps, int dtype) {
 template <typename T, int NV>
 void launch_fwd(const void* x, const float* w, const float* cbias, const float* temb, const float* gamma,
                 const float* beta, void* y, float* mean, float* rstd, const DwArgs& a, int nb, hipStream_t stream) {
-  dwnorm_fwd_kernel<T, NV><<<dim3(nb), dim3(256), 0, stream>>>((const T*)x, w, cbias, temb, gamma, beta, (T*)y, mean,
+  static const int wpb = [] { const char* e = getenv("VG_DW_WAVES"); return e ? atoi(e) : 4; }();
+  dwnorm_fwd_kernel<T, NV><<<dim3(nb), dim3(64 * wpb), 0, stream>>>((const T*)x, w, cbias, temb, gamma, beta, (T*)y, mean,
                                                               rstd, a);
 }
 template <typename T, int NV>
@@ -451,7 +484,7 @@ extern "C" int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, 
   if (int e = check_shape("vg_dwnorm_fwd", M, C, T, taps, dtype)) return e;
   DwArgs a{M, C, T, taps, shift, eps};
   static const int nb_env = [] { const char* e = getenv("VG_DW_BLOCKS"); return e ? atoi(e) : 0; }();
-  const int nb = min((M + 3) / 4, nb_env > 0 ? nb_env : 1024);
+  const int nb = min((M + 3) / 4, nb_env > 0 ? nb_env : 512);   // measured: 2048 waves balance per-wave set-up against parallelism
   const int nv = C / (64 * (dtype == VG_BF16 ? 8 : 4));
   if (dtype == VG_BF16) {
     if (nv == 1) launch_fwd<bf16_t, 1>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
