@@ -236,6 +236,42 @@ __global__ void colsum_kernel(const T* __restrict__ x, int M, int N, long ld, fl
   }
 }
 
+// first stage with 16-byte loads (8 bf16 / 4 fp32 columns per thread, two rows in flight per thread)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int M, int N, long ld,
+                                                         float* __restrict__ out) {
+  constexpr int V = Vec<T>::N;
+  __shared__ float red[4][64][V];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c0 = (blockIdx.x * 64 + tx) * V;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    const int step = gridDim.y * 4;
+    int m = blockIdx.y * 4 + ty;
+    for (; m + step < M; m += 2 * step) {
+      float a[8], b[8];
+      Vec<T>::load(x + (long)m * ld + c0, a);
+      Vec<T>::load(x + (long)(m + step) * ld + c0, b);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += a[e] + b[e];
+    }
+    if (m < M) {
+      float a[8];
+      Vec<T>::load(x + (long)m * ld + c0, a);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += a[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[ty][tx][e] = s[e];
+  __syncthreads();
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      out[(long)blockIdx.y * N + c0 + e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
+  }
+}
+
 // final / small-input stage: one column per thread, 16 row lanes per block, optional accumulate
 template <typename T>
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const T* __restrict__ x, int M, int N, long ld,
@@ -576,9 +612,16 @@ extern "C" int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, flo
     else
       launch_colsum_small((const float*)x, M, N, (long)ld, out, accumulate, stream);
   } else {
-    dim3 grid1((N + 255) / 256, nb);
-    if (dtype == VG_BF16) run_colsum<bf16_t>(grid1, x, M, N, (long)ld, ws, stream);
-    else run_colsum<float>(grid1, x, M, N, (long)ld, ws, stream);
+    const int vec = dtype == VG_BF16 ? 8 : 4;
+    if (N % vec == 0 && ld % vec == 0 && ((uintptr_t)x % 16) == 0) {
+      dim3 gridv((N + 64 * vec - 1) / (64 * vec), nb), blockv(64, 4);
+      if (dtype == VG_BF16) colsum_vec_kernel<bf16_t><<<gridv, blockv, 0, stream>>>((const bf16_t*)x, M, N, (long)ld, ws);
+      else colsum_vec_kernel<float><<<gridv, blockv, 0, stream>>>((const float*)x, M, N, (long)ld, ws);
+    } else {
+      dim3 grid1((N + 255) / 256, nb);
+      if (dtype == VG_BF16) run_colsum<bf16_t>(grid1, x, M, N, (long)ld, ws, stream);
+      else run_colsum<float>(grid1, x, M, N, (long)ld, ws, stream);
+    }
     launch_colsum_small(ws, nb, N, (long)N, out, accumulate, stream);
   }
   return vg_host::check_launch("vg_colsum");
