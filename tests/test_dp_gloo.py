@@ -68,3 +68,70 @@ def test_reducer_two_ranks_gloo(bucket_mb):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), bucket_mb, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+class _SinkLinear(torch.autograd.Function):
+    """Mimics hipvg's gradient sink on CPU: the weight gradient is accumulated straight into ``weight.grad``
+    and reported through ``_vg_grad_hooks``; backward returns None for it (autograd still runs the
+    parameter's post-accumulate hooks for a None gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x)
+        ctx.weight = weight
+        return x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        w = ctx.weight
+        w.grad.add_(g.t() @ x)
+        for h in getattr(w, "_vg_grad_hooks", ()):
+            h(w)
+        return g @ w, None
+
+
+def _sink_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from training_lib.dp import GradReducer
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(6, 5))
+    lin2 = torch.nn.Linear(6, 3)
+    params = [w1, lin2.weight, lin2.bias]
+    red = GradReducer(params, bucket_mb=50.0)          # one bucket: fires when all three have reported
+    launches = []
+    orig = red._launch
+    red._launch = lambda b: (launches.append(1), orig(b))[1]
+    g = torch.Generator().manual_seed(7 + rank)
+    ok = True
+    for step in range(3):
+        x = torch.randn(4, 5, generator=g)
+        red.new_backward()
+        lin2(_SinkLinear.apply(x, w1)).pow(2).sum().backward()
+        red.finish()
+        ok &= all(b["pending"] == b["need"] for b in red.buckets)       # counters balanced after every pass
+        ok &= len(launches) == step + 1                                   # exactly one all-reduce per pass
+        # reference gradient, averaged over ranks by hand
+        tot = torch.zeros_like(w1)
+        for r in range(world):
+            gr = torch.Generator().manual_seed(7 + r)
+            for _ in range(step + 1):
+                xr = torch.randn(4, 5, generator=gr)
+            wr = w1.detach().clone().requires_grad_(True)
+            torch.nn.functional.linear(xr @ wr.t(), lin2.weight.detach(), lin2.bias.detach()).pow(2).sum().backward()
+            tot += wr.grad / world
+        ok &= bool(torch.allclose(w1.grad, tot, atol=1e-5, rtol=1e-5))
+        red.zero_grad()
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sunk_gradients_report_once_per_backward():
+    """A parameter whose gradient is sunk reports readiness twice per backward (sink + autograd's hook for the
+    None gradient); the reducer must count it once, or the bucket's all-reduce starts before the bucket is full."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sink_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
