@@ -78,6 +78,8 @@ class LVTRTrainer(BaseTrainer):
         bind = getattr(self.optimizer, "bind", None)
         if callable(bind) and next(self.model.parameters()).is_cuda:
             bind(self.reducer)                 # AdamW + bf16 weight refresh + gradient clear: one launch per bucket
+            # weights loaded into the bound model later must reach the bf16 copies the GEMMs read
+            self.model.register_load_state_dict_post_hook(lambda module, incompatible: self.optimizer.sync_shadows())
         return self.reducer
 
     def current_kld_weight(self) -> float:

@@ -89,6 +89,13 @@ class FlatAdamW(optim.AdamW):
                                              hipvg.stream()), "vg_adamw")
         return None
 
+    @torch.no_grad()
+    def sync_shadows(self) -> None:
+        """Re-derive the bf16 weight copies from the fp32 masters (after the parameters were written by anything
+        other than :meth:`step`, e.g. ``load_state_dict`` on the bound model)."""
+        for f in self._flat or ():
+            f["S"].copy_(f["P"])
+
     @property
     def clears_gradients(self) -> bool:
         """True once bound: ``step`` leaves the gradient buckets zeroed."""
