@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--graph", type=int, default=1, help="replay each micro-step as a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN, help="frames per sequence (BASELINE config 5: 2000)")
+    ap.add_argument("--coalesce", type=int, default=1,
+                    help="1 (default, = hip.coalesce_accumulation of the yaml): the micro-batches of an accumulation "
+                         "window (8 sequences x 2) run as ONE launch sequence over 16 sequences -- same samples, same "
+                         "summed loss, same gradient and optimizer step, taller GEMMs; 0: one pass per micro-batch")
     ap.add_argument("--ragged", action="store_true",
                     help="sequence lengths ~ U{T/2..T} (right-padded batches, SURVEY 8d): shows the cost of masking; "
                          "tokens/s then counts valid frames only")
@@ -123,6 +127,7 @@ def main():
     hp = Hparams.from_yamlfile(CONFIG)
     hp.hip.precision = args.precision
     hp.hip.graph = bool(args.graph)
+    hp.hip.coalesce_accumulation = bool(args.coalesce)
     torch.manual_seed(1234)
     trainer = LVTRTrainer(hp).to(device)
     if world > 1:
@@ -212,10 +217,13 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "vae-gslm.yaml full config (L=16, d=1024, H=16, ffd=4096, 227M params), "
-                                   f"fwd+bwd+AdamW, micro-batch {B} x grad-accum {accum} per step, seq_len {T_SEQ}",
+                                   f"fwd+bwd+AdamW, micro-batch {B} x grad-accum {accum} per step, seq_len {T_SEQ}"
+                                   + (f" (the {accum} micro-batches run as one pass over {B * accum} sequences)"
+                                      if args.coalesce and accum > 1 else ""),
                        "micro_batch": B, "grad_accum": accum, "seq_len": T_SEQ,
                        "parallelism": f"dp{world}", "loss": float(out["loss"]),
-                       "lengths": "U{T/2..T}, valid frames counted" if args.ragged else "full"},
+                       "lengths": "U{T/2..T}, valid frames counted" if args.ragged else "full",
+                       "accumulation": "one launch sequence over B x accum sequences" if args.coalesce else "per micro-batch"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_source": traffic_src,

@@ -63,6 +63,9 @@ class LVTRTrainer(BaseTrainer):
         self.use_graph = bool(hip.get("graph", False)) if hip is not None else False
         self._graphs = {}
         self._kw_dev = None
+        # optional: the micro-batches of an accumulation window as one batch (same gradient, taller GEMMs)
+        self.coalesce = bool(hip.get("coalesce_accumulation", False)) if hip is not None else False
+        self._held = []
 
     # ------------------------------------------------------------ optimisation plumbing
     def configure_optimizers(self):
@@ -125,8 +128,33 @@ class LVTRTrainer(BaseTrainer):
             result["token_kld"] = out["ce_loss"].detach()
         return result
 
+    @staticmethod
+    def _concat_batches(batches) -> Mapping:
+        """Micro-batches of one accumulation window as ONE batch (rows = all their sequences): the loss terms are
+        sums over frames, so one forward/backward over the concatenation yields the accumulated gradient."""
+        from utils.tensormask import TensorMask
+        out = {}
+        for k in batches[0]:
+            vals = [b[k].value for b in batches]
+            T = max(v.shape[1] for v in vals)
+            full = all(getattr(b[k].mask, "_vg_full", False) and b[k].value.shape[1] == T for b in batches)
+            pad = lambda v, t: v if t == T else torch.nn.functional.pad(v, (0, 0) * (v.dim() - 2) + (0, T - t))
+            value = torch.cat([pad(v, v.shape[1]) for v in vals], 0)
+            if full:
+                out[k] = TensorMask(value)
+            else:
+                out[k] = TensorMask(value, torch.cat([torch.nn.functional.pad(b[k].mask, (0, T - b[k].mask.shape[1]))
+                                                      for b in batches], 0))
+        return out
+
     def training_step(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
         last = (batch_idx + 1) % self.gradient_update_step == 0
+        if self.coalesce and noise is None and self.gradient_update_step > 1:
+            # hip.coalesce_accumulation: hold the window's micro-batches and run them as one launch sequence
+            self._held.append(batch)
+            if not last:
+                return {"coalesced": True}
+            batch, self._held = self._concat_batches(self._held), []
         if self.reducer is not None:
             self.reducer.sync_now = last
         if self.use_graph and noise is None:
