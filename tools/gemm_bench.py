@@ -13,7 +13,7 @@ import hipvg
 from hipvg import functional as F
 
 dev = torch.device("cuda:0")
-M = 8000
+M = int(os.environ.get("M", "8000"))
 SHAPES = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]     # (N_out_features, K_in_features)
 CFGS = [int(c) for c in os.environ.get("CFGS", "-1,1,2,3,4").split(",")]
 ITERS = int(os.environ.get("ITERS", "20"))

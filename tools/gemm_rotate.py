@@ -13,7 +13,7 @@ import hipvg
 from hipvg import functional as F
 
 dev = torch.device("cuda:0")
-M = 8000
+M = int(os.environ.get("M", "8000"))
 R = int(os.environ.get("R", "16"))
 ITERS = int(os.environ.get("ITERS", "4"))
 

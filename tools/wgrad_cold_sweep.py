@@ -12,7 +12,7 @@ import hipvg
 from hipvg import functional as F
 
 dev = torch.device("cuda:0")
-M, R, ITERS = 8000, 12, 4
+M, R, ITERS = int(os.environ.get("M", "8000")), 8, 4
 
 
 def run(fns):

@@ -314,16 +314,20 @@ int pick_cfg(const vg_gemm_desc* d) {
                       (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7ffffff0L;
   if (!dma_ok) return -1;
   if (cfg != 0) return cfg;
-  // measured on MI355X at M = 8000 (tools/gemm_bench.py, tools/gemm_rotate.py): 128x128 wins or ties
-  // everywhere except the wide-N forward / dgrad products (256x256) and the long-K / narrow-N forward
-  // product (FFN down-projection: 256x128 with a 3-stage ring, whose deeper prefetch pays on operands that
-  // come from HBM; VG_CFG_LONGK overrides, 0 = 128x256)
+  // measured on MI355X on cold operands (tools/tile_cold_sweep.py, tools/gemm_rotate.py; M = 8000 and 16000):
+  // forward / dgrad products take 256x256 tiles whenever those fill the 256 CUs in whole waves (>= 224 tiles,
+  // >= 85 % of the last wave used: 10-25 % faster than 128x128, whose operand feed is the CU's whole L1->LDS
+  // and LDS read bandwidth), otherwise 128x128; the long-K / narrow-N forward product that cannot fill the
+  // machine with 256x256 (FFN down-projection at M = 8000) takes 256x128 with a 3-stage ring (VG_CFG_LONGK
+  // overrides, 0 = 128x256).  Weight gradients: 128x128 + split-K (tools/wgrad_cold_sweep.py).
   cfg = 1;
-  if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048) cfg = 4;
-  if (!d->a_tr && d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
-  if (!d->a_tr && !d->b_tr && d->N >= 4096 && d->M >= 2048) cfg = 3;
+  if (!d->a_tr) {
+    const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const long waves = (t256 + 255) / 256;
+    if (t256 >= 224 && t256 * 100 >= waves * 256 * 85) cfg = 3;
+  }
   static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
-  if (!d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
+  if (cfg == 1 && !d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
   if (d->a_tr && d->b_tr && d->colsum_out) cfg = 1;
   return cfg;
 }
