@@ -37,8 +37,8 @@ def main():
         xs = [torch.randn(M, K, generator=g).to(dev).bfloat16() for _ in range(R)]
         gws = [torch.zeros(N, K, device=dev) for _ in range(R)]
         row = []
-        for cfg in (1, 2, 4):
-            for s in (1, 2, 3, 4, 6):
+        for cfg in [int(v) for v in os.environ.get("CFGS", "1,2,4").split(",")]:
+            for s in [int(v) for v in os.environ.get("SPLITS", "1,2,3,4,6").split(",")]:
                 t = run([(lambda i=i: F.gemm(dys[i], xs[i], N, K, M, a_tr=True, b_tr=True, out=gws[i], split_k=s,
                                              accumulate=(s == 1), tile_cfg=cfg)) for i in range(R)])
                 row.append(f"cfg{cfg} s{s}: {t * 1e6:6.1f}")
