@@ -245,7 +245,7 @@ bool launch_thin(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_
   if (p.aux_in || p.aux_out || p.pre_add || p.dact != VG_ACT_NONE || (p.act & VG_ACT_SAVE_DERIV) || p.colsum_out ||
       p.colpart)
     return false;
-  const bool thin = (p.N <= 16 || p.K <= 16 || (a_tr && p.M <= 16)) && (long)p.M * p.N <= (1L << 22);
+  const bool thin = (p.N <= 16 || p.K <= 16 || (a_tr && p.M <= 16)) && (long)p.M * p.N <= (1L << 24);
   if (!thin) return false;
   if (!a_tr && (long)p.K > 1024) return false;                 // serial reduction per thread: keep it short
   if (splits > 1 && !p.out_f32) return false;
@@ -255,7 +255,7 @@ bool launch_thin(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_
   int chunks = 1, rchunk = p.K;
   if (a_tr) {                                                   // reduction over frames: chunk + atomics
     if (!p.out_f32) return false;
-    rchunk = 256;
+    rchunk = 64;          // few outputs, long reduction: many short chunks keep the whole chip busy
     chunks = (p.K + rchunk - 1) / rchunk;
     if (chunks == 1 && !(splits > 1)) rchunk = p.K;
     else if (!(splits > 1 || p.accumulate)) return false;       // atomics need a destination that already holds a value
@@ -279,6 +279,11 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
     if (rc == 0) return vg_host::check_launch("vg_gemm(dma)");
   }
   if (launch_thin<T>(p, a_tr, b_tr, splits, stream)) return vg_host::check_launch("vg_gemm(thin)");
+  static const bool debug = getenv("VG_DEBUG_GEMM") != nullptr;
+  if (debug)
+    fprintf(stderr, "[vg_gemm] register-staged kernel: %s M=%d N=%d K=%d a_tr=%d b_tr=%d splits=%d act=%d dact=%d aux_out=%d res=%d\n",
+            sizeof(T) == 4 ? "f32" : "bf16", p.M, p.N, p.K, a_tr, b_tr, splits, p.act, p.dact, p.aux_out != nullptr,
+            p.residual != nullptr);
   if (p.colsum_out)   // register-staged path: the bias gradient is a separate pass over A = dY [K][lda]
     vg_host::colsum_accumulate(p.A, p.K, p.M, p.lda, p.colsum_out, sizeof(T) == 4 ? VG_F32 : VG_BF16, stream);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
