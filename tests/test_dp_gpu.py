@@ -66,3 +66,24 @@ def test_two_rank_training_on_gpu(full_cfg, use_graph):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), cfg, use_graph, out), nprocs=world, join=True)
     assert dict(out) == {0: (True, True, True, True), 1: (True, True, True, True)}
+
+
+def test_bench_two_ranks_full_model_one_device():
+    """`bench.py --gpus 2` exactly as the driver launches it, at the full vae-gslm.yaml size with the defaults
+    (hipGraph replay + coalesced accumulation + per-bucket optimizer launches), both ranks on cuda:0 over gloo.
+    The full-size graph is what exposed the null-stream graph-launch fault; the small model above
+    never did."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VG_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert d["config"]["loss"] == d["config"]["loss"]          # finite (not NaN)

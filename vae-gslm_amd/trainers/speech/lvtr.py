@@ -63,6 +63,7 @@ class LVTRTrainer(BaseTrainer):
         self.use_graph = bool(hip.get("graph", False)) if hip is not None else False
         self._graphs = {}
         self._kw_dev = None
+        self._compute_stream = None
         # optional: the micro-batches of an accumulation window as one batch (same gradient, taller GEMMs)
         self.coalesce = bool(hip.get("coalesce_accumulation", False)) if hip is not None else False
         self._held = []
@@ -148,6 +149,26 @@ class LVTRTrainer(BaseTrainer):
         return out
 
     def training_step(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
+        if self.use_graph and noise is None and os.environ.get("VG_GRAPH_OWN_STREAM", "1") != "0":
+            self._leave_null_stream(batch["mel"].value.device)
+        return self._training_step(batch, batch_idx, noise)
+
+    def _leave_null_stream(self, dev) -> None:
+        """hipGraph mode never launches on the null stream.  On ROCm 7.2 a graph launched on the null stream after
+        a cross-stream hipStreamWaitEvent (what the reducer issues once world > 1) replays with corrupt kernel
+        arguments -- reproduced in one process, DESIGN.md "hipGraph on the null stream"; on a created stream the
+        same sequence is clean.  The calling thread is moved onto a stream the trainer owns, once (switching per
+        step costs 1 ms of cross-stream waits per step), so the caller's later work is ordered after the step as
+        before."""
+        cur = torch.cuda.current_stream(dev)
+        if cur != torch.cuda.default_stream(dev):
+            return
+        if self._compute_stream is None:
+            self._compute_stream = torch.cuda.Stream(device=dev)
+        self._compute_stream.wait_stream(cur)
+        torch.cuda.set_stream(self._compute_stream)
+
+    def _training_step(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
         last = (batch_idx + 1) % self.gradient_update_step == 0
         if self.coalesce and noise is None and self.gradient_update_step > 1:
             # hip.coalesce_accumulation: hold the window's micro-batches and run them as one launch sequence
