@@ -85,11 +85,13 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
     bf16x8 o;
     if (act == VG_ACT_GELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float cdf, px;
-        gelu_parts_fast(v[e], cdf, px);
-        o[e] = (bf16_t)(cdf + px);
-        v[e] *= cdf;
+      for (int e = 0; e < 8; e += 2) {
+        f32x2_t cdf, px;
+        gelu_parts_pk(f32x2_t{v[e], v[e + 1]}, cdf, px);
+        o[e] = (bf16_t)(cdf[0] + px[0]);
+        o[e + 1] = (bf16_t)(cdf[1] + px[1]);
+        v[e] *= cdf[0];
+        v[e + 1] *= cdf[1];
       }
     } else if (act == VG_ACT_SILU) {
 #pragma unroll
@@ -118,7 +120,12 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     } else if (act == VG_ACT_GELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+      for (int e = 0; e < 8; e += 2) {
+        f32x2_t cdf, px;
+        gelu_parts_pk(f32x2_t{v[e], v[e + 1]}, cdf, px);
+        v[e] *= cdf[0];
+        v[e + 1] *= cdf[1];
+      }
     } else if (act == VG_ACT_SILU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
@@ -182,7 +189,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   const int orig = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+  int mt = wg / ntn, nt = wg % ntn;
+  if (p.group_m > 0) {      // bands of group_m row-tiles, m fastest inside a band: the 32 tiles in flight on an XCD
+    const int gsz = p.group_m * ntn, gid = wg / gsz, first = gid * p.group_m;   // form a group_m x (32 / group_m)
+    const int gm = min(ntm - first, p.group_m), rem = wg - gid * gsz;           // block -> fewer distinct panels
+    mt = first + rem % gm;
+    nt = rem / gm;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
 
   const int kbeg = blockIdx.z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   // over the WN waves that share a fragment set: every block pays 1/ntn of the extra MFMAs.
   f32x4 csum[COLSUM ? TM : 1];
   bf16x8 ones;
-  const int cs_n = wg % ntn;
+  const int cs_n = nt;
   int cs_turn = 0, cs_wave = 0;             // kt % ntn and (kt / ntn) % WN, kept incrementally (no division per K-step)
   bool cs_any = false;
   if constexpr (COLSUM) {

@@ -24,6 +24,7 @@ struct GemmParams {
   float* split_ws;          // split-K slabs [splits][tiles][BM*BN] fp32 (in-launch reduction), or null: fp32 atomics
   int* split_cnt;           // [tiles] arrival counters, zeroed ahead of the launch
   int colsum_rr;            // 1: deal the row-sum MFMAs round-robin over the blocks of an m-panel
+  int group_m;              // > 0: tiles are walked m-fastest inside bands of group_m row-tiles (L2 blocking)
 };
 
 namespace vg_host {
