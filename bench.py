@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--comm", default="torch", choices=("torch", "abi"),
+                    help="gradient all-reduce through torch.distributed (nccl = RCCL) or through vg_allreduce_bucket")
     ap.add_argument("--graph", type=int, default=1, help="replay each micro-step as a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN, help="frames per sequence (BASELINE config 5: 2000)")
     ap.add_argument("--coalesce", type=int, default=1,
@@ -128,6 +130,7 @@ def main():
     hp.hip.precision = args.precision
     hp.hip.graph = bool(args.graph)
     hp.hip.coalesce_accumulation = bool(args.coalesce)
+    hp.hip.comm = args.comm
     torch.manual_seed(1234)
     trainer = LVTRTrainer(hp).to(device)
     if world > 1:

@@ -266,6 +266,22 @@ int vg_flow_bwd(const float* states, const float* wb, int64_t ldw, const float* 
                 const float* du, const float* dlogdet_sum, float* dz, float* dwb, float* dparams_partial,
                 int M, float eps, float hi, float lo, const int32_t* lengths, int T, vg_stream_t stream);
 
+/* ---------------------------------------------------------------- gradient exchange (RCCL)
+ * The one collective of the path: the mean of the gradients over the data-parallel ranks, which the reference
+ * gets from Lightning's DDP wrapper (training_lib/trainer.py:37-65 builds the strategy, the reduce happens inside
+ * manual_backward at trainers/speech/lvtr.py:144).  One process per GPU, one communicator per process.  Rank 0
+ * draws an id with vg_comm_unique_id and hands its VG_COMM_ID_BYTES bytes to the other ranks by any side channel
+ * (a torch.distributed store, a file, MPI); every rank then calls vg_comm_init with its current HIP device set.
+ * vg_allreduce_bucket reduces one flat gradient bucket IN PLACE on comm_stream (sum, or mean with average=1) and
+ * returns immediately; ordering against the producers / consumers of the bucket is by stream, like every other
+ * launch of this library.  RCCL is bound at run time (dlopen), so the library loads on a box without it. */
+enum { VG_COMM_ID_BYTES = 128 };
+int vg_comm_unique_id(void* out, int nbytes);
+int vg_comm_init(int rank, int world, const void* unique_id, int nbytes);
+int vg_comm_world(void);       /* ranks of the live communicator, 0 if none */
+int vg_allreduce_bucket(void* buf, int64_t n, int dtype, int average, vg_stream_t comm_stream);
+int vg_comm_destroy(void);
+
 /* ---------------------------------------------------------------- measurement hooks
  * Optional HIP-event timing of the GEMM / attention launches (bench.py's roofline
  * figure).  vg_prof_enable(1) clears and starts recording, vg_prof_enable(0)

@@ -72,3 +72,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(hipvg, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no fallback"):
         hipvg.lib()
+
+
+def test_comm_entry_points_fail_cleanly_without_a_communicator(built_lib):
+    """vg_allreduce_bucket before vg_comm_init is an error code + message, not a crash (no GPU needed: the
+    check precedes any use of the pointer)."""
+    import hipvg
+    lib = hipvg.lib()
+    assert lib.vg_comm_world() == 0
+    assert lib.vg_allreduce_bucket(ctypes.c_void_p(4096), 256, hipvg.VG_F32, 1, None) != 0
+    assert "vg_comm_init" in hipvg.last_error()
+    assert lib.vg_comm_init(3, 2, ctypes.c_void_p(4096), 128) != 0          # rank outside the world
+    assert lib.vg_comm_destroy() == 0                                         # nothing to destroy is fine

@@ -607,3 +607,32 @@ def test_attention_decode_append(F, dtype):
         ref = (torch.softmax(s, -1) @ v).reshape(D)
         torch.testing.assert_close(out[b].double(), ref, **tol(dtype))
     assert torch.equal(kc[:, 299], kref[:, 299])          # untouched rows stay untouched
+
+
+def test_rccl_bucket_allreduce_through_the_c_abi():
+    """vg_comm_unique_id / vg_comm_init / vg_allreduce_bucket / vg_comm_destroy on a one-rank communicator (two
+    ranks cannot share a device under RCCL): mean and sum over one rank leave fp32 and bf16 buckets unchanged, the
+    call is stream-ordered, and the reducer's 'abi' backend drives the same entry point."""
+    from hipvg import comm
+    from training_lib.dp import GradReducer
+    comm.init(0, 1)
+    assert comm.world() == 1
+    side = torch.cuda.Stream()
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn(3 * 256 * 1024 + 256, device=dev()).to(dtype)
+        ref = x.clone()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            comm.all_reduce_(x, average=True)
+            comm.all_reduce_(x, average=False)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(x, ref)
+    lin = torch.nn.Linear(512, 512).to(dev())
+    red = GradReducer(lin.parameters(), bucket_mb=0.5, comm="abi")
+    red.buckets[0]["flat"].fill_(3.0)
+    red._launch(red.buckets[0])
+    red.finish()
+    torch.cuda.synchronize()
+    assert float(red.buckets[0]["flat"].min()) == 3.0 and float(red.buckets[0]["flat"].max()) == 3.0
+    comm.destroy()
+    assert comm.world() == 0

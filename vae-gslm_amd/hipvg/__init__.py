@@ -76,6 +76,11 @@ SIGNATURES = {
     "vg_dwnorm_blocks": [_i],
     "vg_dwnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "vg_dwnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "vg_comm_unique_id": [_vp, _i],
+    "vg_comm_init": [_i, _i, _vp, _i],
+    "vg_comm_world": [],
+    "vg_allreduce_bucket": [_vp, _i64, _i, _i, _vp],
+    "vg_comm_destroy": [],
     "vg_prof_enable": [_i],
     "vg_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
 }

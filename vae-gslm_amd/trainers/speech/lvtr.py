@@ -78,7 +78,8 @@ class LVTRTrainer(BaseTrainer):
         hip = self.hp.get("hip", None)
         bucket = hip.get("bucket_mb", 50) if hip is not None else 50
         overlap = hip.get("overlap", True) if hip is not None else True
-        self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group)
+        comm = hip.get("comm", "torch") if hip is not None else "torch"
+        self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group, comm=comm)
         bind = getattr(self.optimizer, "bind", None)
         if callable(bind) and next(self.model.parameters()).is_cuda:
             bind(self.reducer)                 # AdamW + bf16 weight refresh + gradient clear: one launch per bucket

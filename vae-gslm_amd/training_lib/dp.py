@@ -31,10 +31,18 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 50.0,
-                 overlap: bool = True, group: Optional[dist.ProcessGroup] = None):
+                 overlap: bool = True, group: Optional[dist.ProcessGroup] = None, comm: str = "torch"):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # "torch": torch.distributed all_reduce (nccl = RCCL, or gloo in the CPU / one-device tests);
+        # "abi": RCCL through the library's own C entry points (vg_comm_init / vg_allreduce_bucket)
+        if comm not in ("torch", "abi"):
+            raise ValueError(f"hip.comm must be 'torch' or 'abi', got {comm!r}")
+        self.comm = comm
+        if comm == "abi" and self.world > 1:
+            from hipvg import comm as vg_comm
+            vg_comm.init(dist.get_rank(group), self.world, group)
         self.overlap = overlap
         self.sync_now = True           # set False on non-final micro-batches
         self._epoch = 0                # backward passes announced through new_backward()
@@ -123,6 +131,10 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def _allreduce(self, flat):
+        if self.comm == "abi":          # RCCL through the C ABI: stream-ordered on the current (comm) stream
+            from hipvg import comm as vg_comm
+            vg_comm.all_reduce_(flat, average=True)
+            return None
         backend = dist.get_backend(self.group)
         if backend == "nccl":
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
