@@ -71,13 +71,20 @@ def cpu_baseline(threads_note=True):
     t0 = time.perf_counter()
     one(T, 1)
     dt = time.perf_counter() - t0
+    steps = 1
     if dt * 5 < 40.0:
         T = SEQ_LEN
         t0 = time.perf_counter()
         one(T, 2)
         dt = time.perf_counter() - t0
-    return {"value": T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd, full config, B=1, T={T}, 1 step ({dt:.1f} s) after a warm-up"}
+        # aim at 10-30 s of timed CPU work: repeat the full-length step while the projection stays under ~25 s
+        more = max(0, min(6, int(20.0 / max(dt, 1e-3)) - 1))
+        for i in range(more):
+            one(T, 3 + i)
+        steps += more
+        dt = time.perf_counter() - t0
+    return {"value": steps * T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 fwd+bwd, full config, B=1, T={T}, {steps} step(s) ({dt:.1f} s) after a warm-up"}
 
 
 def main():
@@ -193,7 +200,8 @@ def main():
 
     if rank == 0:
         kinds = {}
-        tot_ms = tot_work = 0.0
+        tot_ms = tot_work = tot_bytes = 0.0
+        tot_n = 0
         for k in ("gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn", "gemm_f32", "attn_fwd", "attn_bwd"):
             ms, work, n = hipvg.prof_read(k)
             if n:
@@ -201,17 +209,19 @@ def main():
             if k.startswith("gemm_bf16"):
                 tot_ms += ms
                 tot_work += work
+                tot_bytes += hipvg.prof_read_bytes(k)
+                tot_n += n
         hipvg.prof_enable(False)
         achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
         # HBM-side bytes per launch of the same kernel family: bench.py cannot collect PMC counters itself, so
         # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
-        # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v3.json), valid for the default workload only
+        # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v9.json), valid for the default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v3.json")
-        if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16":
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v9.json")
+        if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16" and args.coalesce and not args.ragged:
             with open(pmc) as f:
                 traffic = json.load(f)["bf16_gemm_family"]["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01/pmc_traffic_v3.json (separate --pmc passes over the same command)"
+            traffic_src = "profiles/r01/pmc_traffic_v9.json (separate --pmc passes over the same command)"
         # 25,165,824 GEMM + 2*2*1024*(T+1)/2 attention FLOP per layer, 16 layers, + heads; x3
         flop_per_token = 3.0 * (16 * (25165824 + 2 * 2 * 1024 * (T_SEQ + 1) / 2) + 131072 + 5671936)
         line = {
@@ -230,6 +240,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_source": traffic_src,
+                         # operands and results once each, summed over the launches the figure above averages
+                         "algorithmic_bytes_per_launch": tot_bytes / tot_n if tot_n else None,
                          # register-fed v_mfma_f32_32x32x16_bf16 loop on this pool's MI355X (tools/lab/peak_probe.hip)
                          "peak_measured": 2136.0, "frac_of_measured": achieved / 2136.0,
                          "measured_on": ("one eager optimizer step right after the timed hipGraph replays"

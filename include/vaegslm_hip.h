@@ -291,6 +291,8 @@ enum { VG_PROF_GEMM_BF16_NT = 0, VG_PROF_GEMM_BF16_NN = 1, VG_PROF_GEMM_BF16_TN 
        VG_PROF_GEMM_F32 = 3, VG_PROF_ATTN_FWD = 4, VG_PROF_ATTN_BWD = 5 };
 int vg_prof_enable(int on);
 int vg_prof_read(int kind, double* total_ms, double* total_work, int* launches);
+/* summed ALGORITHMIC bytes (operands and results once each) of the recorded launches of one kind (GEMM kinds) */
+int vg_prof_read_bytes(int kind, double* total_bytes);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ def main():
     hipvg.lib()
     H = 16
     D = H * 64
-    for (B, T) in [(8, 250), (8, 500), (8, 1000), (4, 2000)]:
+    for (B, T) in [(8, 250), (8, 500), (8, 1000), (16, 1000), (4, 2000), (8, 2000)]:
         g = torch.Generator(device="cpu").manual_seed(0)
         qkv = torch.randn(B * T, 3 * D, generator=g).to(dev).bfloat16()
         dout = torch.randn(B * T, D, generator=g).to(dev).bfloat16()

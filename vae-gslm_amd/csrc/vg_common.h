@@ -284,7 +284,7 @@ namespace vg_host {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 // optional HIP-event timing (vg_prof.hip); kinds are the VG_PROF_* enum of the public header
-int prof_begin(int kind, double work, hipStream_t stream);
+int prof_begin(int kind, double work, hipStream_t stream, double bytes = 0.0);
 void prof_end(int token, hipStream_t stream);
 // out[n] += sum_m x[m][n] in one launch without workspace (vg_rows.hip; slow path of fused bias gradients)
 void colsum_accumulate(const void* x, int M, int N, long ld, float* out, int dtype, hipStream_t stream);

@@ -268,12 +268,24 @@ bool launch_thin(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_
   return true;
 }
 
+// algorithmic bytes of one product: both operands once, the result once (twice when it accumulates into C), every
+// optional M x N stream of the epilogue once
+double gemm_algorithmic_bytes(const GemmParams& p, int esz) {
+  const double mn = (double)p.M * p.N;
+  double b = ((double)p.M * p.K + (double)p.K * p.N) * esz + mn * (p.out_f32 ? 4 : esz) * (p.accumulate ? 2 : 1);
+  if (p.residual) b += mn * esz;
+  if (p.pre_add) b += mn * esz;
+  if (p.aux_in) b += mn * esz;
+  if (p.aux_out) b += mn * esz;
+  return b;
+}
+
 template <typename T>
 int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hipStream_t stream) {
   const int kind = sizeof(T) == 4 ? VG_PROF_GEMM_F32
                     : (a_tr ? VG_PROF_GEMM_BF16_TN : (b_tr ? VG_PROF_GEMM_BF16_NN : VG_PROF_GEMM_BF16_NT));
   if (sizeof(T) == 2 && tile_cfg > 0) {   // LDS-DMA pipelined variant (vg_gemm_dma.hip)
-    const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream);
+    const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream, gemm_algorithmic_bytes(p, sizeof(T)));
     const int rc = vg_host::gemm_dma_launch(p, a_tr, b_tr, tile_cfg, splits, stream);
     vg_host::prof_end(tok, stream);
     if (rc == 0) return vg_host::check_launch("vg_gemm(dma)");
@@ -300,7 +312,7 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done[ti][ki] = true;
   }
-  const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream);
+  const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream, gemm_algorithmic_bytes(p, sizeof(T)));
   hipLaunchKernelGGL(k, grid, block, lds, stream, p);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_gemm");

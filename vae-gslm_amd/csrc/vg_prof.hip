@@ -11,7 +11,7 @@
 #include "../../include/vaegslm_hip.h"
 
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double work; };
+struct Rec { hipEvent_t a, b; int kind; double work, bytes; };
 std::atomic<int> g_on{0};
 std::mutex g_mu;
 std::vector<Rec> g_recs;
@@ -27,11 +27,11 @@ hipEvent_t take_event() {
 }  // namespace
 
 namespace vg_host {
-int prof_begin(int kind, double work, hipStream_t stream) {
+int prof_begin(int kind, double work, hipStream_t stream, double bytes) {
   if (!g_on.load(std::memory_order_relaxed)) return -1;
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_recs.size() >= MAX_RECS) return -1;
-  Rec r{take_event(), take_event(), kind, work};
+  Rec r{take_event(), take_event(), kind, work, bytes};
   hipEventRecord(r.a, stream);
   g_recs.push_back(r);
   return (int)g_recs.size() - 1;
@@ -65,5 +65,15 @@ extern "C" int vg_prof_read(int kind, double* total_ms, double* total_work, int*
   if (total_ms) *total_ms = ms;
   if (total_work) *total_work = work;
   if (launches) *launches = n;
+  return 0;
+}
+
+// summed ALGORITHMIC bytes (operands and results once each) of the recorded launches of one kind
+extern "C" int vg_prof_read_bytes(int kind, double* total_bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  double bytes = 0.0;
+  for (auto& r : g_recs)
+    if (r.kind == kind) bytes += r.bytes;
+  if (total_bytes) *total_bytes = bytes;
   return 0;
 }

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vg_comm_destroy": [],
     "vg_prof_enable": [_i],
     "vg_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
+    "vg_prof_read_bytes": [_i, C.POINTER(C.c_double)],
 }
 
 PROF_KINDS = {"gemm_bf16_nt": 0, "gemm_bf16_nn": 1, "gemm_bf16_tn": 2, "gemm_f32": 3,
@@ -97,6 +98,13 @@ def prof_read(kind: str):
     ms, work, n = C.c_double(), C.c_double(), _i()
     lib().vg_prof_read(PROF_KINDS[kind], C.byref(ms), C.byref(work), C.byref(n))
     return ms.value, work.value, n.value
+
+
+def prof_read_bytes(kind: str) -> float:
+    """Summed algorithmic bytes (operands and results once each) of the recorded launches of one GEMM kind."""
+    b = C.c_double()
+    lib().vg_prof_read_bytes(PROF_KINDS[kind], C.byref(b))
+    return b.value
 
 _lib = None
 _lock = threading.Lock()
