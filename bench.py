@@ -102,6 +102,9 @@ def main():
                     help="1 (default, = hip.coalesce_accumulation of the yaml): the micro-batches of an accumulation "
                          "window (8 sequences x 2) run as ONE launch sequence over 16 sequences -- same samples, same "
                          "summed loss, same gradient and optimizer step, taller GEMMs; 0: one pass per micro-batch")
+    ap.add_argument("--host-batches", action="store_true",
+                    help="hand the step HOST batches: pinned memory -> asynchronous copies two steps ahead "
+                         "(training_lib.prefetch); the PCIe-inclusive rate quoted in DESIGN.md")
     ap.add_argument("--ragged", action="store_true",
                     help="sequence lengths ~ U{T/2..T} (right-padded batches, SURVEY 8d): shows the cost of masking; "
                          "tokens/s then counts valid frames only")
@@ -168,16 +171,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.host_batches:
+        from training_lib.prefetch import DevicePrefetcher, pin_batch
+        if args.graph:
+            trainer.enter_compute_stream(device)
+        host = [pin_batch(make_batch(B, T_SEQ, "cpu", seed=1234 + rank * 1000 + i, lengths=all_lens[i]))
+                for i in range(n_micro)]
+        feed = DevicePrefetcher(host, device)
+        fetch = lambda i: next(feed)
+    else:
+        fetch = lambda i: batches[i]
     it = 0
     for _ in range(args.warmup * accum):
-        trainer.training_step(batches[it], it)
+        trainer.training_step(fetch(it), it)
         it += 1
     sync()
     if not args.graph:
         hipvg.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps * accum):
-        out = trainer.training_step(batches[it], it)
+        out = trainer.training_step(fetch(it), it)
         it += 1
     sync()
     elapsed = time.perf_counter() - t0
@@ -236,6 +249,8 @@ def main():
                        "micro_batch": B, "grad_accum": accum, "seq_len": T_SEQ,
                        "parallelism": f"dp{world}", "loss": float(out["loss"]),
                        "lengths": "U{T/2..T}, valid frames counted" if args.ragged else "full",
+                       "inputs": ("pinned host batches, asynchronous H2D two steps ahead (PCIe inside the timed region)"
+                                  if args.host_batches else "resident in HBM before the timed region"),
                        "accumulation": "one launch sequence over B x accum sequences" if args.coalesce else "per micro-batch"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

@@ -145,3 +145,25 @@ def test_unsupported_paths_raise():
         get_norm_fn(8, Hparams(identifier="nope"))
     with pytest.raises(ValueError):
         get_activation(Hparams(identifier="nope"))
+
+
+def test_background_loader_order_and_errors():
+    """The worker-thread loader yields batches in order, keeps 'no padding' masks as such, and re-raises a
+    producer failure on the consumer side."""
+    from training_lib.prefetch import BackgroundLoader
+    from training_lib.synthetic import make_batch
+    got = list(BackgroundLoader(lambda i: make_batch(2, 16, "cpu", seed=i, lengths=[16, 9 + i]), 4, ahead=2, pin=False))
+    assert len(got) == 4
+    for i, b in enumerate(got):
+        ref = make_batch(2, 16, "cpu", seed=i, lengths=[16, 9 + i])
+        assert torch.equal(b["tokens"].value, ref["tokens"].value) and torch.equal(b["mel"].mask, ref["mel"].mask)
+        assert getattr(b["cropped_mel_utt"].mask, "_vg_full", False)
+
+    def bad(i):
+        if i == 1:
+            raise KeyError("broken sample")
+        return make_batch(1, 8, "cpu", seed=i)
+    it = BackgroundLoader(bad, 3, pin=False)
+    next(it)
+    with pytest.raises(KeyError):
+        next(it)

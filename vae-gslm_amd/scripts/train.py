@@ -37,6 +37,8 @@ def parse_args(argv=None):
     ap.add_argument("-v", "--version", type=str, default=None)
     ap.add_argument("-log", "--loglevel", type=str, default="info")
     ap.add_argument("--synthetic", action="store_true", help="force synthetic batches")
+    ap.add_argument("--device_batches", action="store_true",
+                    help="create the synthetic batches on the GPU instead of staging them through pinned host memory")
     ap.add_argument("--max_steps", type=int, default=None, help="optimizer steps to run")
     return ap.parse_args(argv)
 
@@ -84,8 +86,15 @@ def main(argv=None):
         os.makedirs(outdir, exist_ok=True)
         trainer.save_hparams(outdir)
     t0, frames = time.time(), 0
-    for it in range(total * accum):
-        batch = make_batch(B, T, device, seed=1234 + rank * 1000 + it)
+    if args.device_batches:
+        feed = (make_batch(B, T, device, seed=1234 + rank * 1000 + it) for it in range(total * accum))
+    else:   # host batches on a worker thread -> pinned memory -> asynchronous copies two steps ahead
+        from training_lib.prefetch import BackgroundLoader, DevicePrefetcher
+        if getattr(trainer, "use_graph", False):
+            trainer.enter_compute_stream(device)     # the copies synchronise with the stream the step runs on
+        feed = DevicePrefetcher(BackgroundLoader(lambda it: make_batch(B, T, "cpu", seed=1234 + rank * 1000 + it),
+                                                 total * accum), device)
+    for it, batch in enumerate(feed):
         out = trainer.training_step(batch, it)
         frames += B * T * world
         if rank == 0 and (it + 1) % (50 * accum) == 0:

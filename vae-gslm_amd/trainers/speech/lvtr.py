@@ -151,11 +151,13 @@ class LVTRTrainer(BaseTrainer):
 
     def training_step(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
         if self.use_graph and noise is None and os.environ.get("VG_GRAPH_OWN_STREAM", "1") != "0":
-            self._leave_null_stream(batch["mel"].value.device)
+            self.enter_compute_stream(batch["mel"].value.device)
         return self._training_step(batch, batch_idx, noise)
 
-    def _leave_null_stream(self, dev) -> None:
-        """hipGraph mode never launches on the null stream.  On ROCm 7.2 a graph launched on the null stream after
+    def enter_compute_stream(self, dev) -> None:
+        """(Called by ``training_step``; callers that stage inputs on other streams may call it first so that the
+        staging already synchronises with the stream the step will run on.)
+        hipGraph mode never launches on the null stream.  On ROCm 7.2 a graph launched on the null stream after
         a cross-stream hipStreamWaitEvent (what the reducer issues once world > 1) replays with corrupt kernel
         arguments -- reproduced in one process, DESIGN.md "hipGraph on the null stream"; on a created stream the
         same sequence is clean.  The calling thread is moved onto a stream the trainer owns, once (switching per

@@ -1,0 +1,135 @@
+"""Host -> HBM input pipeline for the training step.
+
+The reference feeds the step from ``DataLoader(pin_memory=...)`` worker processes and lets Lightning move each
+collated batch to the device right before ``training_step`` (``training_lib/trainer.py:37-65``; collate in
+``utils/helpers.py:80-135``).  Here the transfer is taken off the step's critical path: batches are staged in pinned
+host memory and copied on a dedicated HIP stream ``depth`` steps ahead, so the compute stream only ever waits on an
+event that fired long ago.  A frame is 81 floats + one int64 (332 B): 16 x 1000 frames are 5.3 MB, about 0.1 ms of
+PCIe time per 42 ms step.
+"""
+from __future__ import annotations
+
+import collections
+import queue
+import threading
+from typing import Iterable, Iterator, Mapping, Optional
+
+import torch
+
+from utils.tensormask import TensorMask
+
+
+def _pin(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_pinned() else t.pin_memory()
+
+
+def pin_batch(batch: Mapping) -> Mapping:
+    """Copy of a host batch whose tensors live in page-locked memory (what ``DataLoader(pin_memory=True)`` does)."""
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, TensorMask):
+            full = getattr(v.mask, "_vg_full", False)
+            out[k] = TensorMask(_pin(v.value), None if full else _pin(v.mask), axis=v.axis)
+        elif torch.is_tensor(v):
+            out[k] = _pin(v)
+        else:
+            out[k] = v
+    return out
+
+
+class DevicePrefetcher:
+    """Iterate device batches from an iterable of HOST batches (dicts of ``TensorMask`` / tensors).
+
+    ``depth`` batches are in flight on the copy stream at any time.  Each yielded tensor has been made safe for the
+    stream that is current at ``next()`` time (the consumer waits on the copy's event; the allocator is told about
+    the cross-stream use)."""
+
+    def __init__(self, host_batches: Iterable[Mapping], device, depth: int = 2):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DevicePrefetcher stages batches into HBM; it needs a GPU device")
+        self.depth = max(1, int(depth))
+        self._it: Iterator[Mapping] = iter(host_batches)
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._inflight = collections.deque()
+        self._done = False
+
+    def _to_device(self, t: torch.Tensor) -> torch.Tensor:
+        return _pin(t).to(self.device, non_blocking=True)
+
+    def _launch_one(self) -> bool:
+        try:
+            host = next(self._it)
+        except StopIteration:
+            self._done = True
+            return False
+        with torch.cuda.stream(self._stream):
+            dev = {}
+            for k, v in host.items():
+                if isinstance(v, TensorMask):
+                    full = getattr(v.mask, "_vg_full", False)
+                    dev[k] = TensorMask(self._to_device(v.value), None if full else self._to_device(v.mask),
+                                        axis=v.axis)
+                elif torch.is_tensor(v):
+                    dev[k] = self._to_device(v)
+                else:
+                    dev[k] = v
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        self._inflight.append((dev, ev, host))       # the pinned source stays alive until the copy is consumed
+        return True
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> Mapping:
+        while not self._done and len(self._inflight) < self.depth:
+            self._launch_one()
+        if not self._inflight:
+            raise StopIteration
+        dev, ev, _host = self._inflight.popleft()
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for v in dev.values():
+            for t in ((v.value, v.mask) if isinstance(v, TensorMask) else (v,)):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+        if not self._done:
+            self._launch_one()                        # keep the pipe full before handing the batch over
+        return dev
+
+
+class BackgroundLoader:
+    """Produce host batches on a worker thread (stand-in for the reference's DataLoader workers): ``make(i)`` returns
+    the i-th host batch; ``count`` batches are produced, at most ``ahead`` wait in the queue."""
+
+    def __init__(self, make, count: int, ahead: int = 4, pin: bool = True):
+        self._q: "queue.Queue[Optional[Mapping]]" = queue.Queue(maxsize=max(1, ahead))
+        self._err: Optional[BaseException] = None
+
+        def run():
+            # intra-op threading is a per-thread setting: left at the default, every tensor op of this thread spins
+            # up its own OpenMP team (128 threads on the GPU host: 33 ms per batch instead of 1 ms)
+            torch.set_num_threads(1)
+            try:
+                for i in range(count):
+                    b = make(i)
+                    self._q.put(pin_batch(b) if pin else b)
+            except BaseException as exc:              # surfaced on the consumer side
+                self._err = exc
+            finally:
+                self._q.put(None)
+
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> Mapping:
+        b = self._q.get()
+        if b is None:
+            if self._err is not None:
+                raise self._err
+            raise StopIteration
+        return b

@@ -23,7 +23,7 @@ def make_batch(batch_size: int, seq_len: int, device, seed: int, vocab: int = 20
         mask = None
     else:
         mask = torch.arange(seq_len)[None] < torch.as_tensor(lengths)[:, None]
-    dev = torch.device(device)
+    dev = torch.device(device)          # "cpu": a host batch for training_lib.prefetch.DevicePrefetcher
     mk = None if mask is None else mask.to(dev)
     return {"tokens": TensorMask(tokens.to(dev), mk),
             "mel": TensorMask(mel.to(dev), mk),
