@@ -62,6 +62,27 @@ def test_gemm_exact_small_integers(F, dtype, mode, K):
     assert torch.equal(out.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm_every_tile_shape_exact(F, cfg, mode):
+    """Every LDS-DMA tile configuration (64-deep 2/3-stage rings and the 32-deep 4-stage ring), forced through
+    tile_cfg, on shapes with ragged M / N edges, a K tail and more K tiles than stages: exact on small integers."""
+    M, N, K = 520, 392, 328
+    g = torch.Generator().manual_seed(9)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    ref = A @ B.T
+    Ad, Bd = A.to(dev()).bfloat16(), B.to(dev()).bfloat16()
+    if mode == "nt":
+        out = F.gemm(Ad, Bd, M, N, K, tile_cfg=cfg, out_f32=True)
+    elif mode == "nn":
+        out = F.gemm(Ad, Bd.T.contiguous(), M, N, K, b_tr=True, tile_cfg=cfg, out_f32=True)
+    else:
+        out = torch.zeros(M, N, device=dev())
+        F.gemm(Ad.T.contiguous(), Bd.T.contiguous(), M, N, K, a_tr=True, b_tr=True, out=out, split_k=3, tile_cfg=cfg)
+    assert torch.equal(out.float().cpu(), ref)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(F, dtype):
     B_, T = 2, 100

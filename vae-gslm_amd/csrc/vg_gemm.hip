@@ -348,7 +348,7 @@ int pick_cfg(const vg_gemm_desc* d) {
   if (d->a_tr && d->b_tr && d->colsum_out) cfg = 1;
   return cfg;
 }
-int cfg_tile_rows(int cfg) { return (cfg == 2 || cfg == 3 || cfg == 5) ? 256 : 128; }
+int cfg_tile_rows(int cfg) { return (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6) ? 256 : 128; }
 }  // namespace
 
 extern "C" int vg_gemm_tile_rows(const vg_gemm_desc* d) {
