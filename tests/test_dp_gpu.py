@@ -31,7 +31,7 @@ def _worker(rank, world, port, cfg, use_graph, out):
     from training_lib.synthetic import make_batch
     cfg = copy.deepcopy(cfg)
     cfg.setdefault("hip", {})
-    cfg["hip"].update(precision="bf16", graph=use_graph, bucket_mb=4)
+    cfg["hip"].update(precision="bf16", graph=use_graph, bucket_mb=4, graph_bucket_mb=4)
     torch.manual_seed(11)                      # same initial weights on every rank
     tr = LVTRTrainer(Hparams.from_dict(cfg)).to(dev)
     for p in tr.model.parameters():

@@ -77,6 +77,11 @@ class LVTRTrainer(BaseTrainer):
     def attach_reducer(self, group=None) -> GradReducer:
         hip = self.hp.get("hip", None)
         bucket = hip.get("bucket_mb", 50) if hip is not None else 50
+        if self.use_graph and hip is not None:
+            # hipGraph mode reduces the buckets back-to-back after the replay (nothing to overlap with), so fewer,
+            # larger messages are strictly better for the ring all-reduce; four buckets still let each bucket's
+            # AdamW launch run under the next bucket's all-reduce
+            bucket = hip.get("graph_bucket_mb", 256)
         overlap = hip.get("overlap", True) if hip is not None else True
         comm = hip.get("comm", "torch") if hip is not None else "torch"
         self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group, comm=comm)
