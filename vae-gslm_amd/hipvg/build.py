@@ -34,6 +34,20 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
+    # one builder at a time: the ranks of a multi-GPU launch import the package together, and a snapshot copy may
+    # not keep the library newer than its sources
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     cc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -50,10 +64,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + f".tmp{os.getpid()}"          # link beside the target, then rename: a reader never sees a partial file
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    os.replace(tmp, LIB)
     if verbose:
         print(f"[hipvg] built {LIB}", file=sys.stderr)
     return LIB
