@@ -342,6 +342,9 @@ int pick_cfg(const vg_gemm_desc* d) {
     const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     const long waves = (t256 + 255) / 256;
     if (t256 >= 224 && t256 * 100 >= waves * 256 * 85) cfg = 3;
+    // long-K forward products keep the 256x256 tile down to ~56 % of the CUs (M = 10240, the yaml's 2 x 8 x 640
+    // frames: FFN-out 112 us vs 127.5 (128x128) and 138.6 (256x128, 3 stages); K = 3072: 89.6 vs 100.7)
+    if (!d->b_tr && d->K >= 2048 && t256 >= 144 && t256 <= 256) cfg = 3;
   }
   static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
   if (cfg == 1 && !d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
