@@ -40,7 +40,7 @@ def main():
         ys = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(R)]
         for mode in ("NT", "NN"):
             row = []
-            for cfg in (1, 2, 3, 4, 5):
+            for cfg in [int(v) for v in os.environ.get("CFGS", "1,2,3,4,5").split(",")]:
                 if mode == "NT":
                     fns = [(lambda i=i: F.gemm(xs[i], ws[i], M, N, K, out=ys[i], tile_cfg=cfg)) for i in range(R)]
                 else:

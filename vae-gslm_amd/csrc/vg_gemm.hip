@@ -331,27 +331,34 @@ int pick_cfg(const vg_gemm_desc* d) {
                       (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7ffffff0L;
   if (!dma_ok) return -1;
   if (cfg != 0) return cfg;
-  // measured on MI355X on cold operands (tools/tile_cold_sweep.py, tools/gemm_rotate.py; M = 8000 and 16000):
-  // forward / dgrad products take 256x256 tiles whenever those fill the 256 CUs in whole waves (>= 224 tiles,
-  // >= 85 % of the last wave used: 10-25 % faster than 128x128, whose operand feed is the CU's whole L1->LDS
-  // and LDS read bandwidth), otherwise 128x128; the long-K / narrow-N forward product that cannot fill the
-  // machine with 256x256 (FFN down-projection at M = 8000) takes 256x128 with a 3-stage ring (VG_CFG_LONGK
-  // overrides, 0 = 128x256).  Weight gradients: 128x128 + split-K (tools/wgrad_cold_sweep.py).
+  // Forward / dgrad products: the tile shape with the least estimated time among 128x128 (two blocks per CU),
+  // 256x256 and 192x256 (one block per CU; 192 rows only exist for a row-image A).  A launch runs in rounds of
+  // 256 x blocks-per-CU tiles; a round costs its tile area (a K-step is bound by the operand fill, which scales
+  // with the area a CU works on) times a measured per-shape factor, and a partly filled last round is a little
+  // cheaper (fewer CUs share the memory system).  Calibrated on cold operands at M = 5120 / 8000 / 10240 / 16000
+  // (tools/tile_cold_sweep.py with CFGS=1,3,9; tools/gemm_rotate.py): e.g. the N = 1024 products of the yaml's own
+  // step shape (M = 2 x 8 x 640 = 10240) take 192x256 -- 216 tiles on 256 CUs instead of 160 -- and run 17-20 %
+  // faster than either square tile; M = 16000 keeps 256x256 (252 tiles), M = 8000 keeps 128x128 (504).
+  // Weight gradients: 128x128 + split-K (tools/wgrad_cold_sweep.py).
   cfg = 1;
   if (!d->a_tr) {
-    const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    const long waves = (t256 + 255) / 256;
-    if (t256 >= 224 && t256 * 100 >= waves * 256 * 85) cfg = 3;
-    // long-K forward products keep the 256x256 tile down to ~56 % of the CUs (M = 10240, the yaml's 2 x 8 x 640
-    // frames: FFN-out 112 us vs 127.5 (128x128) and 138.6 (256x128, 3 stages); K = 3072: 89.6 vs 100.7)
-    if (!d->b_tr && d->K >= 2048 && t256 >= 144 && t256 <= 256) cfg = 3;
+    auto cost = [&](int rows, int cols, int per_cu, double shape) {
+      const long tiles = (long)((d->M + rows - 1) / rows) * ((d->N + cols - 1) / cols), slots = 256L * per_cu;
+      const long full = tiles / slots, rem = tiles % slots;
+      const double rounds = (double)full + (rem ? 0.85 + 0.15 * (double)rem / (double)slots : 0.0);
+      return rounds * rows * cols * per_cu * shape;
+    };
+    const double longk_pen = 0.10 * fmin(1.0, fmax(0.0, (d->K - 1024) / 3072.0));   // 128x128 falls behind at long K
+    const double c1 = cost(128, 128, 2, 1.08 + longk_pen), c3 = cost(256, 256, 1, 1.0), c9 = cost(192, 256, 1, 0.97);
+    cfg = c3 <= c1 ? 3 : 1;
+    if (c9 < 0.95 * fmin(c1, c3)) cfg = 9;      // the odd shape must win clearly (model error ~5 %)
   }
   static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
   if (cfg == 1 && !d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
   if (d->a_tr && d->b_tr && d->colsum_out) cfg = 1;
   return cfg;
 }
-int cfg_tile_rows(int cfg) { return (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6) ? 256 : 128; }
+int cfg_tile_rows(int cfg) { return cfg == 9 ? 192 : (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6) ? 256 : 128; }
 }  // namespace
 
 extern "C" int vg_gemm_tile_rows(const vg_gemm_desc* d) {

@@ -653,6 +653,9 @@ int launch_mode(const GemmParams& p, int cfg, int splits, hipStream_t stream) {
     case 4: return launch_cfg<A_TR, B_TR, 128, 256, 2, 4>(p, splits, stream);
     case 5: return launch_cfg<A_TR, B_TR, 256, 128, 4, 2, 3>(p, splits, stream);   // 3-stage ring (144 KiB LDS)
     case 6: return launch_cfg32<A_TR, B_TR, 256, 256, 2, 4>(p, splits, stream);     // 32-deep tiles, 4 stages
+    case 9:                                                                          // 192 rows: row-image A only
+      if constexpr (!A_TR) return launch_cfg<A_TR, B_TR, 192, 256, 2, 4>(p, splits, stream);
+      else return -1;
     case 7: return launch_cfg32<A_TR, B_TR, 128, 128, 2, 2>(p, splits, stream);
     default: return -1;
   }
