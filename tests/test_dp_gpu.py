@@ -53,6 +53,9 @@ def _worker(rank, world, port, cfg, use_graph, out):
     finite = bool(torch.isfinite(flat).all()) and bool(torch.isfinite(outp["loss"]))
     graphed = (not use_graph) or len(tr._graphs) == 1
     out[rank] = (same, moved, finite, graphed)
+    if rank == 0:
+        out["params"] = flat.cpu()
+        out["segmented"] = bool(getattr(tr, "_segmented", False)) and len(tr._early_buckets) >= 1
     dist.destroy_process_group()
 
 
@@ -65,7 +68,25 @@ def test_two_rank_training_on_gpu(full_cfg, use_graph):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), cfg, use_graph, out), nprocs=world, join=True)
-    assert dict(out) == {0: (True, True, True, True), 1: (True, True, True, True)}
+    assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True)
+    assert out["segmented"] == use_graph          # two ranks + hipGraph mode: the two-graph replay is the default
+
+
+def test_two_rank_segmented_replay_matches_one_graph(full_cfg, monkeypatch):
+    """Data parallel over two ranks, hipGraph mode: reducing the upper half's buckets between the two graphs must
+    end where reducing everything after a single graph ends (a bucket sent too early would carry partial sums)."""
+    from oracle.lvtr_oracle import small_config
+    cfg = copy.deepcopy(full_cfg)
+    cfg["model"] = small_config(full_cfg["model"])
+    finals = {}
+    for seg in ("2", "1"):
+        monkeypatch.setenv("VG_GRAPH_SEGMENTS", seg)
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), cfg, True, out), nprocs=2, join=True)
+        assert out[0] == (True, True, True, True) and out["segmented"] == (seg == "2")
+        finals[seg] = out["params"]
+    torch.testing.assert_close(finals["2"], finals["1"], rtol=0.0, atol=4e-3)
 
 
 def test_bench_two_ranks_full_model_one_device():

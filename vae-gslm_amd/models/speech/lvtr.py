@@ -165,6 +165,14 @@ class LVTR(nn.Module):
         # ---- posterior q(z | mel): conv encoder (stock ops) -> fused head + reparameterisation
         with _side_autocast():
             enc = self.encoder[0](mel)
+        # optional backward cuts (set by the trainer; see LVTRTrainer._graphed_micro_step): below Transformer layer
+        # `grad_cut_layer`, below the fused (token, z) input and below the reparameterised sample.  Each entry is
+        # (tensors with tape, detached leaves used downstream); the backward of the part above a cut leaves its
+        # gradient in the leaves, and every piece of tape is walked exactly once.
+        self.grad_cuts = []
+        stack = self.transformer[0]
+        stack.grad_cut_layer, stack.grad_cuts = None, self.grad_cuts
+        cutting = getattr(self, "grad_cut_layer", None) is not None and torch.is_grad_enabled()
         q_head = self.encoder[1]
         if q_head.plain:
             mu_ls_q = q_head.project(enc.value.float())
@@ -177,10 +185,20 @@ class LVTR(nn.Module):
             eps_q = torch.randn(B, T, D, device=mel.device)
         z2, lq2 = HF.reparameterize(mu_q.reshape(-1, D), ls_q.reshape(-1, D), eps_q.reshape(-1, D),
                                     1.0, lens, T)
+        cutting = cutting and z2.requires_grad
+        if cutting:
+            leaves = (z2.detach().requires_grad_(True), lq2.detach().requires_grad_(True))
+            self.grad_cuts.append(((z2, lq2), leaves))
+            z2, lq2 = leaves
+            stack.grad_cut_layer = int(self.grad_cut_layer)
         sample_q = TensorMask(z2.view(B, T, D), mask)
         log_q = TensorMask(lq2.view(B, T, D), mask)
         # ---- shift right by one frame, prior network
         fused = self.fuse_inputs(sample_q, tokens)
+        if cutting:
+            leaf = fused.value.detach().requires_grad_(True)
+            self.grad_cuts.append(((fused.value,), (leaf,)))
+            fused = TensorMask(leaf, fused.mask)
         init = noise.get("init_state")
         if init is None:
             init = self.initial_state(B, mel.device)

@@ -137,7 +137,14 @@ class TransformerLayerStack(nn.Module):
         layer_outs = []
         if fast:
             slopes = _slopes_from((self.rpe_id, self.rpe), None, x2.device).slopes
-            for layer in self.layers:
+            cut = getattr(self, "grad_cut_layer", None)
+            for l, layer in enumerate(self.layers):
+                if cut is not None and l == cut and torch.is_grad_enabled() and x2.requires_grad:
+                    # backward cut (trainers.speech.lvtr: segmented hipGraph replay): the tape stops at this leaf;
+                    # the trainer later feeds its gradient into the tape of the layers below
+                    leaf = x2.detach().requires_grad_(True)
+                    self.grad_cuts.append(((x2,), (leaf,)))
+                    x2 = leaf
                 x2 = layer.forward_2d(x2, B, T, lens, slopes)
                 layer_outs.append(TensorMask(x2.view(B, T, D), mask))
         else:

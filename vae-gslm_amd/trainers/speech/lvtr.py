@@ -84,7 +84,44 @@ class LVTRTrainer(BaseTrainer):
             bucket = hip.get("graph_bucket_mb", 256)
         overlap = hip.get("overlap", True) if hip is not None else True
         comm = hip.get("comm", "torch") if hip is not None else "torch"
-        self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group, comm=comm)
+        # Segmented replay (hipGraph mode, more than one rank): the micro-step is captured as TWO graphs cut below
+        # Transformer layer `graph_cut_layer` (with two more cuts near the input so that every piece of the autograd
+        # tape is walked once): after the first graph the gradients of everything above the cut are final and their
+        # buckets go on the wire while the second graph runs the rest of backward.
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        cut = hip.get("graph_cut_layer", "auto") if hip is not None else None
+        stack = self.model.transformer[0]
+        nl = len(stack.layers)
+        if os.environ.get("VG_GRAPH_CUT"):           # lab override
+            cut = int(os.environ["VG_GRAPH_CUT"])
+        if cut == "auto":
+            # forced on one rank (VG_GRAPH_SEGMENTS=force, full model, 16 layers) the second graph is free when the
+            # cut is at layer 12, 14 or 15 (41.76 / 41.91 / 41.79 vs 41.70 ms per step) and costs 1.0-1.2 ms at 10,
+            # 8, 4 or 1: three quarters up
+            cut = max(1, (3 * nl) // 4)
+        seg_env = os.environ.get("VG_GRAPH_SEGMENTS", "2")       # "1": one graph; "force": two graphs on one rank too
+        self._segmented = bool(self.use_graph and (world > 1 or seg_env == "force") and cut is not None
+                               and 0 < int(cut or 0) < nl and seg_env != "1")
+        boundaries = ()
+        if self._segmented:
+            self._cut_layer = int(cut)
+            boundaries = (list(stack.layers[self._cut_layer - 1].parameters())[-1],)   # bucket break at the cut
+        self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group, comm=comm,
+                                   boundaries=boundaries)
+        self._early_buckets = []
+        if self._segmented:
+            m = self.model
+            above = [p for mod in (m.decoder, m.utterance_encoder, m.transformer_flow, m.transformer[1],
+                                   stack.final_norm, getattr(stack, "out", None), m.q_spliter, m.token_spliter,
+                                   m.token_predictor) if mod is not None for p in mod.parameters()]
+            for layer in stack.layers[self._cut_layer:]:
+                above += list(layer.parameters())
+            self._early_buckets = self.reducer.buckets_within(above)
+            if self._early_buckets:
+                self.model.grad_cut_layer = self._cut_layer
+            else:
+                self._segmented = False
         bind = getattr(self.optimizer, "bind", None)
         if callable(bind) and next(self.model.parameters()).is_cuda:
             bind(self.reducer)                 # AdamW + bf16 weight refresh + gradient clear: one launch per bucket
@@ -102,8 +139,16 @@ class LVTRTrainer(BaseTrainer):
         return w
 
     # ------------------------------------------------------------ one micro-batch
+    def _backward_tail(self) -> None:
+        """Backward of the parts below the model's backward cuts (none unless ``model.grad_cut_layer`` is set): the
+        gradient left in each cut's leaf is fed into the tape below it, deepest cut last."""
+        for below, leaves in reversed(getattr(self.model, "grad_cuts", [])):
+            pairs = [(t, l.grad) for t, l in zip(below, leaves) if l.grad is not None]
+            if pairs:
+                torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+
     def _training_loop(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None,
-                       kld_weight=None):
+                       kld_weight=None, backward_tail: bool = True):
         if kld_weight is None:
             kld_weight = self.current_kld_weight()
         kwargs = {}
@@ -126,6 +171,8 @@ class LVTRTrainer(BaseTrainer):
         if self.reducer is not None:
             self.reducer.new_backward()
         loss.backward()
+        if backward_tail:
+            self._backward_tail()
         result = {"kld": kld.detach(), "rec_loss": rec.detach(), "log_p": -out["log_p"].mean().detach(),
                   "length": out["log_p"].length.sum(), "kld_weight": kld_weight,
                   "logstd": out["logstd"].detach(), "q_logstd": out["q_logstd"].detach(),
@@ -282,13 +329,23 @@ class LVTRTrainer(BaseTrainer):
             graph = torch.cuda.CUDAGraph()
             if getattr(self, "_graph_pool", None) is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
+            graph2 = None
             try:
-                with torch.cuda.graph(graph, pool=self._graph_pool):
-                    out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
+                if getattr(self, "_segmented", False):
+                    with torch.cuda.graph(graph, pool=self._graph_pool):
+                        out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev, backward_tail=False)
+                    graph2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph2, pool=self._graph_pool):
+                        self._backward_tail()
+                else:
+                    with torch.cuda.graph(graph, pool=self._graph_pool):
+                        out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
             except Exception as exc:      # e.g. another library touching the device mid-capture: run eagerly instead
                 import warnings
                 warnings.warn(f"hipGraph capture of the micro-step failed ({exc!r}); continuing with eager launches")
                 self.use_graph = False
+                self._segmented = False
+                self.model.grad_cut_layer = None     # eager launches report gradients as they complete: no cuts
                 torch.cuda.synchronize()
                 if self.reducer is not None:
                     self.reducer.zero_grad()
@@ -296,15 +353,20 @@ class LVTRTrainer(BaseTrainer):
                 return self._training_loop(batch, batch_idx, None)
             if self.reducer is not None:
                 self.reducer.zero_grad()               # capture does not execute; start from clean buckets
-            ent = self._graphs[key] = (graph, static, out)
-        graph, static, out = ent
+            ent = self._graphs[key] = (graph, static, out, graph2)
+        graph, static, out, graph2 = ent
         for k, v in batch.items():
             static[k].value.copy_(v.value, non_blocking=True)
             if static[k].mask is not v.mask and not getattr(static[k].mask, "_vg_full", False):
                 static[k].mask.copy_(v.mask, non_blocking=True)
                 static[k].mask._vg_len32 = None
         graph.replay()
-        if last and self.reducer is not None and self.reducer.world > 1:
+        reduce_now = last and self.reducer is not None and self.reducer.world > 1
+        if graph2 is not None:
+            if reduce_now:
+                self.reducer.reduce_buckets(self._early_buckets)   # final already: on the wire under the second graph
+            graph2.replay()
+        if reduce_now:
             self.reducer.reduce_all()
         res = dict(out)
         res["kld_weight"] = self.current_kld_weight()

@@ -31,7 +31,8 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 50.0,
-                 overlap: bool = True, group: Optional[dist.ProcessGroup] = None, comm: str = "torch"):
+                 overlap: bool = True, group: Optional[dist.ProcessGroup] = None, comm: str = "torch",
+                 boundaries=()):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -54,9 +55,10 @@ class GradReducer:
         # 256-element chunks that must not straddle two parameters (per-group lr / weight decay).
         self.buckets: List[dict] = []
         cur, cur_n = [], 0
+        breaks = {id(p) for p in boundaries}     # a bucket ends before each of these (walking in reverse order)
         for p in reversed(self.params):
             n = self._padded(p.numel())
-            if cur and cur_n + n > limit:
+            if cur and (cur_n + n > limit or id(p) in breaks):
                 self._close(cur, cur_n, dev)
                 cur, cur_n = [], 0
             cur.append(p)
@@ -144,10 +146,24 @@ class GradReducer:
         return None
 
     def reduce_all(self) -> None:
-        """Launch the all-reduce of every bucket now (used when backward ran inside a hipGraph)."""
+        """Launch the all-reduce of every bucket not yet on the wire (used when backward ran inside a hipGraph)."""
         if self.world > 1:
             for b in self.buckets:
-                self._launch(b)
+                if not b.get("launched", False):
+                    self._launch(b)
+
+    def reduce_buckets(self, indices) -> None:
+        """Launch the all-reduce of the given buckets only (their gradients are final although backward is not:
+        segmented hipGraph replay)."""
+        if self.world > 1:
+            for i in indices:
+                if not self.buckets[i].get("launched", False):
+                    self._launch(self.buckets[i])
+
+    def buckets_within(self, params) -> List[int]:
+        """Indices of the buckets all of whose parameters are in ``params``."""
+        ids = {id(p) for p in params}
+        return [i for i, b in enumerate(self.buckets) if all(id(p) in ids for p in b["params"])]
 
     def finish(self) -> None:
         """Call after the last backward of the window, before ``optimizer.step()``."""
