@@ -190,7 +190,8 @@ class LVTR(nn.Module):
             leaves = (z2.detach().requires_grad_(True), lq2.detach().requires_grad_(True))
             self.grad_cuts.append(((z2, lq2), leaves))
             z2, lq2 = leaves
-            stack.grad_cut_layer = int(self.grad_cut_layer)
+            cl = self.grad_cut_layer
+            stack.grad_cut_layer = tuple(int(c) for c in cl) if isinstance(cl, (list, tuple)) else (int(cl),)
         sample_q = TensorMask(z2.view(B, T, D), mask)
         log_q = TensorMask(lq2.view(B, T, D), mask)
         # ---- shift right by one frame, prior network

@@ -139,7 +139,7 @@ class TransformerLayerStack(nn.Module):
             slopes = _slopes_from((self.rpe_id, self.rpe), None, x2.device).slopes
             cut = getattr(self, "grad_cut_layer", None)
             for l, layer in enumerate(self.layers):
-                if cut is not None and l == cut and torch.is_grad_enabled() and x2.requires_grad:
+                if cut is not None and l in cut and torch.is_grad_enabled() and x2.requires_grad:
                     # backward cut (trainers.speech.lvtr: segmented hipGraph replay): the tape stops at this leaf;
                     # the trainer later feeds its gradient into the tape of the layers below
                     leaf = x2.detach().requires_grad_(True)

@@ -84,42 +84,48 @@ class LVTRTrainer(BaseTrainer):
             bucket = hip.get("graph_bucket_mb", 256)
         overlap = hip.get("overlap", True) if hip is not None else True
         comm = hip.get("comm", "torch") if hip is not None else "torch"
-        # Segmented replay (hipGraph mode, more than one rank): the micro-step is captured as TWO graphs cut below
-        # Transformer layer `graph_cut_layer` (with two more cuts near the input so that every piece of the autograd
-        # tape is walked once): after the first graph the gradients of everything above the cut are final and their
-        # buckets go on the wire while the second graph runs the rest of backward.
+        # Segmented replay (hipGraph mode, more than one rank): the micro-step is captured as several graphs cut
+        # below the Transformer layers `graph_cut_layer` (with two more cuts near the input so that every piece of
+        # the autograd tape is walked once): after each graph the gradients of everything above its cut are final and
+        # their buckets go on the wire while the next graph runs more of backward.
         import torch.distributed as dist
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         cut = hip.get("graph_cut_layer", "auto") if hip is not None else None
         stack = self.model.transformer[0]
         nl = len(stack.layers)
-        if os.environ.get("VG_GRAPH_CUT"):           # lab override
-            cut = int(os.environ["VG_GRAPH_CUT"])
+        if os.environ.get("VG_GRAPH_CUT"):           # lab override: one layer or a comma-separated list
+            cut = [int(v) for v in os.environ["VG_GRAPH_CUT"].split(",")]
         if cut == "auto":
-            # forced on one rank (VG_GRAPH_SEGMENTS=force, full model, 16 layers) the second graph is free when the
-            # cut is at layer 12, 14 or 15 (41.76 / 41.91 / 41.79 vs 41.70 ms per step) and costs 1.0-1.2 ms at 10,
-            # 8, 4 or 1: three quarters up
-            cut = max(1, (3 * nl) // 4)
-        seg_env = os.environ.get("VG_GRAPH_SEGMENTS", "2")       # "1": one graph; "force": two graphs on one rank too
-        self._segmented = bool(self.use_graph and (world > 1 or seg_env == "force") and cut is not None
-                               and 0 < int(cut or 0) < nl and seg_env != "1")
+            # Forced on one rank (VG_GRAPH_SEGMENTS=force, full model, 16 layers, 42.05 ms per step with one graph):
+            # further graphs are free as long as the FIRST one stays short -- cuts at 12 / 12,8 / 13,10,7 /
+            # 14,12,10,8: 42.05 / 41.95 / 41.94 / 42.04 ms -- while a first graph that reaches down to layer 10 or
+            # lower costs 1.0-1.2 ms (cut at 10, 8, 4, 1 alone).  Quarter points, top one first.
+            cut = [(3 * nl) // 4, nl // 2, nl // 4]
+        cuts = [] if cut is None else sorted({int(c) for c in (cut if isinstance(cut, (list, tuple)) else [cut])},
+                                             reverse=True)
+        cuts = [c for c in cuts if 0 < c < nl]
+        seg_env = os.environ.get("VG_GRAPH_SEGMENTS", "2")       # "1": one graph; "force": segmented on one rank too
+        self._segmented = bool(self.use_graph and (world > 1 or seg_env == "force") and cuts and seg_env != "1")
         boundaries = ()
-        if self._segmented:
-            self._cut_layer = int(cut)
-            boundaries = (list(stack.layers[self._cut_layer - 1].parameters())[-1],)   # bucket break at the cut
+        if self._segmented:     # a bucket ends at every cut
+            boundaries = tuple(list(stack.layers[c - 1].parameters())[-1] for c in cuts)
         self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group, comm=comm,
                                    boundaries=boundaries)
-        self._early_buckets = []
+        self._cut_layers, self._early_buckets = [], []
         if self._segmented:
             m = self.model
             above = [p for mod in (m.decoder, m.utterance_encoder, m.transformer_flow, m.transformer[1],
                                    stack.final_norm, getattr(stack, "out", None), m.q_spliter, m.token_spliter,
                                    m.token_predictor) if mod is not None for p in mod.parameters()]
-            for layer in stack.layers[self._cut_layer:]:
-                above += list(layer.parameters())
-            self._early_buckets = self.reducer.buckets_within(above)
-            if self._early_buckets:
-                self.model.grad_cut_layer = self._cut_layer
+            top = nl
+            for c in cuts:          # after graph k the parameters above cut k are final
+                for layer in stack.layers[c:top]:
+                    above += list(layer.parameters())
+                top = c
+                self._early_buckets.append(self.reducer.buckets_within(above))
+            self._cut_layers = cuts
+            if self._early_buckets[0]:
+                self.model.grad_cut_layer = tuple(cuts)
             else:
                 self._segmented = False
         bind = getattr(self.optimizer, "bind", None)
@@ -139,10 +145,16 @@ class LVTRTrainer(BaseTrainer):
         return w
 
     # ------------------------------------------------------------ one micro-batch
-    def _backward_tail(self) -> None:
+    def _backward_tail(self, segment: Optional[int] = None) -> None:
         """Backward of the parts below the model's backward cuts (none unless ``model.grad_cut_layer`` is set): the
-        gradient left in each cut's leaf is fed into the tape below it, deepest cut last."""
-        for below, leaves in reversed(getattr(self.model, "grad_cuts", [])):
+        gradient left in each cut's leaves is fed into the tape below it, deepest cut last.  ``segment`` k runs only
+        the piece that belongs to graph k + 2 of a segmented replay: the k-th Transformer cut from the top, and with
+        the last one the cuts near the input."""
+        cuts = list(reversed(getattr(self.model, "grad_cuts", [])))      # top Transformer cut first ... z last
+        if segment is not None:
+            n = len(self._cut_layers)
+            cuts = cuts[segment:segment + 1] if segment < n - 1 else cuts[n - 1:]
+        for below, leaves in cuts:
             pairs = [(t, l.grad) for t, l in zip(below, leaves) if l.grad is not None]
             if pairs:
                 torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
@@ -334,9 +346,12 @@ class LVTRTrainer(BaseTrainer):
                 if getattr(self, "_segmented", False):
                     with torch.cuda.graph(graph, pool=self._graph_pool):
                         out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev, backward_tail=False)
-                    graph2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph2, pool=self._graph_pool):
-                        self._backward_tail()
+                    graph2 = []
+                    for k in range(len(self._cut_layers)):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=self._graph_pool):
+                            self._backward_tail(k)
+                        graph2.append(g)
                 else:
                     with torch.cuda.graph(graph, pool=self._graph_pool):
                         out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
@@ -363,9 +378,10 @@ class LVTRTrainer(BaseTrainer):
         graph.replay()
         reduce_now = last and self.reducer is not None and self.reducer.world > 1
         if graph2 is not None:
-            if reduce_now:
-                self.reducer.reduce_buckets(self._early_buckets)   # final already: on the wire under the second graph
-            graph2.replay()
+            for k, g in enumerate(graph2):
+                if reduce_now:     # final already: on the wire under the next graph
+                    self.reducer.reduce_buckets(self._early_buckets[k])
+                g.replay()
         if reduce_now:
             self.reducer.reduce_all()
         res = dict(out)
