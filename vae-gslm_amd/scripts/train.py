@@ -54,11 +54,18 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("scripts.train needs an MI355X GPU: the HIP hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # functional dry run of the multi-rank path on a one-GPU box: VG_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # exchanges gradients over gloo (same switch as bench.py; real runs use one GPU per rank and RCCL)
+    one_dev = os.environ.get("VG_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
 
     module_name, cls_name = hp.trainer.identifier.rsplit(".", 1)
