@@ -266,6 +266,21 @@ int vg_flow_bwd(const float* states, const float* wb, int64_t ldw, const float* 
                 const float* du, const float* dlogdet_sum, float* dz, float* dwb, float* dparams_partial,
                 int M, float eps, float hi, float lo, const int32_t* lengths, int T, vg_stream_t stream);
 
+/* ---------------------------------------------------------------- input fusion of the training step
+ * out[m][E] (fp32) = mask(E[ids[m]]) + relu(Wf z[m] + bf): Embedding.forward (modules/linear/layers.py:150-152,
+ * masked) + token_fuser Linear(D -> E) + ReLU (:184-193, not masked) + LVTR.fuse_inputs
+ * (models/speech/lvtr.py:390-392).  ids int64 [M], z fp32 [M][ldz] (D <= 8 columns used), emb [vocab][E],
+ * Wf [E][D], bf [E] or NULL.  Backward: demb[vocab][E] += mask(dout) (fp32 atomics; NULL to skip),
+ * dz[m][0..D) = Wf^T (dout * (pre > 0)) (NULL to skip), part[vg_embed_fuse_blocks(M)][E][D+1] = per-block
+ * partial sums of (dWf | dbf), to be folded by vg_colsum. */
+int vg_embed_fuse_blocks(int M);
+int vg_embed_fuse_fwd(const int64_t* ids, const float* z, int64_t ldz, const float* emb, int vocab, int E,
+                      const float* wf, const float* bf, int D, const int32_t* lengths, int T, float* out, int M,
+                      vg_stream_t stream);
+int vg_embed_fuse_bwd(const float* dout, const int64_t* ids, const float* z, int64_t ldz, int vocab, int E,
+                      const float* wf, const float* bf, int D, const int32_t* lengths, int T, float* demb, float* dz,
+                      int64_t lddz, float* part, int M, vg_stream_t stream);
+
 /* ---------------------------------------------------------------- gradient exchange (RCCL)
  * The one collective of the path: the mean of the gradients over the data-parallel ranks, which the reference
  * gets from Lightning's DDP wrapper (training_lib/trainer.py:37-65 builds the strategy, the reduce happens inside

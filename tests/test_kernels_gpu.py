@@ -657,3 +657,28 @@ def test_rccl_bucket_allreduce_through_the_c_abi():
     assert float(red.buckets[0]["flat"].min()) == 3.0 and float(red.buckets[0]["flat"].max()) == 3.0
     comm.destroy()
     assert comm.world() == 0
+
+
+def test_embed_fuse_train_matches_stock_modules(F):
+    """vg_embed_fuse_fwd / _bwd against Embedding (masked) + Linear(4 -> 64) + ReLU (not masked) + add in stock
+    PyTorch: output, d z, and the gradients of the table, Wf and bf; ragged lengths incl. an empty sequence."""
+    B, T, D, E, V = 3, 70, 4, 64, 200
+    g = torch.Generator().manual_seed(31)
+    ids = torch.randint(0, V, (B, T), generator=g).to(dev())
+    z = torch.randn(B, T, D, generator=g).to(dev()).requires_grad_(True)
+    emb = torch.nn.Parameter((torch.rand(V, E, generator=g) * 2 - 1).to(dev()))
+    wf = torch.nn.Parameter((torch.randn(E, D, generator=g) * 0.5).to(dev()))
+    bf = torch.nn.Parameter((torch.randn(E, generator=g) * 0.3).to(dev()))
+    lens = torch.tensor([70, 0, 33], dtype=torch.int32, device=dev())
+    mask = (torch.arange(T, device=dev())[None] < lens[:, None])
+    dout = torch.randn(B * T, E, generator=g).to(dev())
+    ref = torch.nn.functional.embedding(ids, emb) * mask[..., None] + torch.relu(z @ wf.T + bf)
+    ref.reshape(-1, E).backward(dout)
+    want = [t.grad.clone() for t in (z, emb, wf, bf)]
+    for t in (z, emb, wf, bf):
+        t.grad = None
+    out = F.embed_fuse_train(ids.reshape(-1), z.reshape(-1, D), emb, wf, bf, lens, T)
+    torch.testing.assert_close(out, ref.detach().reshape(-1, E), rtol=1e-6, atol=1e-6)
+    out.backward(dout)
+    for name, t, w in zip(("dz", "demb", "dWf", "dbf"), (z, emb, wf, bf), want):
+        torch.testing.assert_close(t.grad, w, rtol=2e-5, atol=2e-5, msg=name)

@@ -723,3 +723,120 @@ extern "C" int vg_prior_logp_bwd(const float* dlog_p, const float* dkl_rows, con
       dlog_p, dkl_rows, mu_ls, (long)ld_mu_ls, u, dmu_ls, du, dlogdet_sum, dlog_q, M, D, lengths, T > 0 ? T : 1);
   return vg_host::check_launch("vg_prior_logp_bwd");
 }
+
+// =====================================================================================
+// Training-side input fusion: out[m] = mask(E[id[m]]) + relu(Wf z[m] + bf)
+// (Embedding.forward modules/linear/layers.py:150-152, token_fuser Linear + ReLU :184-193 -- NOT masked --,
+// LVTR.fuse_inputs models/speech/lvtr.py:390-392).  One wave per frame, lane-strided over the embedding width.
+// Backward: dE[id] += mask(dout) by fp32 atomics (200 x 64 table, L2-resident), dz[m] = Wf^T g with
+// g = dout * (pre > 0), and per-block partial sums of dWf = g^T z and dbf = sum g that a second pass folds
+// (deterministic for Wf / bf; the embedding rows add in arrival order).
+// =====================================================================================
+namespace {
+constexpr int EF_ROWS = 64;        // frames per block (4 waves x 16)
+constexpr int EF_MAXD = 8;
+
+__global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ z,
+                                                             long ldz, const float* __restrict__ emb, int vocab, int E,
+                                                             const float* __restrict__ wf, const float* __restrict__ bf,
+                                                             int D, const int* __restrict__ lengths, int T,
+                                                             float* __restrict__ out, int M) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < EF_ROWS; r += 4) {
+    const int m = blockIdx.x * EF_ROWS + r;
+    if (m >= M) return;
+    const bool valid = row_valid(lengths, T, m);
+    const long id = min(max(ids[m], 0L), (long)vocab - 1);
+    float zv[EF_MAXD];
+#pragma unroll
+    for (int d = 0; d < EF_MAXD; ++d) zv[d] = d < D ? z[(long)m * ldz + d] : 0.f;
+    for (int c = lane; c < E; c += 64) {
+      float a = bf ? bf[c] : 0.f;
+#pragma unroll
+      for (int d = 0; d < EF_MAXD; ++d)
+        if (d < D) a = fmaf(wf[(long)c * D + d], zv[d], a);
+      out[(long)m * E + c] = (valid ? emb[id * E + c] : 0.f) + fmaxf(a, 0.f);
+    }
+  }
+}
+
+// part[block][E][D + 1]: columns 0..D-1 = dWf rows, column D = dbf
+__global__ __launch_bounds__(256) void embed_fuse_bwd_kernel(const float* __restrict__ dout, const long* __restrict__ ids,
+                                                             const float* __restrict__ z, long ldz, int vocab, int E,
+                                                             const float* __restrict__ wf, const float* __restrict__ bf,
+                                                             int D, const int* __restrict__ lengths, int T,
+                                                             float* __restrict__ demb, float* __restrict__ dz, long lddz,
+                                                             float* __restrict__ part, int M) {
+  __shared__ float acc[4][64][EF_MAXD + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < E; c0 += 64) {
+    const int c = c0 + lane;
+    float w[EF_MAXD], pw[EF_MAXD + 1];
+#pragma unroll
+    for (int d = 0; d < EF_MAXD; ++d) w[d] = (c < E && d < D) ? wf[(long)c * D + d] : 0.f;
+#pragma unroll
+    for (int d = 0; d <= EF_MAXD; ++d) pw[d] = 0.f;
+    const float b = (c < E && bf) ? bf[c] : 0.f;
+    for (int r = wave; r < EF_ROWS; r += 4) {
+      const int m = blockIdx.x * EF_ROWS + r;
+      if (m >= M) break;
+      float zv[EF_MAXD];
+#pragma unroll
+      for (int d = 0; d < EF_MAXD; ++d) zv[d] = d < D ? z[(long)m * ldz + d] : 0.f;
+      float pre = b;
+#pragma unroll
+      for (int d = 0; d < EF_MAXD; ++d) pre = fmaf(w[d], zv[d], pre);
+      const float go = c < E ? dout[(long)m * E + c] : 0.f;
+      if (c < E && demb != nullptr && go != 0.f && row_valid(lengths, T, m)) {
+        const long id = min(max(ids[m], 0L), (long)vocab - 1);
+        atomicAdd(demb + id * E + c, go);
+      }
+      const float g = pre > 0.f ? go : 0.f;
+#pragma unroll
+      for (int d = 0; d < EF_MAXD; ++d) {
+        if (d < D) {
+          pw[d] = fmaf(g, zv[d], pw[d]);
+          const float t = wave_sum(g * w[d]);           // dz[m][d] = sum_c g[c] Wf[c][d]
+          if (lane == 0 && dz != nullptr) {
+            if (c0 == 0) dz[(long)m * lddz + d] = t;
+            else dz[(long)m * lddz + d] += t;
+          }
+        }
+      }
+      pw[EF_MAXD] += g;
+    }
+#pragma unroll
+    for (int d = 0; d <= EF_MAXD; ++d) acc[wave][lane][d] = pw[d];
+    __syncthreads();
+    if (wave == 0 && c < E) {
+      for (int d = 0; d < D; ++d)
+        part[((long)blockIdx.x * E + c) * (D + 1) + d] = acc[0][lane][d] + acc[1][lane][d] + acc[2][lane][d] + acc[3][lane][d];
+      part[((long)blockIdx.x * E + c) * (D + 1) + D] =
+          acc[0][lane][EF_MAXD] + acc[1][lane][EF_MAXD] + acc[2][lane][EF_MAXD] + acc[3][lane][EF_MAXD];
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int vg_embed_fuse_blocks(int M) { return (M + EF_ROWS - 1) / EF_ROWS; }
+
+extern "C" int vg_embed_fuse_fwd(const int64_t* ids, const float* z, int64_t ldz, const float* emb, int vocab, int E,
+                                 const float* wf, const float* bf, int D, const int32_t* lengths, int T, float* out,
+                                 int M, hipStream_t stream) {
+  VG_REQUIRE(M > 0 && E > 0 && vocab > 0 && D >= 1 && D <= EF_MAXD, "vg_embed_fuse_fwd: M=%d E=%d D=%d", M, E, D);
+  embed_fuse_fwd_kernel<<<dim3((M + EF_ROWS - 1) / EF_ROWS), dim3(256), 0, stream>>>(
+      reinterpret_cast<const long*>(ids), z, ldz, emb, vocab, E, wf, bf, D, lengths, T > 0 ? T : 1, out, M);
+  return vg_host::check_launch("vg_embed_fuse_fwd");
+}
+
+extern "C" int vg_embed_fuse_bwd(const float* dout, const int64_t* ids, const float* z, int64_t ldz, int vocab, int E,
+                                 const float* wf, const float* bf, int D, const int32_t* lengths, int T, float* demb,
+                                 float* dz, int64_t lddz, float* part, int M, hipStream_t stream) {
+  VG_REQUIRE(M > 0 && E > 0 && vocab > 0 && D >= 1 && D <= EF_MAXD && part != nullptr,
+             "vg_embed_fuse_bwd: M=%d E=%d D=%d", M, E, D);
+  embed_fuse_bwd_kernel<<<dim3((M + EF_ROWS - 1) / EF_ROWS), dim3(256), 0, stream>>>(
+      dout, reinterpret_cast<const long*>(ids), z, ldz, vocab, E, wf, bf, D, lengths, T > 0 ? T : 1, demb, dz, lddz,
+      part, M);
+  return vg_host::check_launch("vg_embed_fuse_bwd");
+}

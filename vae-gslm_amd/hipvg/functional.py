@@ -501,6 +501,60 @@ def prior_logp_kl(mu_ls, u, logdet_sum, log_q, lengths=None, T=0):
     return PriorKLFn.apply(mu_ls, u, logdet_sum, log_q, lengths, T)
 
 
+class EmbedFuseFn(torch.autograd.Function):
+    """out[m] = mask(E[ids[m]]) + relu(Wf z[m] + bf) in fp32 (Embedding.forward
+    modules/linear/layers.py:150-152 + token_fuser :184-193 + LVTR.fuse_inputs models/speech/lvtr.py:390-392)."""
+
+    @staticmethod
+    def forward(ctx, ids, z, emb, wf, bf, lengths, T):
+        M, D = z.shape
+        E = emb.shape[1]
+        ids = ids.contiguous()
+        z = _as(z, torch.float32)
+        embd, wfd = emb.detach().float().contiguous(), wf.detach().float().contiguous()
+        bfd = None if bf is None else bf.detach().float().contiguous()
+        out = torch.empty(M, E, dtype=torch.float32, device=z.device)
+        check(lib().vg_embed_fuse_fwd(ptr(ids), ptr(z), z.stride(0), ptr(embd), emb.shape[0], E, ptr(wfd), ptr(bfd), D,
+                                      ptr(lengths), int(T), ptr(out), M, stream()), "vg_embed_fuse_fwd")
+        ctx.save_for_backward(ids, z, wfd, bfd, lengths)
+        ctx.params = (emb, wf, bf)
+        ctx.meta = (int(T), emb.shape[0], E)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, z, wfd, bfd, lengths = ctx.saved_tensors
+        emb, wf, bf = ctx.params
+        T, vocab, E = ctx.meta
+        M, D = z.shape
+        dout = _as(dout, torch.float32)
+        need_z = ctx.needs_input_grad[1]
+        dz = torch.empty(M, D, dtype=torch.float32, device=z.device) if need_z else None
+        g_emb = None
+        demb = None
+        if ctx.needs_input_grad[2]:
+            if _sinkable(emb):
+                demb = _grad_buffer(emb)
+            else:
+                demb = g_emb = torch.zeros(vocab, E, dtype=torch.float32, device=z.device)
+        nb = lib().vg_embed_fuse_blocks(M)
+        part = torch.empty(nb, E * (D + 1), dtype=torch.float32, device=z.device)
+        check(lib().vg_embed_fuse_bwd(ptr(dout), ptr(ids), ptr(z), z.stride(0), vocab, E, ptr(wfd), ptr(bfd), D,
+                                      ptr(lengths), T, ptr(demb), ptr(dz), D, ptr(part), M, stream()),
+              "vg_embed_fuse_bwd")
+        if demb is not None and g_emb is None:
+            _fire(emb)
+        folded = colsum(part).view(E, D + 1)
+        g_wf = folded[:, :D].contiguous().view_as(wf) if ctx.needs_input_grad[3] else None
+        g_bf = folded[:, D].contiguous().view_as(bf) if (bf is not None and ctx.needs_input_grad[4]) else None
+        return None, dz, g_emb, g_wf, g_bf, None, None
+
+
+def embed_fuse_train(ids, z, emb, wf, bf, lengths=None, T=0):
+    """ids int64 [M], z [M, D<=8] -> fp32 [M, E]."""
+    return EmbedFuseFn.apply(ids, z, emb, wf, bf, lengths, T)
+
+
 # ---------------------------------------------------------------- gradient sink
 # Weight gradients of the fused Transformer layer are accumulated by the wgrad GEMM
 # DIRECTLY into ``param.grad`` (fp32; split-K atomics or a read-modify-write epilogue),

@@ -22,6 +22,7 @@ carries the fused ``kld`` sum, the token ``logits`` arg-max and ``lengths``.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Mapping, Optional, Tuple
 
 import torch
@@ -161,7 +162,18 @@ class LVTR(nn.Module):
         mask, lens = x.mask, x.lengths32
         B, T = mask.shape
         D = self.hp.latent_dim
-        ids, mel, tokens = self._embed(x)
+        # token embedding + token_fuser + add as one row kernel when the configuration is the yaml's (ReLU fuser,
+        # fp32 embedding table); the module path below is the general one
+        fuser = self.token_fuser
+        fast_fuse = (diff_input is None and x.value.is_cuda and isinstance(getattr(fuser, "activation", None), nn.ReLU)
+                     and self.hp.latent_dim <= 8 and self.token_embedding.weight.dtype == torch.float32
+                     and os.environ.get("VG_EMBED_FUSE", "1") != "0")
+        if fast_fuse:
+            ids, mel = self.split_inputs(x)
+            ids = TensorMask(ids.value.long().squeeze(-1), ids.mask)
+            tokens = None
+        else:
+            ids, mel, tokens = self._embed(x)
         # ---- posterior q(z | mel): conv encoder (stock ops) -> fused head + reparameterisation
         with _side_autocast():
             enc = self.encoder[0](mel)
@@ -195,7 +207,11 @@ class LVTR(nn.Module):
         sample_q = TensorMask(z2.view(B, T, D), mask)
         log_q = TensorMask(lq2.view(B, T, D), mask)
         # ---- shift right by one frame, prior network
-        fused = self.fuse_inputs(sample_q, tokens)
+        if fast_fuse:
+            fused = TensorMask(HF.embed_fuse_train(ids.value.reshape(-1), z2, self.token_embedding.weight,
+                                                   fuser.linear.weight, fuser.linear.bias, lens, T).view(B, T, -1), mask)
+        else:
+            fused = self.fuse_inputs(sample_q, tokens)
         if cutting:
             leaf = fused.value.detach().requires_grad_(True)
             self.grad_cuts.append(((fused.value,), (leaf,)))
@@ -325,7 +341,18 @@ class LVTR(nn.Module):
         """Per-sequence mean token log-likelihood (tokens model) as in reference :337-388."""
         mask, lens = x.mask, x.lengths32
         B, T = mask.shape
-        ids, mel, tokens = self._embed(x)
+        # token embedding + token_fuser + add as one row kernel when the configuration is the yaml's (ReLU fuser,
+        # fp32 embedding table); the module path below is the general one
+        fuser = self.token_fuser
+        fast_fuse = (diff_input is None and x.value.is_cuda and isinstance(getattr(fuser, "activation", None), nn.ReLU)
+                     and self.hp.latent_dim <= 8 and self.token_embedding.weight.dtype == torch.float32
+                     and os.environ.get("VG_EMBED_FUSE", "1") != "0")
+        if fast_fuse:
+            ids, mel = self.split_inputs(x)
+            ids = TensorMask(ids.value.long().squeeze(-1), ids.mask)
+            tokens = None
+        else:
+            ids, mel, tokens = self._embed(x)
         with _side_autocast():
             enc = self.encoder[0](mel)
         q = self.encoder[1](TensorMask(enc.value.float(), enc.mask), temperature).sample
