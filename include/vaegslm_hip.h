@@ -281,6 +281,19 @@ int vg_embed_fuse_bwd(const float* dout, const int64_t* ids, const float* z, int
                       const float* wf, const float* bf, int D, const int32_t* lengths, int T, float* demb, float* dz,
                       int64_t lddz, float* part, int M, vg_stream_t stream);
 
+/* ---------------------------------------------------------------- diffusion-decoder loss arithmetic
+ * GaussianDiffusion1D.q_sample / p_losses (modules/diffusion/ddpm.py:337-366) with the masked L1 of
+ * training_lib/losses.py:9-27,44-57 (objective pred_noise, loss_type l1).  Rows are frames (b, t), b = m / T.
+ * vg_qsample: x_t = mask(coef_x0[t_b] x0 + coef_noise[t_b] noise), fp32 [M][C]; t int64 [M / T].
+ * vg_l1_rows_fwd: rows[m] = mask(mean_c |pred - target|) (sum them with vg_sum_f32); pred in dtype, target fp32.
+ * vg_l1_rows_bwd: dpred = mask(gscale[0] sign(pred - target) / C) in dtype; gscale is a device scalar. */
+int vg_qsample(const float* x0, const float* noise, const float* coef_x0, const float* coef_noise, const int64_t* t,
+               const int32_t* lengths, int T, float* out, int M, int C, vg_stream_t stream);
+int vg_l1_rows_fwd(const void* pred, const float* target, const int32_t* lengths, int T, float* rows, int M, int C,
+                   int dtype, vg_stream_t stream);
+int vg_l1_rows_bwd(const void* pred, const float* target, const float* gscale, const int32_t* lengths, int T,
+                   void* dpred, int M, int C, int dtype, vg_stream_t stream);
+
 /* ---------------------------------------------------------------- gradient exchange (RCCL)
  * The one collective of the path: the mean of the gradients over the data-parallel ranks, which the reference
  * gets from Lightning's DDP wrapper (training_lib/trainer.py:37-65 builds the strategy, the reduce happens inside

@@ -682,3 +682,28 @@ def test_embed_fuse_train_matches_stock_modules(F):
     out.backward(dout)
     for name, t, w in zip(("dz", "demb", "dWf", "dbf"), (z, emb, wf, bf), want):
         torch.testing.assert_close(t.grad, w, rtol=2e-5, atol=2e-5, msg=name)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_diffusion_loss_kernels_match_stock_arithmetic(F, dtype):
+    """vg_qsample and vg_l1_rows_fwd/bwd against the tensor expressions of GaussianDiffusion1D.q_sample / p_losses
+    with masked_l1_loss (ragged lengths incl. an empty sequence): x_t exact, loss and d pred to rounding."""
+    B, T, C = 3, 50, 80
+    g = torch.Generator().manual_seed(17)
+    x0 = torch.randn(B, T, C, generator=g).to(dev())
+    noise = torch.randn(B, T, C, generator=g).to(dev())
+    ca, cs = torch.rand(1000, generator=g).to(dev()), torch.rand(1000, generator=g).to(dev())
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev())
+    lens = torch.tensor([50, 0, 21], dtype=torch.int32, device=dev())
+    mask = (torch.arange(T, device=dev())[None] < lens[:, None])[..., None]
+    want = torch.where(mask, ca[t][:, None, None] * x0 + cs[t][:, None, None] * noise, torch.zeros(()).to(dev()))
+    got = F.qsample(x0.reshape(-1, C), noise.reshape(-1, C), ca, cs, t, lens, T)
+    torch.testing.assert_close(got, want.reshape(-1, C), rtol=1e-6, atol=1e-6)
+    pred = torch.randn(B, T, C, generator=g).to(dev()).to(dtype).requires_grad_(True)
+    ref = (torch.where(mask, pred.float(), torch.zeros(()).to(dev())) - torch.where(mask, noise, torch.zeros(()).to(dev()))).abs().mean(-1).sum()
+    ref.backward()
+    want_g, pred.grad = pred.grad.clone(), None
+    loss = F.masked_l1_sum(pred.reshape(-1, C), noise.reshape(-1, C), lens, T)
+    torch.testing.assert_close(loss, ref.detach(), rtol=1e-5, atol=1e-4)
+    (loss * 1.0).backward()
+    torch.testing.assert_close(pred.grad.float(), want_g.float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-6)

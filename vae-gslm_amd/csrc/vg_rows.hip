@@ -840,3 +840,95 @@ extern "C" int vg_embed_fuse_bwd(const float* dout, const int64_t* ids, const fl
       part, M);
   return vg_host::check_launch("vg_embed_fuse_bwd");
 }
+
+// =====================================================================================
+// Diffusion-decoder loss arithmetic (GaussianDiffusion1D.q_sample / p_losses,
+// modules/diffusion/ddpm.py:337-366; masked L1 of training_lib/losses.py:9-27,44-57):
+//   q_sample : x_t[m][c] = mask( a[t_b] x0[m][c] + s[t_b] noise[m][c] ),  b = m / T
+//   l1 rows  : loss_row[m] = mask( mean_c |pred[m][c] - target[m][c]| )            (summed by vg_sum_f32)
+//   l1 bwd   : dpred[m][c] = mask( g sign(pred - target) / C )
+// One wave per frame, lane-strided over the channels.
+// =====================================================================================
+namespace {
+__global__ __launch_bounds__(256) void qsample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                      const float* __restrict__ ca, const float* __restrict__ cs,
+                                                      const long* __restrict__ t, const int* __restrict__ lengths, int T,
+                                                      float* __restrict__ out, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const bool valid = row_valid(lengths, T, m);
+  const long tb = t[m / T];
+  const float a = ca[tb], sgm = cs[tb];
+  for (int c = lane; c < C; c += 64) {
+    const long i = (long)m * C + c;
+    out[i] = valid ? fmaf(a, x0[i], sgm * noise[i]) : 0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l1_rows_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+                                                          const int* __restrict__ lengths, int Tn,
+                                                          float* __restrict__ rows, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float acc = 0.f;
+  if (row_valid(lengths, Tn, m))
+    for (int c = lane; c < C; c += 64) acc += fabsf(to_f32<T>(pred[(long)m * C + c]) - target[(long)m * C + c]);
+  acc = wave_sum(acc);
+  if (lane == 0) rows[m] = acc / (float)C;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l1_rows_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+                                                          const float* __restrict__ gscale,
+                                                          const int* __restrict__ lengths, int Tn,
+                                                          T* __restrict__ dpred, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const bool valid = row_valid(lengths, Tn, m);
+  const float g = gscale[0] / (float)C;
+  for (int c = lane; c < C; c += 64) {
+    const long i = (long)m * C + c;
+    const float d = to_f32<T>(pred[i]) - target[i];
+    dpred[i] = from_f32<T>(valid ? (d > 0.f ? g : (d < 0.f ? -g : 0.f)) : 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int vg_qsample(const float* x0, const float* noise, const float* coef_x0, const float* coef_noise,
+                          const int64_t* t, const int32_t* lengths, int T, float* out, int M, int C,
+                          hipStream_t stream) {
+  VG_REQUIRE(M > 0 && C > 0 && T > 0 && M % T == 0, "vg_qsample: M=%d C=%d T=%d", M, C, T);
+  qsample_kernel<<<dim3((M + 3) / 4), dim3(256), 0, stream>>>(x0, noise, coef_x0, coef_noise,
+                                                              reinterpret_cast<const long*>(t), lengths, T, out, M, C);
+  return vg_host::check_launch("vg_qsample");
+}
+
+extern "C" int vg_l1_rows_fwd(const void* pred, const float* target, const int32_t* lengths, int T, float* rows, int M,
+                              int C, int dtype, hipStream_t stream) {
+  VG_REQUIRE(M > 0 && C > 0, "vg_l1_rows_fwd: M=%d C=%d", M, C);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_l1_rows_fwd: bad dtype %d", dtype);
+  const int Tn = T > 0 ? T : 1;
+  if (dtype == VG_BF16)
+    l1_rows_fwd_kernel<bf16_t><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const bf16_t*)pred, target, lengths, Tn, rows, M, C);
+  else
+    l1_rows_fwd_kernel<float><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const float*)pred, target, lengths, Tn, rows, M, C);
+  return vg_host::check_launch("vg_l1_rows_fwd");
+}
+
+extern "C" int vg_l1_rows_bwd(const void* pred, const float* target, const float* gscale, const int32_t* lengths, int T,
+                              void* dpred, int M, int C, int dtype, hipStream_t stream) {
+  VG_REQUIRE(M > 0 && C > 0 && gscale != nullptr, "vg_l1_rows_bwd: M=%d C=%d", M, C);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_l1_rows_bwd: bad dtype %d", dtype);
+  const int Tn = T > 0 ? T : 1;
+  if (dtype == VG_BF16)
+    l1_rows_bwd_kernel<bf16_t><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const bf16_t*)pred, target, gscale, lengths, Tn,
+                                                                             (bf16_t*)dpred, M, C);
+  else
+    l1_rows_bwd_kernel<float><<<dim3((M + 3) / 4), dim3(256), 0, stream>>>((const float*)pred, target, gscale, lengths, Tn,
+                                                                           (float*)dpred, M, C);
+  return vg_host::check_launch("vg_l1_rows_bwd");
+}

@@ -79,6 +79,9 @@ SIGNATURES = {
     "vg_embed_fuse_blocks": [_i],
     "vg_embed_fuse_fwd": [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "vg_embed_fuse_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _i, _vp],
+    "vg_qsample": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "vg_l1_rows_fwd": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "vg_l1_rows_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "vg_comm_unique_id": [_vp, _i],
     "vg_comm_init": [_i, _i, _vp, _i],
     "vg_comm_world": [],

@@ -501,6 +501,45 @@ def prior_logp_kl(mu_ls, u, logdet_sum, log_q, lengths=None, T=0):
     return PriorKLFn.apply(mu_ls, u, logdet_sum, log_q, lengths, T)
 
 
+def qsample(x0: Tensor, noise: Tensor, coef_x0: Tensor, coef_noise: Tensor, t: Tensor, lengths, T: int) -> Tensor:
+    """x_t = mask(coef_x0[t_b] x0 + coef_noise[t_b] noise) on [M = B*T, C] fp32 rows (no gradient: x0 is data)."""
+    M, C = x0.shape
+    out = torch.empty(M, C, dtype=torch.float32, device=x0.device)
+    check(lib().vg_qsample(ptr(_as(x0, torch.float32)), ptr(_as(noise, torch.float32)), ptr(coef_x0), ptr(coef_noise),
+                           ptr(t.contiguous()), ptr(lengths), int(T), ptr(out), M, C, stream()), "vg_qsample")
+    return out
+
+
+class MaskedL1SumFn(torch.autograd.Function):
+    """sum over valid frames of mean_c |pred - target| (training_lib/losses.py:9-27 with l1, default reductions)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, lengths, T):
+        M, C = pred.shape
+        pred = pred.contiguous()
+        target = _as(target, torch.float32)
+        rows = torch.empty(M, dtype=torch.float32, device=pred.device)
+        check(lib().vg_l1_rows_fwd(ptr(pred), ptr(target), ptr(lengths), int(T), ptr(rows), M, C, dtype_id(pred.dtype),
+                                   stream()), "vg_l1_rows_fwd")
+        ctx.save_for_backward(pred, target, lengths)
+        ctx.T = int(T)
+        return sum_f32(rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, lengths = ctx.saved_tensors
+        M, C = pred.shape
+        dpred = torch.empty_like(pred)
+        g = _as(g, torch.float32).reshape(1)
+        check(lib().vg_l1_rows_bwd(ptr(pred), ptr(target), ptr(g), ptr(lengths), ctx.T, ptr(dpred), M, C,
+                                   dtype_id(pred.dtype), stream()), "vg_l1_rows_bwd")
+        return dpred, None, None, None
+
+
+def masked_l1_sum(pred: Tensor, target: Tensor, lengths=None, T: int = 0) -> Tensor:
+    return MaskedL1SumFn.apply(pred, target, lengths, T)
+
+
 class EmbedFuseFn(torch.autograd.Function):
     """out[m] = mask(E[ids[m]]) + relu(Wf z[m] + bf) in fp32 (Embedding.forward
     modules/linear/layers.py:150-152 + token_fuser :184-193 + LVTR.fuse_inputs models/speech/lvtr.py:390-392)."""
