@@ -173,6 +173,17 @@ int vg_sum_f32(const float* x, int64_t n, float* out, vg_stream_t stream);
 int vg_colsum_blocks(int M);
 int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, int dtype, int accumulate,
               vg_stream_t stream);
+/* up to VG_COLSUM_MAX_TASKS independent fp32 column sums (dst[cols] (+)= sum over rows of src[rows][ld]) in one
+ * launch: the partial-sum arrays behind the bias / norm-scale gradients of one backward node */
+enum { VG_COLSUM_MAX_TASKS = 8 };
+typedef struct vg_colsum_task {
+  const float* src;
+  int rows, cols;
+  int64_t ld;
+  float* dst;
+  int accumulate;
+} vg_colsum_task;
+int vg_colsum_multi(const vg_colsum_task* tasks, int n, vg_stream_t stream);
 /* dx = dy * act'(aux): ReLU takes aux = activation output, GELU (erf) takes aux = pre-activation
  * (modules/activations.py:5-18 backward, for Linear+activation heads with several consumers). */
 int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, vg_stream_t stream);

@@ -707,3 +707,21 @@ def test_diffusion_loss_kernels_match_stock_arithmetic(F, dtype):
     torch.testing.assert_close(loss, ref.detach(), rtol=1e-5, atol=1e-4)
     (loss * 1.0).backward()
     torch.testing.assert_close(pred.grad.float(), want_g.float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-6)
+
+
+def test_colsum_multi_folds_several_partial_arrays_in_one_launch(F):
+    """vg_colsum_multi through hipvg.functional.vec_grads: three partial-sum arrays of different shapes -> two
+    sunk parameters (accumulated into existing .grad) and one dense result; an ineligible source (bf16) takes the
+    single path inside the same call."""
+    g = torch.Generator().manual_seed(2)
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(dev())
+    srcs = [mk(512, 1024), mk(63, 4096), mk(7, 64), mk(300, 128).bfloat16()]
+    ps = [torch.nn.Parameter(torch.zeros(1024, device=dev())), torch.nn.Parameter(torch.zeros(4096, device=dev())),
+          torch.zeros(64, device=dev()), torch.nn.Parameter(torch.zeros(128, device=dev()))]
+    ps[0].grad = torch.full_like(ps[0], 2.0)
+    outs = F.vec_grads(list(zip(ps, srcs)))
+    assert outs[0] is None and outs[1] is None and outs[3] is None
+    torch.testing.assert_close(ps[0].grad, 2.0 + srcs[0].sum(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(ps[1].grad, srcs[1].sum(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(outs[2], srcs[2].sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ps[3].grad, srcs[3].float().sum(0), rtol=1e-2, atol=1e-2)

@@ -932,3 +932,64 @@ extern "C" int vg_l1_rows_bwd(const void* pred, const float* target, const float
                                                                            (float*)dpred, M, C);
   return vg_host::check_launch("vg_l1_rows_bwd");
 }
+
+// =====================================================================================
+// Several small column sums in ONE launch: the second stage of the two-stage reductions (bias / norm-scale
+// gradients from per-block partial arrays) is launch-bound at ~4.5 us each and a backward node produces up to
+// five of them.  Tasks travel by value in the kernel arguments; blockIdx.y = task, blockIdx.x = 16 columns.
+// =====================================================================================
+namespace {
+struct ColsumTasks {
+  vg_colsum_task t[VG_COLSUM_MAX_TASKS];
+};
+
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumTasks tk) {
+  __shared__ float red[64][17];
+  const vg_colsum_task& k = tk.t[blockIdx.y];
+  const int N = k.cols, M = k.rows;
+  if ((int)blockIdx.x * 16 >= N) return;           // uniform per block
+  const long ld = k.ld;
+  const float* __restrict__ x = k.src;
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c0 = blockIdx.x * 16 + cl * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+#pragma unroll 8
+    for (int m = rl; m < M; m += 64) s += *reinterpret_cast<const f32x4*>(x + (long)m * ld + c0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cl * 4 + e] = s[e];
+  __syncthreads();
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  float t = red[4 * g][c] + red[4 * g + 1][c] + red[4 * g + 2][c] + red[4 * g + 3][c];
+  __syncthreads();
+  red[g][c] = t;
+  __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x * 16 + c < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += red[r][c];
+    float* o = k.dst + blockIdx.x * 16 + c;
+    *o = k.accumulate ? *o + v : v;
+  }
+}
+}  // namespace
+
+extern "C" int vg_colsum_multi(const vg_colsum_task* tasks, int n, hipStream_t stream) {
+  VG_REQUIRE(tasks != nullptr && n >= 1 && n <= VG_COLSUM_MAX_TASKS, "vg_colsum_multi: n=%d (1..%d)", n,
+             VG_COLSUM_MAX_TASKS);
+  ColsumTasks tk;
+  int maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    const vg_colsum_task& k = tasks[i];
+    VG_REQUIRE(k.src != nullptr && k.dst != nullptr && k.rows > 0 && k.cols > 0 && k.cols % 4 == 0 && k.ld % 4 == 0 &&
+                   ((uintptr_t)k.src % 16) == 0,
+               "vg_colsum_multi: task %d: rows=%d cols=%d ld=%ld (fp32, 16-byte aligned rows, cols %% 4 == 0)", i, k.rows,
+               k.cols, (long)k.ld);
+    tk.t[i] = k;
+    maxc = k.cols > maxc ? k.cols : maxc;
+  }
+  for (int i = n; i < VG_COLSUM_MAX_TASKS; ++i) tk.t[i] = tasks[0];
+  colsum_multi_kernel<<<dim3((maxc + 15) / 16, n), dim3(256), 0, stream>>>(tk);
+  return vg_host::check_launch("vg_colsum_multi");
+}

@@ -38,6 +38,12 @@ class GemmDesc(C.Structure):
                 ("split_ws", _vp), ("split_cnt", _vp), ("split_ws_floats", _i64)]
 
 
+class ColsumTask(C.Structure):
+    _fields_ = [("src", _vp), ("rows", _i), ("cols", _i), ("ld", _i64), ("dst", _vp), ("accumulate", _i)]
+
+
+COLSUM_MAX_TASKS = 8
+
 # name -> argtypes (restype is always int); must list EVERY symbol of the header
 SIGNATURES = {
     "vg_version": [],
@@ -59,6 +65,7 @@ SIGNATURES = {
     "vg_sum_f32": [_vp, _i64, _vp, _vp],
     "vg_colsum_blocks": [_i],
     "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp],
+    "vg_colsum_multi": [C.POINTER(ColsumTask), _i, _vp],
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "vg_mask_rows": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],

@@ -33,6 +33,7 @@ def _flag(name: str, default: str) -> bool:
 # column-sum launches on MI355X (the conditional MFMA inside the K loop costs the wgrad ~8 us)
 _FUSE_BIAS_GRAD = _flag("VG_FUSE_BIAS_GRAD", "0")
 _STORED_DERIV = _flag("VG_STORED_DERIV", "1")   # forward stores act'(u): the backward epilogue is one multiply
+_COLSUM_MULTI = _flag("VG_COLSUM_MULTI", "1")   # the small column sums of a backward node in one launch
 _COLPART = _flag("VG_COLPART", "1")             # dgrad launches also reduce their result per row tile (bias gradients)
 # in-launch slab reduction of split-K weight gradients instead of fp32 atomics: measured SLOWER on these tiles
 # (64 KiB of slab per slice; write-through slabs + ticket: 80 vs 67 us per wgrad launch, 289k vs 305k tokens/s;
@@ -180,6 +181,37 @@ def vec_grad(p, src2d: Tensor):
         sink_colsum(p, src2d)
         return None
     return colsum(src2d).view_as(p)
+
+
+def vec_grads(pairs):
+    """``[vec_grad(p, src) for p, src in pairs]`` with all the small fp32 partial-sum arrays reduced by ONE launch
+    (vg_colsum_multi); anything that does not qualify takes the single path."""
+    import hipvg
+    out = [None] * len(pairs)
+    tasks, fire, dense = [], [], []
+    for i, (p, src) in enumerate(pairs):
+        if p is None or src is None:
+            continue
+        ok = (_COLSUM_MULTI and src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
+              and src.shape[0] <= 2048 and src.shape[1] % 4 == 0 and src.stride(0) % 4 == 0
+              and src.data_ptr() % 16 == 0 and src.shape[1] == p.numel() and len(tasks) < hipvg.COLSUM_MAX_TASKS)
+        if not ok:
+            out[i] = vec_grad(p, src)
+            continue
+        if _sinkable(p):
+            dst, acc = _grad_buffer(p).view(-1), 1
+            fire.append(p)
+        else:
+            dst, acc = torch.empty(p.numel(), dtype=torch.float32, device=src.device), 0
+            out[i] = dst.view_as(p)
+        tasks.append(hipvg.ColsumTask(src.data_ptr(), src.shape[0], src.shape[1], src.stride(0), dst.data_ptr(), acc))
+        dense.append((src, dst))                     # keep both alive until the launch is enqueued
+    if tasks:
+        arr = (hipvg.ColsumTask * len(tasks))(*tasks)
+        check(lib().vg_colsum_multi(arr, len(tasks), stream()), "vg_colsum_multi")
+        for p in fire:
+            _fire(p)
+    return out
 
 
 def sink_colsum(p: Tensor, x: Tensor) -> None:
@@ -782,13 +814,15 @@ class TransformerLayerFn(torch.autograd.Function):
         ws = WgradStream(x.device, _WGRAD_STREAM)
         g_w2, g_b2 = ws.wgrad(w2, b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
+        small = []                               # (parameter, fp32 partial sums): folded by one launch at the end
+        g_b1 = None
         if want_part and parts[0] is not None:
             g_w1, _ = ws.wgrad(w1, None, du, n3)
-            g_b1 = vec_grad(b1, parts[0])
+            small.append((b1, parts[0]))
         else:
             g_w1, g_b1 = ws.wgrad(w1, b1, du, n3)
         dx1, ds3 = rmsnorm_bwd_raw(dn3, x1, sc3, rstd3, dy, lengths, T)
-        g_n3 = vec_grad(n3s, ds3)
+        small.append((n3s, ds3))
         # ---- attention
         datt = gemm(dx1, so, M, D, D, b_tr=True)
         g_wo, g_bo = ws.wgrad(wo, bo, dx1, att)
@@ -799,7 +833,11 @@ class TransformerLayerFn(torch.autograd.Function):
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
         g_wq, g_bq = ws.wgrad(wqkv, bqkv, dqkv, n1)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
-        g_n1 = vec_grad(n1s, ds1)
+        small.append((n1s, ds1))
+        folded = dict(zip((id(p) for p, _ in small), vec_grads(small)))
+        g_n1, g_n3 = folded[id(n1s)], folded[id(n3s)]
+        if b1 is not None and id(b1) in folded:
+            g_b1 = folded[id(b1)]
         ws.join()                                # before qkv / att / du ... can be released
         return (dx, g_n1, g_wq, g_bq, g_wo, g_bo, g_n3, g_w1, g_b1, g_w2, g_b2,
                 None, None, None, None, None, None)
@@ -930,13 +968,12 @@ class ConvBlockFn(torch.autograd.Function):
             _fire(c3w)
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
-        g_c2b = None if id(c2b) in fused_bias else vec_grad(c2b, parts[0] if parts and parts[0] is not None else dpre)
         dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
         dte = dv.view(-1, T, Cc).float().sum(1)
-        g_c1w = vec_grad(c1w, pw)
-        g_c1b = vec_grad(c1b, dte)
-        g_nw = vec_grad(nw, pg)
-        g_nb = vec_grad(nb_, pb)
+        # the five small reductions of this block (conv weight / bias, norm weight / bias, c2's bias) in one launch
+        g_c2b, g_c1w, g_c1b, g_nw, g_nb = vec_grads([
+            (None if id(c2b) in fused_bias else c2b, parts[0] if parts and parts[0] is not None else dpre),
+            (c1w, pw), (c1b, dte), (nw, pg), (nb_, pb)])
         return (dx, dte if has_te else None, dcond, g_c1w, g_c1b, g_nw, g_nb, g_c2, g_c2b, g_c3, g_c3b,
                 None, None, None, None, None)
 
