@@ -90,9 +90,11 @@ class BottleneckBlock(nn.Module):
         return isinstance(self.norm, InstanceNorm) and hip_act_id(self.act) in ("relu", "silu")
 
     def forward_rows(self, x2: torch.Tensor, T: int, cond2: Optional[torch.Tensor],
-                     temb: Optional[torch.Tensor]) -> torch.Tensor:
-        """Channels-last HIP path: x2 [B*T, C] in the compute dtype."""
-        te = self.time_emb(self.act(temb)) if self.has_time else None
+                     temb: Optional[torch.Tensor], te: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Channels-last HIP path: x2 [B*T, C] in the compute dtype.  ``te``: this block's time-embedding
+        projection if the caller already computed it (one batched GEMM for all blocks)."""
+        if te is None:
+            te = self.time_emb(self.act(temb)) if self.has_time else None
         return HF.conv_block(x2, te, cond2 if self.has_cond else None, self.conv1.weight, self.conv1.bias,
                              self.norm.weight, self.norm.bias, self.conv2.weight, self.conv2.bias,
                              self.conv3.weight, self.conv3.bias, T=T, taps=self.taps, shift=self.shift,
@@ -170,9 +172,21 @@ class BottleNeckResNet(nn.Module):
         cond2 = None if c is None else c.value.reshape(B * T, -1).to(dt).contiguous()
         temb = None if t is None else t.float()
         history = [h]
+        # time-embedding projections of all blocks as ONE Linear: same SiLU(t) for every block, the six
+        # (256 -> 512) weights concatenated along N (6 x ~14 tiny launches forward + backward become ~17)
+        tes = {}
+        timed = [i for i, b in enumerate(self.layers) if b.has_time] if (temb is not None and self.time_dim is not None) else []
+        if (len(timed) > 1 and len({type(self.layers[i].act) for i in timed}) == 1
+                and os.environ.get("VG_BATCH_TEMB", "1") != "0"):
+            a = self.layers[timed[0]].act(temb)
+            W = torch.cat([self.layers[i].time_emb.weight for i in timed], 0)
+            bvec = torch.cat([self.layers[i].time_emb.bias for i in timed], 0)
+            sizes = [self.layers[i].time_emb.out_features for i in timed]
+            for i, piece in zip(timed, F.linear(a, W, bvec).split(sizes, dim=1)):
+                tes[i] = piece
         for i, block in enumerate(self.layers):
             h = block.forward_rows(h, T, cond2 if self.conditional[i] else None,
-                                   temb if self.time_dim is not None else None)
+                                   temb if self.time_dim is not None else None, tes.get(i))
             src = self.skip_connection[i]
             if src is not None:
                 if self.skip_concat:
