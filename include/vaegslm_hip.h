@@ -305,6 +305,17 @@ int vg_l1_rows_fwd(const void* pred, const float* target, const int32_t* lengths
 int vg_l1_rows_bwd(const void* pred, const float* target, const float* gscale, const int32_t* lengths, int T,
                    void* dpred, int M, int C, int dtype, vg_stream_t stream);
 
+/* ---------------------------------------------------------------- channel norm of narrow rows
+ * y = act(gamma (x - mean) rstd + beta) per frame over C channels, UNBIASED variance (reference modules/norm.py:35-47)
+ * with an optional fused ReLU (ConvNormAct, modules/conv/layers.py:543-560), for widths the vg_dwnorm_* kernels do not
+ * take (2 <= C <= 1024; the utterance encoder's 128 / 256-channel layers).  x, y, dy, dx [M][C] in dtype; mean, rstd
+ * fp32 [M].  Backward: dx and part[vg_chnorm_blocks(M)][2 C] = per-block partial sums of (dgamma | dbeta). */
+int vg_chnorm_blocks(int M);
+int vg_chnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int C,
+                  float eps, int relu, int dtype, vg_stream_t stream);
+int vg_chnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
+                  void* dx, float* part, int M, int C, int relu, int dtype, vg_stream_t stream);
+
 /* ---------------------------------------------------------------- gradient exchange (RCCL)
  * The one collective of the path: the mean of the gradients over the data-parallel ranks, which the reference
  * gets from Lightning's DDP wrapper (training_lib/trainer.py:37-65 builds the strategy, the reduce happens inside

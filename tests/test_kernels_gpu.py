@@ -725,3 +725,37 @@ def test_colsum_multi_folds_several_partial_arrays_in_one_launch(F):
     torch.testing.assert_close(ps[1].grad, srcs[1].sum(0), rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(outs[2], srcs[2].sum(0), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(ps[3].grad, srcs[3].float().sum(0), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,relu", [(128, True), (256, False), (72, True)])
+def test_narrow_channel_norm_matches_tensor_ops(F, dtype, C, relu):
+    """vg_chnorm_fwd / _bwd (unbiased variance, optional fused ReLU) against the tensor expression the narrow
+    utterance-encoder layers used before: output, dx, dgamma, dbeta."""
+    M = 333
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(M, C, generator=g) * 1.5 + 0.3).to(dev()).to(dtype).requires_grad_(True)
+    w = torch.nn.Parameter((torch.rand(C, generator=g) + 0.5).to(dev()))
+    b = torch.nn.Parameter((torch.randn(C, generator=g) * 0.2).to(dev()))
+    dy = torch.randn(M, C, generator=g).to(dev()).to(dtype)
+    xf = x.float()
+    var, mean = torch.var_mean(xf, dim=-1, keepdim=True)
+    ref = w * ((xf - mean) * torch.rsqrt(var + 1e-5)) + b
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(dy.float())
+    want = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    y = F.narrow_channel_norm(x, w, b, eps=1e-5, relu=relu)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y.float(), ref.detach(), **tol)
+    y.backward(dy)
+    if dtype == torch.float32:
+        torch.testing.assert_close(x.grad, want[0], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(w.grad, want[1], rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(b.grad, want[2], rtol=1e-3, atol=1e-3)
+    else:       # bf16: the ReLU mask is taken from the rounded output, a handful of near-zero elements may differ
+        assert (x.grad.float() - want[0].float()).abs().mean() < 2e-2 * want[0].float().abs().mean() + 1e-3
+        torch.testing.assert_close(w.grad, want[1], rtol=5e-2, atol=0.5)
+        torch.testing.assert_close(b.grad, want[2], rtol=5e-2, atol=0.5)

@@ -993,3 +993,141 @@ extern "C" int vg_colsum_multi(const vg_colsum_task* tasks, int n, hipStream_t s
   colsum_multi_kernel<<<dim3((maxc + 15) / 16, n), dim3(256), 0, stream>>>(tk);
   return vg_host::check_launch("vg_colsum_multi");
 }
+
+// =====================================================================================
+// Per-frame channel norm for NARROW rows (the utterance encoder's 128- and 256-channel layers; the wide layers use
+// vg_dwnorm_*): y = act(gamma (x - mean) rstd + beta), unbiased variance (reference modules/norm.py:35-47), optional
+// fused ReLU (ConvNormAct, modules/conv/layers.py:543-560).  One wave per frame, lane-strided over C <= 1024.
+// Backward: dx, and per-block partial sums of (dgamma | dbeta) for vg_colsum_multi.
+// =====================================================================================
+namespace {
+constexpr int CN_ROWS = 16;            // frames per block (4 waves x 4)
+constexpr int CN_MAXE = 16;            // elements per lane: C <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void chnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                         int C, float eps, int relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < CN_ROWS; r += 4) {
+    const int m = blockIdx.x * CN_ROWS + r;
+    if (m >= M) return;
+    float v[CN_MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < CN_MAXE; ++e) {
+      const int c = lane + 64 * e;
+      v[e] = c < C ? to_f32<T>(x[(long)m * C + c]) : 0.f;
+      s += v[e];
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < CN_MAXE; ++e) {
+      const int c = lane + 64 * e;
+      const float d = c < C ? v[e] - mu : 0.f;
+      q += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)(C > 1 ? C - 1 : 1) + eps);
+#pragma unroll
+    for (int e = 0; e < CN_MAXE; ++e) {
+      const int c = lane + 64 * e;
+      if (c < C) {
+        float o = fmaf(gamma[c] * rs, v[e] - mu, beta[c]);
+        if (relu) o = fmaxf(o, 0.f);
+        y[(long)m * C + c] = from_f32<T>(o);
+      }
+    }
+    if (lane == 0) {
+      mean[m] = mu;
+      rstd[m] = rs;
+    }
+  }
+}
+
+// part[block][2 C]: dgamma | dbeta partial sums of the block's frames
+template <typename T>
+__global__ __launch_bounds__(256) void chnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const T* __restrict__ y, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         T* __restrict__ dx, float* __restrict__ part, int M, int C,
+                                                         int relu) {
+  __shared__ float acc[4][2][64 * CN_MAXE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[CN_MAXE], pb[CN_MAXE];
+#pragma unroll
+  for (int e = 0; e < CN_MAXE; ++e) pg[e] = pb[e] = 0.f;
+  for (int r = wave; r < CN_ROWS; r += 4) {
+    const int m = blockIdx.x * CN_ROWS + r;
+    if (m >= M) break;
+    const float mu = mean[m], rs = rstd[m];
+    float g[CN_MAXE], xh[CN_MAXE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < CN_MAXE; ++e) {
+      const int c = lane + 64 * e;
+      g[e] = xh[e] = 0.f;
+      if (c < C) {
+        float d = to_f32<T>(dy[(long)m * C + c]);
+        if (relu && !(to_f32<T>(y[(long)m * C + c]) > 0.f)) d = 0.f;
+        xh[e] = (to_f32<T>(x[(long)m * C + c]) - mu) * rs;
+        pg[e] = fmaf(d, xh[e], pg[e]);
+        pb[e] += d;
+        g[e] = d * gamma[c];
+        s1 += g[e];
+        s2 = fmaf(g[e], xh[e], s2);
+      }
+    }
+    // y = gamma xh + beta with xh = (x - mu) rs and rs from the UNBIASED variance:
+    // dx = rs (g - mean(g) - xh sum(g xh) / (C - 1))
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)(C > 1 ? C - 1 : 1);
+#pragma unroll
+    for (int e = 0; e < CN_MAXE; ++e) {
+      const int c = lane + 64 * e;
+      if (c < C) dx[(long)m * C + c] = from_f32<T>(rs * (g[e] - s1 - xh[e] * s2));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CN_MAXE; ++e) {
+    acc[wave][0][lane + 64 * e] = pg[e];
+    acc[wave][1][lane + 64 * e] = pb[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    part[(long)blockIdx.x * 2 * C + c] = acc[0][0][c] + acc[1][0][c] + acc[2][0][c] + acc[3][0][c];
+    part[(long)blockIdx.x * 2 * C + C + c] = acc[0][1][c] + acc[1][1][c] + acc[2][1][c] + acc[3][1][c];
+  }
+}
+}  // namespace
+
+extern "C" int vg_chnorm_blocks(int M) { return (M + CN_ROWS - 1) / CN_ROWS; }
+
+extern "C" int vg_chnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                             int M, int C, float eps, int relu, int dtype, hipStream_t stream) {
+  VG_REQUIRE(M > 0 && C >= 2 && C <= 64 * CN_MAXE, "vg_chnorm_fwd: M=%d C=%d (2..%d)", M, C, 64 * CN_MAXE);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_chnorm_fwd: bad dtype %d", dtype);
+  const dim3 grid((M + CN_ROWS - 1) / CN_ROWS);
+  if (dtype == VG_BF16)
+    chnorm_fwd_kernel<bf16_t><<<grid, dim3(256), 0, stream>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps, relu);
+  else
+    chnorm_fwd_kernel<float><<<grid, dim3(256), 0, stream>>>((const float*)x, gamma, beta, (float*)y, mean, rstd, M, C, eps, relu);
+  return vg_host::check_launch("vg_chnorm_fwd");
+}
+
+extern "C" int vg_chnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
+                             const float* rstd, void* dx, float* part, int M, int C, int relu, int dtype,
+                             hipStream_t stream) {
+  VG_REQUIRE(M > 0 && C >= 2 && C <= 64 * CN_MAXE && part != nullptr, "vg_chnorm_bwd: M=%d C=%d", M, C);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_chnorm_bwd: bad dtype %d", dtype);
+  VG_REQUIRE(!relu || y != nullptr, "vg_chnorm_bwd: the fused ReLU needs the forward output");
+  const dim3 grid((M + CN_ROWS - 1) / CN_ROWS);
+  if (dtype == VG_BF16)
+    chnorm_bwd_kernel<bf16_t><<<grid, dim3(256), 0, stream>>>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, mean,
+                                                              rstd, (bf16_t*)dx, part, M, C, relu);
+  else
+    chnorm_bwd_kernel<float><<<grid, dim3(256), 0, stream>>>((const float*)dy, (const float*)x, (const float*)y, gamma, mean, rstd,
+                                                             (float*)dx, part, M, C, relu);
+  return vg_host::check_launch("vg_chnorm_bwd");
+}

@@ -1006,6 +1006,44 @@ def channel_norm(x, weight, bias, *, T, eps):
     return ChannelNormFn.apply(x, weight, bias, T, eps)
 
 
+class NarrowChannelNormFn(torch.autograd.Function):
+    """Per-frame channel norm (unbiased variance, reference modules/norm.py:35-47) with an optional fused ReLU for
+    row widths the fused conv+norm kernels do not take (vg_chnorm_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        x = x.contiguous()
+        M, C = x.shape
+        gamma, beta = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        check(lib().vg_chnorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, C, float(eps),
+                                  int(bool(relu)), dtype_id(x.dtype), stream()), "vg_chnorm_fwd")
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, rstd)
+        ctx.params = (weight, bias)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.params
+        M, C = x.shape
+        dy = _as(dy, x.dtype)
+        dx = torch.empty_like(x)
+        nb = lib().vg_chnorm_blocks(M)
+        part = torch.empty(nb, 2 * C, dtype=torch.float32, device=x.device)
+        check(lib().vg_chnorm_bwd(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(part), M, C,
+                                  int(ctx.relu), dtype_id(x.dtype), stream()), "vg_chnorm_bwd")
+        g_w, g_b = vec_grads([(weight, part[:, :C]), (bias, part[:, C:])])
+        return dx, g_w, g_b, None, None
+
+
+def narrow_channel_norm(x, weight, bias, *, eps, relu=False):
+    return NarrowChannelNormFn.apply(x, weight, bias, eps, relu)
+
+
 # ---------------------------------------------------------------- coupling flow on the latent (row kernel)
 FLOW_PARAMS_PER_LAYER = 580     # W1[64][2] b1[64] ln_w[64] ln_b[64] W2[4][64] b2[4]
 

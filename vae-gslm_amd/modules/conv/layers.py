@@ -38,6 +38,8 @@ def channel_norm_rows(y: torch.Tensor, norm, T: int) -> torch.Tensor:
     width = 64 * (8 if y.dtype == torch.bfloat16 else 4)
     if y.shape[1] % width == 0 and y.shape[1] // width <= 2:
         return HF.channel_norm(y, norm.weight, norm.bias, T=T, eps=norm.eps)
+    if y.is_cuda and 2 <= y.shape[1] <= 1024 and os.environ.get("VG_NARROW_NORM", "1") != "0":
+        return HF.narrow_channel_norm(y, norm.weight, norm.bias, eps=norm.eps)      # vg_chnorm_*: any width
     x = y.float()
     var, mean = torch.var_mean(x, dim=-1, keepdim=True)
     return (norm.weight * ((x - mean) * torch.rsqrt(var + norm.eps)) + norm.bias).to(y.dtype)
@@ -263,8 +265,14 @@ class ConvNormAct(nn.Module):
         rows = win.permute(0, 1, 3, 2).reshape(B * t_out, k * C)        # tap-major, channel-minor
         w2 = self.conv.weight.permute(0, 2, 1).reshape(self.conv.out_channels, k * C)
         y = HF.linear(rows.to(hipvg.compute_dtype()).contiguous(), w2, self.conv.bias)
-        y = channel_norm_rows(y, self.norm, t_out)
-        y = self.act(y).view(B, t_out, -1)
+        width = 64 * (8 if y.dtype == torch.bfloat16 else 4)
+        wide = y.shape[1] % width == 0 and y.shape[1] // width <= 2
+        if (not wide and isinstance(self.act, nn.ReLU) and y.is_cuda and y.shape[1] <= 1024
+                and os.environ.get("VG_NARROW_NORM", "1") != "0"):
+            y = HF.narrow_channel_norm(y, self.norm.weight, self.norm.bias, eps=self.norm.eps, relu=True)
+        else:
+            y = self.act(channel_norm_rows(y, self.norm, t_out))
+        y = y.view(B, t_out, -1)
         if self.factor != 1:
             length = torch.clamp(TensorMask.resize_length(length, float(self.factor)), max=t_out)
         return y, length
