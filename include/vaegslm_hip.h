@@ -316,6 +316,15 @@ int vg_chnorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
 int vg_chnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
                   void* dx, float* part, int M, int C, int relu, int dtype, vg_stream_t stream);
 
+/* ---------------------------------------------------------------- strided-conv window gather
+ * Conv1d(k, stride, padding) on channels-last rows = window gather + one vg_gemm (ConvNormAct of the utterance
+ * encoder, modules/conv/layers.py:543-560): rows[b][to][tap][c] = x[b][to*stride + tap - pad_left][c] (zero outside
+ * the sequence), rows viewed as [B*t_out][k*C]; vg_conv_scatter is the adjoint (dx from drows, gather form). */
+int vg_conv_gather(const void* x, void* rows, int B, int T, int C, int t_out, int k, int stride, int pad_left, int dtype,
+                   vg_stream_t stream);
+int vg_conv_scatter(const void* drows, void* dx, int B, int T, int C, int t_out, int k, int stride, int pad_left,
+                    int dtype, vg_stream_t stream);
+
 /* ---------------------------------------------------------------- gradient exchange (RCCL)
  * The one collective of the path: the mean of the gradients over the data-parallel ranks, which the reference
  * gets from Lightning's DDP wrapper (training_lib/trainer.py:37-65 builds the strategy, the reduce happens inside

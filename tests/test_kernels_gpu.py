@@ -759,3 +759,21 @@ def test_narrow_channel_norm_matches_tensor_ops(F, dtype, C, relu):
         assert (x.grad.float() - want[0].float()).abs().mean() < 2e-2 * want[0].float().abs().mean() + 1e-3
         torch.testing.assert_close(w.grad, want[1], rtol=5e-2, atol=0.5)
         torch.testing.assert_close(b.grad, want[2], rtol=5e-2, atol=0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,stride,pl,pr", [(4, 2, 1, 1), (4, 2, 3, 0), (3, 1, 1, 1), (5, 3, 2, 1)])
+def test_conv_gather_and_its_adjoint(F, dtype, k, stride, pl, pr):
+    """vg_conv_gather / vg_conv_scatter against pad + unfold + permute (and autograd's backward of that)."""
+    B, T, C = 3, 37, 24
+    g = torch.Generator().manual_seed(k * 10 + stride)
+    x = torch.randn(B, T, C, generator=g).to(dev()).to(dtype).requires_grad_(True)
+    win = torch.nn.functional.pad(x, (0, 0, pl, pr)).unfold(1, k, stride)
+    ref = win.permute(0, 1, 3, 2).reshape(B * win.shape[1], k * C)
+    dr = torch.randn(ref.shape, generator=g).to(dev()).to(dtype)
+    ref.backward(dr)
+    want, x.grad = x.grad.clone(), None
+    rows = F.conv_gather(x, k, stride, pl, pr)
+    assert torch.equal(rows, ref.detach())
+    rows.backward(dr)
+    torch.testing.assert_close(x.grad.float(), want.float(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-2 if dtype == torch.bfloat16 else 1e-6)

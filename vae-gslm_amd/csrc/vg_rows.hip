@@ -1131,3 +1131,74 @@ extern "C" int vg_chnorm_bwd(const void* dy, const void* x, const void* y, const
                                                              (float*)dx, part, M, C, relu);
   return vg_host::check_launch("vg_chnorm_bwd");
 }
+
+// =====================================================================================
+// Window gather of a strided 1-D convolution on channels-last rows (ConvNormAct of the utterance encoder,
+// modules/conv/layers.py:543-560: Conv1d(k, stride) = gather + one GEMM):
+//   rows[b][to][tap][c] = x[b][to * stride + tap - pad_left][c]   (0 outside the sequence)
+// and its adjoint in gather form (no atomics):
+//   dx[b][t][c] = sum over taps with (t + pad_left - tap) % stride == 0 of drows[b][(t + pad_left - tap) / stride][tap][c]
+// =====================================================================================
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ x, T* __restrict__ rows, int B, int Tn,
+                                                          int C, int t_out, int k, int stride, int pl) {
+  const long total = (long)B * t_out * k * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int tap = (int)(r % k);
+    r /= k;
+    const int to = (int)(r % t_out), b = (int)(r / t_out);
+    const int t = to * stride + tap - pl;
+    rows[i] = (t >= 0 && t < Tn) ? x[((long)b * Tn + t) * C + c] : from_f32<T>(0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_scatter_kernel(const T* __restrict__ drows, T* __restrict__ dx, int B, int Tn,
+                                                           int C, int t_out, int k, int stride, int pl) {
+  const long total = (long)B * Tn * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int t = (int)(r % Tn), b = (int)(r / Tn);
+    float acc = 0.f;
+    for (int tap = 0; tap < k; ++tap) {
+      const int u = t + pl - tap;
+      if (u < 0 || u % stride != 0) continue;
+      const int to = u / stride;
+      if (to < t_out) acc += to_f32<T>(drows[(((long)b * t_out + to) * k + tap) * C + c]);
+    }
+    dx[i] = from_f32<T>(acc);
+  }
+}
+}  // namespace
+
+extern "C" int vg_conv_gather(const void* x, void* rows, int B, int T, int C, int t_out, int k, int stride, int pad_left,
+                              int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && T > 0 && C > 0 && t_out > 0 && k > 0 && stride > 0 && pad_left >= 0,
+             "vg_conv_gather: B=%d T=%d C=%d t_out=%d k=%d stride=%d", B, T, C, t_out, k, stride);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_conv_gather: bad dtype %d", dtype);
+  const long total = (long)B * t_out * k * C;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == VG_BF16)
+    conv_gather_kernel<bf16_t><<<dim3(grid), dim3(256), 0, stream>>>((const bf16_t*)x, (bf16_t*)rows, B, T, C, t_out, k, stride, pad_left);
+  else
+    conv_gather_kernel<float><<<dim3(grid), dim3(256), 0, stream>>>((const float*)x, (float*)rows, B, T, C, t_out, k, stride, pad_left);
+  return vg_host::check_launch("vg_conv_gather");
+}
+
+extern "C" int vg_conv_scatter(const void* drows, void* dx, int B, int T, int C, int t_out, int k, int stride,
+                               int pad_left, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && T > 0 && C > 0 && t_out > 0 && k > 0 && stride > 0 && pad_left >= 0,
+             "vg_conv_scatter: B=%d T=%d C=%d t_out=%d k=%d stride=%d", B, T, C, t_out, k, stride);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_conv_scatter: bad dtype %d", dtype);
+  const long total = (long)B * T * C;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == VG_BF16)
+    conv_scatter_kernel<bf16_t><<<dim3(grid), dim3(256), 0, stream>>>((const bf16_t*)drows, (bf16_t*)dx, B, T, C, t_out, k, stride, pad_left);
+  else
+    conv_scatter_kernel<float><<<dim3(grid), dim3(256), 0, stream>>>((const float*)drows, (float*)dx, B, T, C, t_out, k, stride, pad_left);
+  return vg_host::check_launch("vg_conv_scatter");
+}

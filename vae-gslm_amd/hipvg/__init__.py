@@ -92,6 +92,8 @@ SIGNATURES = {
     "vg_chnorm_blocks": [_i],
     "vg_chnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp],
     "vg_chnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vg_conv_gather": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "vg_conv_scatter": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "vg_comm_unique_id": [_vp, _i],
     "vg_comm_init": [_i, _i, _vp, _i],
     "vg_comm_world": [],

@@ -1006,6 +1006,34 @@ def channel_norm(x, weight, bias, *, T, eps):
     return ChannelNormFn.apply(x, weight, bias, T, eps)
 
 
+class ConvGatherFn(torch.autograd.Function):
+    """rows [B*t_out, k*C] of a strided 1-D convolution's windows from x [B, T, C] (tap-major, channel-minor)."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad_left, pad_right):
+        x = x.contiguous()
+        B, T, C = x.shape
+        t_out = (T + pad_left + pad_right - k) // stride + 1
+        rows = torch.empty(B * t_out, k * C, dtype=x.dtype, device=x.device)
+        check(lib().vg_conv_gather(ptr(x), ptr(rows), B, T, C, t_out, int(k), int(stride), int(pad_left),
+                                   dtype_id(x.dtype), stream()), "vg_conv_gather")
+        ctx.meta = (B, T, C, t_out, int(k), int(stride), int(pad_left))
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        B, T, C, t_out, k, stride, pl = ctx.meta
+        drows = drows.contiguous()
+        dx = torch.empty(B, T, C, dtype=drows.dtype, device=drows.device)
+        check(lib().vg_conv_scatter(ptr(drows), ptr(dx), B, T, C, t_out, k, stride, pl, dtype_id(drows.dtype), stream()),
+              "vg_conv_scatter")
+        return dx, None, None, None, None
+
+
+def conv_gather(x, k, stride, pad_left, pad_right):
+    return ConvGatherFn.apply(x, k, stride, pad_left, pad_right)
+
+
 class NarrowChannelNormFn(torch.autograd.Function):
     """Per-frame channel norm (unbiased variance, reference modules/norm.py:35-47) with an optional fused ReLU for
     row widths the fused conv+norm kernels do not take (vg_chnorm_*)."""

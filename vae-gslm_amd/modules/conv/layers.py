@@ -260,11 +260,16 @@ class ConvNormAct(nn.Module):
         B, T, C = h3.shape
         k, stride = self.conv.kernel_size[0], self.conv.stride[0]
         pl, pr = self.conv.two_side_padding if self.conv.two_side_padding is not None else (self.conv.padding[0],) * 2
-        win = F.pad(h3, (0, 0, pl, pr)).unfold(1, k, stride)            # (B, T_out, C, k) view
-        t_out = win.shape[1]
-        rows = win.permute(0, 1, 3, 2).reshape(B * t_out, k * C)        # tap-major, channel-minor
         w2 = self.conv.weight.permute(0, 2, 1).reshape(self.conv.out_channels, k * C)
-        y = HF.linear(rows.to(hipvg.compute_dtype()).contiguous(), w2, self.conv.bias)
+        if h3.is_cuda and os.environ.get("VG_CONV_GATHER", "1") != "0":
+            # window gather (padding, unfold, tap-major layout, dtype) as one HIP kernel; its adjoint in backward
+            rows = HF.conv_gather(h3.to(hipvg.compute_dtype()), k, stride, pl, pr)
+            t_out = rows.shape[0] // B
+        else:
+            win = F.pad(h3, (0, 0, pl, pr)).unfold(1, k, stride)            # (B, T_out, C, k) view
+            t_out = win.shape[1]
+            rows = win.permute(0, 1, 3, 2).reshape(B * t_out, k * C).to(hipvg.compute_dtype()).contiguous()
+        y = HF.linear(rows, w2, self.conv.bias)
         width = 64 * (8 if y.dtype == torch.bfloat16 else 4)
         wide = y.shape[1] % width == 0 and y.shape[1] // width <= 2
         if (not wide and isinstance(self.act, nn.ReLU) and y.is_cuda and y.shape[1] <= 1024
