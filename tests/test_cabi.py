@@ -84,3 +84,23 @@ def test_comm_entry_points_fail_cleanly_without_a_communicator(built_lib):
     assert "vg_comm_init" in hipvg.last_error()
     assert lib.vg_comm_init(3, 2, ctypes.c_void_p(4096), 128) != 0          # rank outside the world
     assert lib.vg_comm_destroy() == 0                                         # nothing to destroy is fine
+
+
+def test_colsum_task_layout_matches_header():
+    """Field order of the ctypes mirror of vg_colsum_task == the C struct (parsed from the header), and the task
+    limit agrees."""
+    import hipvg
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct vg_colsum_task \{(.*?)\} vg_colsum_task;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = [n.strip().lstrip("*") for n in decl.split(",")]
+        names[0] = names[0].split()[-1].lstrip("*")
+        fields += names
+    assert fields == [f[0] for f in hipvg.ColsumTask._fields_]
+    assert int(re.search(r"VG_COLSUM_MAX_TASKS\s*=\s*(\d+)", text).group(1)) == hipvg.COLSUM_MAX_TASKS
+    assert ctypes.sizeof(hipvg.ColsumTask) == 40
