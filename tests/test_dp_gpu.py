@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, cfg, use_graph, out):
+def _worker(rank, world, port, cfg, use_graph, out, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
@@ -31,7 +31,7 @@ def _worker(rank, world, port, cfg, use_graph, out):
     from training_lib.synthetic import make_batch
     cfg = copy.deepcopy(cfg)
     cfg.setdefault("hip", {})
-    cfg["hip"].update(precision="bf16", graph=use_graph, bucket_mb=4, graph_bucket_mb=4)
+    cfg["hip"].update(precision="bf16", graph=use_graph, bucket_mb=4, graph_bucket_mb=4, overlap=overlap)
     torch.manual_seed(11)                      # same initial weights on every rank
     tr = LVTRTrainer(Hparams.from_dict(cfg)).to(dev)
     for p in tr.model.parameters():
@@ -108,3 +108,20 @@ def test_bench_two_ranks_full_model_one_device():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert d["config"]["loss"] == d["config"]["loss"]          # finite (not NaN)
+
+
+def test_two_rank_eager_overlap_on_and_off_agree(full_cfg):
+    """SURVEY section 4 'overlap correctness': launching each bucket's all-reduce on the side stream as soon as its
+    last gradient lands (overlap on) must end where reducing on the compute stream (overlap off) ends.  Eager
+    micro-steps, two ranks on one device; split-K atomics reorder sums, so a few AdamW steps of tolerance."""
+    from oracle.lvtr_oracle import small_config
+    cfg = copy.deepcopy(full_cfg)
+    cfg["model"] = small_config(full_cfg["model"])
+    finals = {}
+    for overlap in (True, False):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), cfg, False, out, overlap), nprocs=2, join=True)
+        assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True)
+        finals[overlap] = out["params"]
+    torch.testing.assert_close(finals[True], finals[False], rtol=0.0, atol=4e-3)

@@ -777,3 +777,51 @@ def test_conv_gather_and_its_adjoint(F, dtype, k, stride, pl, pr):
     assert torch.equal(rows, ref.detach())
     rows.backward(dr)
     torch.testing.assert_close(x.grad.float(), want.float(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+
+
+def test_kernels_without_atomics_are_bitwise_repeatable(F):
+    """SURVEY section 5 (no GPU sanitizer on ROCm): determinism checks.  The same inputs twice through the kernels
+    that do not use floating-point atomics -- tile GEMM forward / dgrad (bf16, every operand mode, GELU + stored
+    derivative epilogue), attention forward and backward, RMSNorm forward and backward -- must give bitwise
+    identical results (an uninitialised LDS read or a race shows up as a flipped bit)."""
+    import hipvg
+    L, p, st = hipvg.lib(), hipvg.ptr, hipvg.stream()
+    B, T, H = 3, 200, 4
+    D = H * 64
+    M = B * T
+    lens = torch.tensor([200, 77, 1], dtype=torch.int32, device=dev())
+    x = rnd(M, D, dtype=torch.bfloat16)
+    w = rnd(3 * D, D, dtype=torch.bfloat16, scale=D ** -0.5)
+    bias = rnd(3 * D, scale=0.1)
+
+    def once():
+        out = {}
+        aux = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev())
+        out["nt"] = F.gemm(x, w, M, 3 * D, D, bias=bias, act=hipvg.ACT_GELU | hipvg.ACT_SAVE_DERIV, aux_out=aux,
+                           lengths=lens, T=T)
+        out["aux"] = aux
+        qkv = out["nt"]
+        out["nn"] = F.gemm(qkv, w, M, D, 3 * D, b_tr=True, lengths=lens, T=T)
+        slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
+        att = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+        lse = torch.empty(B, H, T, dtype=torch.float32, device=dev())
+        hipvg.check(L.vg_attn_fwd(p(qkv), p(att), p(lse), p(slopes), B, T, H, p(lens), 1, st), "attn_fwd")
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        hipvg.check(L.vg_attn_bwd(p(qkv), p(att), p(x), p(lse), p(slopes), p(dqkv), p(delta), B, T, H, p(lens), 1, st),
+                    "attn_bwd")
+        out.update(att=att, lse=lse, dqkv=dqkv)
+        sc = torch.rand(D, device=dev()) + 0.5 if False else torch.full((D,), 1.25, device=dev())
+        y, rstd = F.rmsnorm_fwd_raw(x, sc, 1e-6, lens, T)
+        dx, part = F.rmsnorm_bwd_raw(att, x, sc, rstd, None, lens, T)
+        out.update(rms_y=y, rms_dx=dx, rms_part=part)
+        return out
+
+    a, b = once(), once()
+    torch.cuda.synchronize()
+    valid = (torch.arange(T, device=dev())[None] < lens[:, None])[:, None, :].expand(B, H, T)
+    for k in a:
+        if k == "lse":          # the log-sum-exp of padded query rows is never written (nor read)
+            assert torch.equal(a[k][valid], b[k][valid]), k
+        else:
+            assert torch.equal(a[k], b[k]), k
