@@ -125,3 +125,72 @@ def test_two_rank_eager_overlap_on_and_off_agree(full_cfg):
         assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True)
         finals[overlap] = out["params"]
     torch.testing.assert_close(finals[True], finals[False], rtol=0.0, atol=4e-3)
+
+
+def _noise_for(B, T, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return dict(eps_q=torch.randn(B, T, 4, generator=g).to(dev), init_state=(torch.rand(B, 1, 64, generator=g) * 2 - 1).to(dev),
+                eps_p=torch.zeros(B, T, 4, device=dev), t_diff=torch.randint(0, 1000, (B,), generator=g).to(dev),
+                eps_diff=torch.randn(B, T, 80, generator=g).to(dev))
+
+
+def _one_step_worker(rank, world, port, cfg, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from hparams.hp import Hparams
+    from trainers.speech.lvtr import LVTRTrainer
+    from training_lib.synthetic import make_batch
+    torch.manual_seed(11)
+    tr = LVTRTrainer(Hparams.from_dict(copy.deepcopy(cfg))).to(dev)
+    tr.configure_optimizers()
+    tr.attach_reducer()
+    tr.global_step = cfg["training"]["scheduler"]["warmup_kld"]
+    tr.training_step(make_batch(2, 64, dev, seed=700 + rank, lengths=[64, 40 + rank]), 0, noise=_noise_for(2, 64, 900 + rank, dev))
+    torch.cuda.synchronize()
+    if rank == 0:
+        out["params"] = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()]).cpu()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_concatenated_batch(full_cfg):
+    """SURVEY section 4 'DP=k with global batch N == one GPU with batch N': two ranks with two sequences each
+    (gradients averaged as DDP does) against one process on the four sequences, same injected noise, one AdamW step
+    from the same initial weights.  The single-process gradient is the sum instead of the mean -- a factor of 2 that
+    Adam's normalisation removes -- so the updated parameters must agree closely."""
+    from oracle.lvtr_oracle import small_config
+    from hparams.hp import Hparams
+    from trainers.speech.lvtr import LVTRTrainer
+    from training_lib.synthetic import make_batch
+    from utils.tensormask import TensorMask
+    cfg = copy.deepcopy(full_cfg)
+    cfg["model"] = small_config(full_cfg["model"])
+    cfg["training"]["gradient_accumulation"] = 1
+    cfg.setdefault("hip", {})
+    cfg["hip"].update(precision="bf16", graph=False, bucket_mb=4)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_step_worker, args=(2, _free_port(), cfg, out), nprocs=2, join=True)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    tr = LVTRTrainer(Hparams.from_dict(copy.deepcopy(cfg))).to(dev)
+    tr.configure_optimizers()
+    tr.attach_reducer()
+    tr.global_step = cfg["training"]["scheduler"]["warmup_kld"]
+    start = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()]).cpu()
+    parts = [make_batch(2, 64, dev, seed=700 + r, lengths=[64, 40 + r]) for r in range(2)]
+    batch = {k: TensorMask(torch.cat([b[k].value for b in parts], 0), torch.cat([b[k].mask for b in parts], 0))
+             for k in parts[0]}
+    ns = [_noise_for(2, 64, 900 + r, dev) for r in range(2)]
+    noise = {k: torch.cat([n[k] for n in ns], 0) for k in ns[0]}
+    tr.training_step(batch, 0, noise=noise)
+    torch.cuda.synchronize()
+    single = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()]).cpu()
+    dp = out["params"]
+    moved = (single - start).abs()
+    assert moved.max() > 1e-4
+    # one Adam step moves every weight by about lr = 5e-4; the two runs must land within a small fraction of that
+    # almost everywhere (bf16 kernels, atomics and Adam's eps leave a tail on near-zero gradients)
+    close = ((single - dp).abs() <= 1e-4).float().mean().item()
+    assert close > 0.97, close
