@@ -104,3 +104,16 @@ def test_colsum_task_layout_matches_header():
     assert fields == [f[0] for f in hipvg.ColsumTask._fields_]
     assert int(re.search(r"VG_COLSUM_MAX_TASKS\s*=\s*(\d+)", text).group(1)) == hipvg.COLSUM_MAX_TASKS
     assert ctypes.sizeof(hipvg.ColsumTask) == 40
+
+
+def test_roctx_ranges_wrap_the_entry_points(monkeypatch):
+    """VG_ROCTX=1: launch entry points are bracketed by roctx ranges (tracing aid); query functions stay direct.
+    Checked in a fresh interpreter so the cached library handle of this process is left alone."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import hipvg; L = hipvg.lib(); "
+            "assert type(L).__name__ == '_RoctxLib'; assert L.vg_version() >= 100; "
+            "assert L.vg_comm_destroy() == 0; assert L.vg_rmsnorm_bwd_blocks(8000) == 512; print('ok')"
+            % os.path.join(ROOT, "vae-gslm_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VG_ROCTX="1"), capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -144,8 +144,48 @@ def lib() -> C.CDLL:
                     fn = getattr(handle, name)     # AttributeError if the ABI lost a symbol
                     fn.argtypes = argtypes
                     fn.restype = C.c_int
+                if os.environ.get("VG_ROCTX", "0") == "1":
+                    handle = _with_roctx_ranges(handle)
                 _lib = handle
     return _lib
+
+
+class _RoctxLib:
+    """The library with every launch entry point bracketed by a roctx range named after the symbol, so that
+    `rocprofv3 --marker-trace` shows which C-ABI call a kernel belongs to (VG_ROCTX=1; tracing only)."""
+
+    def __init__(self, handle, roctx):
+        self._h, self._push, self._pop = handle, roctx.roctxRangePushA, roctx.roctxRangePop
+        self._push.argtypes, self._push.restype = [C.c_char_p], C.c_int
+        self._pop.argtypes, self._pop.restype = [], C.c_int
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw = getattr(self._h, name)
+            if name.endswith("_blocks") or name in ("vg_version", "vg_last_error", "vg_comm_world", "vg_gemm_tile_rows"):
+                fn = raw
+            else:
+                tag, push, pop = name.encode(), self._push, self._pop
+
+                def fn(*args, _raw=raw, _tag=tag):
+                    push(_tag)
+                    try:
+                        return _raw(*args)
+                    finally:
+                        pop()
+            self._cache[name] = fn
+        return fn
+
+
+def _with_roctx_ranges(handle):
+    for cand in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+        try:
+            return _RoctxLib(handle, C.CDLL(cand))
+        except OSError:
+            continue
+    raise RuntimeError("VG_ROCTX=1 but libroctx64.so was not found")
 
 
 def last_error() -> str:
