@@ -375,6 +375,7 @@ class LVTRTrainer(BaseTrainer):
             if static[k].mask is not v.mask and not getattr(static[k].mask, "_vg_full", False):
                 static[k].mask.copy_(v.mask, non_blocking=True)
                 static[k].mask._vg_len32 = None
+                static[k].mask._vg_len64 = None
         graph.replay()
         reduce_now = last and self.reducer is not None and self.reducer.world > 1
         if graph2 is not None:

@@ -71,7 +71,17 @@ class TensorMask(object):
 
     @property
     def length(self) -> torch.Tensor:
-        return self.mask.long().sum(-1)
+        """int64 [B] valid-frame counts, cached on the mask tensor like ``lengths32`` (a step asks for them about
+        ten times: two tiny launches each)."""
+        m = self.mask
+        cached = getattr(m, "_vg_len64", None)
+        if cached is None:
+            cached = m.long().sum(-1)
+            try:
+                m._vg_len64 = cached
+            except AttributeError:
+                pass
+        return cached
 
     @property
     def device(self):
