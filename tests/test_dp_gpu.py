@@ -65,7 +65,7 @@ def test_two_rank_training_on_gpu(full_cfg, use_graph):
     cfg = copy.deepcopy(full_cfg)
     cfg["model"] = small_config(full_cfg["model"])
     world = 2
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), cfg, use_graph, out), nprocs=world, join=True)
     assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True)
@@ -81,7 +81,7 @@ def test_two_rank_segmented_replay_matches_one_graph(full_cfg, monkeypatch):
     finals = {}
     for seg in ("2", "1"):
         monkeypatch.setenv("VG_GRAPH_SEGMENTS", seg)
-        mgr = mp.Manager()
+        mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
         out = mgr.dict()
         mp.spawn(_worker, args=(2, _free_port(), cfg, True, out), nprocs=2, join=True)
         assert out[0] == (True, True, True, True) and out["segmented"] == (seg == "2")
@@ -119,7 +119,7 @@ def test_two_rank_eager_overlap_on_and_off_agree(full_cfg):
     cfg["model"] = small_config(full_cfg["model"])
     finals = {}
     for overlap in (True, False):
-        mgr = mp.Manager()
+        mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
         out = mgr.dict()
         mp.spawn(_worker, args=(2, _free_port(), cfg, False, out, overlap), nprocs=2, join=True)
         assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True)
@@ -169,7 +169,7 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(full_cfg):
     cfg["training"]["gradient_accumulation"] = 1
     cfg.setdefault("hip", {})
     cfg["hip"].update(precision="bf16", graph=False, bucket_mb=4)
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
     out = mgr.dict()
     mp.spawn(_one_step_worker, args=(2, _free_port(), cfg, out), nprocs=2, join=True)
     dev = torch.device("cuda:0")

@@ -651,6 +651,7 @@ def _grad_buffer(p: Tensor) -> Tensor:
 
 
 def _fire(p: Tensor) -> None:
+    p._vg_sunk = True            # this parameter's gradient is written by the library, not by AccumulateGrad
     for h in getattr(p, "_vg_grad_hooks", ()):
         h(p)
 

@@ -64,6 +64,8 @@ class LVTRTrainer(BaseTrainer):
         self._graphs = {}
         self._kw_dev = None
         self._compute_stream = None
+        self._owned = None             # parameters whose gradients arrive through autograd's AccumulateGrad
+        self._fold_accum = os.environ.get("VG_FOLD_ACCUM", "1") != "0"
         # optional: the micro-batches of an accumulation window as one batch (same gradient, taller GEMMs)
         self.coalesce = bool(hip.get("coalesce_accumulation", False)) if hip is not None else False
         self._held = []
@@ -182,9 +184,29 @@ class LVTRTrainer(BaseTrainer):
             loss = loss + out["ce_loss"] * (self.token_kld_weight * kld_weight)
         if self.reducer is not None:
             self.reducer.new_backward()
+        # Parameters autograd still owns (stock sub-networks) get their gradient through AccumulateGrad, which ADDS
+        # into the bucket view (one tiny launch per parameter, ~50 per step).  With the views taken away autograd
+        # keeps the fresh gradient tensors instead, and one multi-tensor launch adds them afterwards.  Only where
+        # nothing acts on "gradient ready" before the pass ends (one rank, or a captured / non-final micro-step).
+        fold = None
+        if (self._owned is not None and self.reducer is not None and backward_tail and not getattr(self, "_segmented", False)
+                and (self.reducer.world == 1 or not self.reducer.sync_now) and self._fold_accum):
+            fold = [(p, p.grad) for p in self._owned if p.grad is not None]
+            for p, _ in fold:
+                p.grad = None
         loss.backward()
         if backward_tail:
             self._backward_tail()
+        if fold is not None:
+            pairs = [(v, p.grad) for p, v in fold if p.grad is not None]
+            if pairs:
+                torch._foreach_add_([v for v, _ in pairs], [g for _, g in pairs])
+            for p, v in fold:
+                p.grad = v
+        elif self._owned is None and self.reducer is not None:
+            # after the first backward: who was never written by the library?
+            self._owned = [p for p in self.model.parameters()
+                           if p.requires_grad and p.grad is not None and not getattr(p, "_vg_sunk", False)]
         result = {"kld": kld.detach(), "rec_loss": rec.detach(), "log_p": -out["log_p"].mean().detach(),
                   "length": out["log_p"].length.sum(), "kld_weight": kld_weight,
                   "logstd": out["logstd"].detach(), "q_logstd": out["q_logstd"].detach(),
