@@ -39,27 +39,39 @@ TRAIN_FLOP_PER_TOKEN = 1.3238e9      # BASELINE.md section 3 (hot path, causal-e
 PEAK_BF16 = 2.5e15                   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(threads_note=True):
-    """Oracle (CPU port of the reference fp32 path): full config, B=1, T=1000,
-    one forward+backward after a short warm-up at T=64."""
+    """Oracle (CPU port of the reference fp32 path): full config, B=2, T=1000,
+    forward+backward after a short warm-up at T=64, on every host core."""
     import yaml
     from oracle import lvtr_oracle as O
     from oracle.weights import fill_like
     with open(CONFIG) as f:
         cfg = yaml.safe_load(f)
-    # intra-op threads: all cores up to 32 (more only adds synchronisation cost on these shapes)
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(os.cpu_count() or 1)
     mcfg = cfg["model"]
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in fill_like(O.param_shapes(mcfg), 1).items()}
 
+    B = 2
+
     def one(T, seed):
         g = torch.Generator().manual_seed(seed)
-        batch = dict(tokens=torch.randint(0, 200, (1, T), generator=g), mel=torch.randn(1, T, 80, generator=g),
-                     lengths=torch.tensor([T]), utt=torch.randn(1, 150, 80, generator=g),
-                     utt_lengths=torch.tensor([150]))
-        noise = dict(eps_q=torch.randn(1, T, 4, generator=g), init_state=torch.rand(1, 1, 64, generator=g) * 2 - 1,
-                     eps_p=torch.zeros(1, T, 4), t_diff=torch.randint(0, 1000, (1,), generator=g),
-                     eps_diff=torch.randn(1, T, 80, generator=g))
+        batch = dict(tokens=torch.randint(0, 200, (B, T), generator=g), mel=torch.randn(B, T, 80, generator=g),
+                     lengths=torch.tensor([T] * B), utt=torch.randn(B, 150, 80, generator=g),
+                     utt_lengths=torch.tensor([150] * B))
+        noise = dict(eps_q=torch.randn(B, T, 4, generator=g), init_state=torch.rand(B, 1, 64, generator=g) * 2 - 1,
+                     eps_p=torch.zeros(B, T, 4), t_diff=torch.randint(0, 1000, (B,), generator=g),
+                     eps_diff=torch.randn(B, T, 80, generator=g))
         out = O.training_loss(sd, mcfg, cfg["training"], batch, noise)
         out["loss"].backward()
         for v in sd.values():
@@ -83,8 +95,9 @@ def cpu_baseline(threads_note=True):
             one(T, 3 + i)
         steps += more
         dt = time.perf_counter() - t0
-    return {"value": steps * T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd, full config, B=1, T={T}, {steps} step(s) ({dt:.1f} s) after a warm-up"}
+    return {"value": steps * B * T / dt, "unit": "tokens/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "cpu_model": cpu_model_name(), "threads": torch.get_num_threads(),
+            "sample": f"oracle fp32 fwd+bwd, full config, B={B}, T={T}, {steps} step(s) ({dt:.1f} s) after a warm-up"}
 
 
 def main():
@@ -147,7 +160,12 @@ def main():
         for p in trainer.model.parameters():
             dist.broadcast(p.data, 0)
     trainer.configure_optimizers()
-    trainer.attach_reducer()
+    reducer = trainer.attach_reducer()
+    ranks = reducer.communicator_ranks()
+    if ranks != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the gradient communicator has {ranks} rank(s) "
+                         f"(comm={args.comm}, backend={dist.get_backend() if world > 1 else 'none'})")
+    reducer.time_collectives = world > 1
     trainer.global_step = hp.training.scheduler.warmup_kld      # past the KL warm-up
     # event pairs captured into the graph do not report on replay (and cost graph nodes): off unless asked for
     trainer.profile_in_graph = bool(args.graph) and os.environ.get("VG_PROF_IN_GRAPH", "0") == "1"
@@ -198,6 +216,22 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    comm = reducer.comm_stats() if world > 1 else None
+    comm_exposed_ms = None
+    if world > 1:
+        # the same steps without their collectives: the difference is the part of the exchange nothing hides
+        reducer.time_collectives, reducer.stub_collectives = False, True
+        n_stub = min(args.steps, 3)
+        sync()
+        t1 = time.perf_counter()
+        for j in range(n_stub * accum):
+            trainer.training_step(fetch(it - accum * n_stub + j) if not args.host_batches else batches[it - accum * n_stub + j],
+                                  it - accum * n_stub + j)
+        sync()
+        stub = torch.tensor([(time.perf_counter() - t1) / n_stub], device=device, dtype=torch.float64)
+        dist.all_reduce(stub, op=dist.ReduceOp.MAX)
+        reducer.stub_collectives = False
+        comm_exposed_ms = 1e3 * (elapsed / args.steps - float(stub.item()))
     tokens = args.steps * accum * B * T_SEQ * world
     if args.ragged:     # valid frames of the timed micro-batches (this rank's draw, times the ranks)
         tokens = world * sum(sum(l) for l in all_lens[args.warmup * accum:])
@@ -219,6 +253,12 @@ def main():
             ms, work, n = hipvg.prof_read(k)
             if n:
                 kinds[k] = {"launches": n, "avg_us": 1e3 * ms / n, "tflops": work / (ms * 1e-3) / 1e12}
+        # HBM-bound row kernels: algorithmic bytes / launch time, against the copy rate measured below
+        hbm_kernels = {}
+        for k in ("rmsnorm_fwd", "rmsnorm_bwd", "adamw", "dwnorm_fwd", "dwnorm_bwd"):
+            ms, nbytes, n = hipvg.prof_read(k)
+            if n:
+                hbm_kernels[k] = {"launches": n, "avg_us": 1e3 * ms / n, "gb_per_s": nbytes / (ms * 1e-3) / 1e9}
             if k.startswith("gemm_bf16"):
                 tot_ms += ms
                 tot_work += work
@@ -226,15 +266,20 @@ def main():
                 tot_n += n
         hipvg.prof_enable(False)
         achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
+        peaks = hipvg.probe_peaks(device)          # this box, this run: register-fed MFMA chains and a 1 GiB copy
         # HBM-side bytes per launch of the same kernel family: bench.py cannot collect PMC counters itself, so
         # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
         # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v9.json), valid for the default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v9.json")
+        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v9.json")
         if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16" and args.coalesce and not args.ragged:
             with open(pmc) as f:
                 traffic = json.load(f)["bf16_gemm_family"]["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01/pmc_traffic_v9.json (separate --pmc passes over the same command)"
+            traffic_src = (os.path.relpath(pmc, ROOT) + ": STATIC figure from committed rocprofv3 --pmc FETCH_SIZE / "
+                           "WRITE_SIZE passes over this command (bench.py cannot read PMC counters itself); it "
+                           "describes the build that profile was taken on")
         # 25,165,824 GEMM + 2*2*1024*(T+1)/2 attention FLOP per layer, 16 layers, + heads; x3
         flop_per_token = 3.0 * (16 * (25165824 + 2 * 2 * 1024 * (T_SEQ + 1) / 2) + 131072 + 5671936)
         line = {
@@ -254,17 +299,32 @@ def main():
                        "accumulation": "one launch sequence over B x accum sequences" if args.coalesce else "per micro-batch"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_static": traffic is not None,
+                         "traffic_source": traffic_src,
                          # operands and results once each, summed over the launches the figure above averages
                          "algorithmic_bytes_per_launch": tot_bytes / tot_n if tot_n else None,
-                         # register-fed v_mfma_f32_32x32x16_bf16 loop on this pool's MI355X (tools/lab/peak_probe.hip)
-                         "peak_measured": 2136.0, "frac_of_measured": achieved / 2136.0,
+                         # measured in this run (hipvg.probe_peaks: register-fed v_mfma_f32_32x32x16_bf16 chains)
+                         "peak_measured": peaks["mfma_bf16_dense_tflops"],
+                         "frac_of_measured": achieved / peaks["mfma_bf16_dense_tflops"],
+                         "hbm_copy_measured_tb_per_s": peaks["hbm_copy_tb_per_s"], "hbm_peak_tb_per_s": 8.0,
+                         "hbm_kernels": hbm_kernels,
                          "measured_on": ("one eager optimizer step right after the timed hipGraph replays"
                                          if args.graph else "the timed region"),
                          "step_model_tflops": value / world * flop_per_token / 1e12,
                          "step_model_frac": value / world * flop_per_token / PEAK_BF16,
                          "kernels": kinds},
         }
+        if world > 1:
+            nb = len(reducer.buckets)
+            line["comm"] = {"rccl_ranks": ranks, "mode": args.comm,
+                            "backend": dist.get_backend(), "buckets": nb,
+                            "bucket_bytes": [int(b["flat"].numel() * 4) for b in reducer.buckets],
+                            "allreduce_ms_per_step": comm["allreduce_ms"] / args.steps,
+                            "allreduce_bytes_per_step": comm["allreduce_bytes"] / args.steps,
+                            "collectives_per_step": comm["collectives"] / args.steps,
+                            "comm_exposed_ms": comm_exposed_ms,
+                            "note": "allreduce_ms: events on the communication stream (rank 0); comm_exposed_ms: "
+                                    "ms_per_step minus the same steps with the collectives skipped"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

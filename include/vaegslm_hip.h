@@ -347,11 +347,23 @@ int vg_comm_destroy(void);
  * stops; vg_prof_read() synchronises and returns, for one kind, the summed
  * launch durations (ms), the summed ALGORITHMIC work (FLOPs) and the launch count. */
 enum { VG_PROF_GEMM_BF16_NT = 0, VG_PROF_GEMM_BF16_NN = 1, VG_PROF_GEMM_BF16_TN = 2,
-       VG_PROF_GEMM_F32 = 3, VG_PROF_ATTN_FWD = 4, VG_PROF_ATTN_BWD = 5 };
+       VG_PROF_GEMM_F32 = 3, VG_PROF_ATTN_FWD = 4, VG_PROF_ATTN_BWD = 5,
+       /* HBM-bound row kernels: `work` is their ALGORITHMIC byte count */
+       VG_PROF_RMSNORM_FWD = 6, VG_PROF_RMSNORM_BWD = 7, VG_PROF_ADAMW = 8,
+       VG_PROF_DWNORM_FWD = 9, VG_PROF_DWNORM_BWD = 10, VG_PROF_KINDS = 11 };
 int vg_prof_enable(int on);
 int vg_prof_read(int kind, double* total_ms, double* total_work, int* launches);
 /* summed ALGORITHMIC bytes (operands and results once each) of the recorded launches of one kind (GEMM kinds) */
 int vg_prof_read_bytes(int kind, double* total_bytes);
+
+/* Peak probes for the box the measurement runs on ("measured peaks, do not hard-code"); the caller
+ * times the launch with events on `stream`.
+ *   vg_probe_mfma: `blocks` x 256 threads, every wave issues 4 independent chains of `iters` x 4
+ *                  v_mfma_f32_32x32x16_bf16 from registers = blocks * 4 waves * iters * 4 * 32768 FLOP;
+ *                  `out` takes blocks * 256 floats (keeps the chains alive).
+ *   vg_probe_copy: streaming copy of `bytes` (multiple of 16) with 16-byte accesses = 2 * bytes of HBM traffic. */
+int vg_probe_mfma(float* out, int blocks, int iters, vg_stream_t stream);
+int vg_probe_copy(const void* src, void* dst, int64_t bytes, int blocks, vg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,8 @@ What is captured:
   (B=2, T=96) -- pins H=16 ALiBi slopes, d=1024, 16 layers;
 * ``modules.npz``   per-module vectors: RMSNorm, SelfAttention,
   TransformerLayer, GaussianParameterize, masked_ce_loss, masked_loss, ALiBi;
-* ``decode_c1.npz`` teacher-forced KV-cache decode (prefill 30 + 10 steps).
+* ``decode_c1.npz`` teacher-forced KV-cache decode (prefill 30 + 10 steps);
+* ``extras_c1.npz`` ``LVTR.likelihood`` (models/speech/lvtr.py:337-388) on the C1 batch.
 
 Weights are not stored: both sides regenerate them with
 ``oracle.weights.fill_like``.  Noise tensors ARE stored (they are inputs).
@@ -313,6 +314,21 @@ def run_decode(mods, model_cfg, model, seed=99):
     print("[decode] written; cache len", kv[0]["key"].shape[1])
 
 
+def run_extras(mods, model, batch, noise):
+    """``LVTR.likelihood`` of the reference on the step_c1 batch (temperature 0; the start frame is the same
+    injected draw as in the training step; the two Gaussian heads still draw their unused noise)."""
+    TensorMask = mods["utils.tensormask"].TensorMask
+    T = batch["tokens"].shape[1]
+    mask = torch.arange(T)[None] < torch.from_numpy(batch["lengths"])[:, None]
+    x = TensorMask(torch.from_numpy(batch["tokens"]), mask).expand().cat(TensorMask(torch.from_numpy(batch["mel"]), mask))
+    q = [("randn", torch.from_numpy(noise["eps_q"])), ("rand", torch.from_numpy(noise["init_rand"])),
+         ("randn", torch.from_numpy(noise["eps_p"]))]
+    with torch.no_grad(), NoiseQueue(q):
+        ll = model.likelihood(x, temperature=0.0)
+    np.savez_compressed(os.path.join(HERE, "extras_c1.npz"), likelihood=ll.numpy().astype(np.float64))
+    print("[extras] likelihood", ll.numpy())
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -325,7 +341,8 @@ def main():
     mine = {k: v for k, v in cfg.items() if k != "hip"}
     assert mine == ref_cfg, "build yaml diverged from the reference yaml"
     c1 = small_config(cfg["model"])
-    model, _, _ = run_step(mods, c1, cfg["training"], "c1", 2, 200, [200, 163], 150, seed=1234)
+    model, batch, noise = run_step(mods, c1, cfg["training"], "c1", 2, 200, [200, 163], 150, seed=1234)
+    run_extras(mods, model, batch, noise)
     run_decode(mods, c1, model)
     run_step(mods, cfg["model"], cfg["training"], "full", 2, 96, [96, 61], 150, seed=4321)
     run_modules(mods, c1)

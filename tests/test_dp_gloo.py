@@ -135,3 +135,62 @@ def test_sunk_gradients_report_once_per_backward():
     out = mgr.dict()
     mp.spawn(_sink_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _reuse_worker(rank, world, port, out):
+    """A sunk parameter that is used TWICE in the forward (its gradient sink reports after each contribution) next
+    to a parameter that gets no gradient at all: the bucket must be reduced after the last contribution, exactly
+    once per pass, and the result must be the rank average of the full gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from training_lib.dp import GradReducer
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(5, 5))
+    unused = torch.nn.Parameter(torch.randn(3))
+    lin = torch.nn.Linear(5, 2)
+    red = GradReducer([w, unused, lin.weight, lin.bias], bucket_mb=50.0)
+    launches, snapshots = [], []
+    orig = red._launch
+
+    def spy(b):
+        launches.append(1)
+        snapshots.append(w.grad.clone())          # local (un-reduced) gradient of `w` at launch time
+        return orig(b)
+    red._launch = spy
+    g = torch.Generator().manual_seed(3 + rank)
+    ok = True
+    for step in range(3):
+        x = torch.randn(4, 5, generator=g)
+        red.new_backward(signature=("twice",))
+        y = lin(_SinkLinear.apply(_SinkLinear.apply(x, w), w))      # w used twice
+        y.pow(2).sum().backward()
+        red.finish()
+        ok &= len(launches) == step + 1
+        wr = w.detach().clone().requires_grad_(True)
+        torch.nn.functional.linear((x @ wr.t()) @ wr.t(), lin.weight.detach(), lin.bias.detach()).pow(2).sum().backward()
+        ok &= bool(torch.allclose(snapshots[-1], wr.grad, atol=1e-5, rtol=1e-5))     # BOTH contributions were in
+        gathered = [torch.zeros_like(wr.grad) for _ in range(world)]
+        dist.all_gather(gathered, wr.grad)
+        ok &= bool(torch.allclose(w.grad, sum(gathered) / world, atol=1e-5, rtol=1e-5))
+        ok &= float(unused.grad.abs().sum()) == 0.0
+        ok &= all(b["pending"] == b["need"] for b in red.buckets)
+        red.zero_grad()
+    # a different step structure under the SAME signature is detected instead of silently racing
+    x = torch.randn(4, 5, generator=g)
+    red.new_backward(signature=("twice",))
+    lin(_SinkLinear.apply(_SinkLinear.apply(_SinkLinear.apply(x, w), w), w)).pow(2).sum().backward()
+    try:
+        red.finish()
+        ok = False
+    except RuntimeError as exc:
+        ok &= "more often" in str(exc)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_reused_sunk_parameter_is_reduced_after_its_last_contribution():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_reuse_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}

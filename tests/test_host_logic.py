@@ -167,3 +167,114 @@ def test_background_loader_order_and_errors():
     next(it)
     with pytest.raises(KeyError):
         next(it)
+
+
+def test_weight_initialisation_follows_the_reference_rules(full_cfg):
+    """SURVEY row a17.  ``BaseTrainer.init_weights`` (reference training_lib/trainer.py:113-125): every bias zero,
+    LayerNorm / GroupNorm scales one, then the modules' own rules: ``SelfAttention.custom_weight_init``
+    (modules/attention/attention.py:95-98) draws in_proj / out_proj from U(-b, b), b = init_std / sqrt(dim / 3);
+    ``Embedding.custom_weight_init`` (modules/linear/layers.py:154-157) draws from U(-1, 1); every other weight
+    keeps torch's default (|w| <= 1 / sqrt(fan_in) for Linear / Conv1d)."""
+    from oracle.lvtr_oracle import small_config
+    from trainers.speech.lvtr import LVTRTrainer
+    cfg = copy.deepcopy(full_cfg)
+    cfg["model"] = small_config(cfg["model"])
+    torch.manual_seed(3)
+    tr = LVTRTrainer(Hparams.from_dict(cfg))
+    init_std = cfg["training"].get("init_std", 1.0)
+    dim = cfg["model"]["transformer"]["layer"]["dim"]
+    bound = init_std / math.sqrt(dim / 3)
+    seen_attn = 0
+    for name, mod in tr.model.named_modules():
+        bias = getattr(mod, "bias", None)
+        if isinstance(bias, torch.Tensor):
+            assert float(bias.abs().max()) == 0.0, name
+        if isinstance(mod, (torch.nn.LayerNorm, torch.nn.GroupNorm)) and mod.weight is not None:
+            assert torch.all(mod.weight == 1.0), name
+        if type(mod).__name__ == "SelfAttention":
+            seen_attn += 1
+            for w in (mod.in_proj.weight, mod.out_proj.weight):
+                assert float(w.abs().max()) <= bound
+                assert float(w.abs().max()) > 0.98 * bound                     # the range is filled ...
+                assert abs(float(w.std()) - bound / math.sqrt(3)) < 0.03 * bound  # ... uniformly
+                assert abs(float(w.mean())) < 0.02 * bound
+        elif type(mod).__name__ == "Embedding":
+            w = mod.weight
+            assert float(w.abs().max()) <= 1.0 and float(w.abs().max()) > 0.99
+            assert abs(float(w.std()) - 1 / math.sqrt(3)) < 0.02
+        elif isinstance(mod, (torch.nn.Linear, torch.nn.Conv1d)) and "self_attn" not in name:
+            fan_in = mod.weight[0].numel()
+            assert float(mod.weight.abs().max()) <= 1 / math.sqrt(fan_in) + 1e-6, name
+    assert seen_attn == cfg["model"]["transformer"]["num_layers"]
+    # RMSNorm scales stay at one (reference modules/norm.py:26)
+    assert all(torch.all(p == 1.0) for n, p in tr.model.named_parameters() if n.endswith(".scale"))
+
+
+def test_non_hot_surface_is_importable_and_matches_the_reference():
+    """``modules.position.{rotary,t5}`` and the other ``modules.linear.layers`` classes import, build
+    and -- where the reference file is importable here -- compute what the reference computes."""
+    from modules.linear.layers import GumbelSoftMaxParameterize, LinearBlock, LinearLayerStack, RVQEmbedding
+    from modules.position.embedding import Rotary, T5RPE
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(2, 3, 9, 32, generator=g)
+    rot = Rotary(32)
+    out = rot.rotate_queries_or_keys(q)
+    assert out.shape == q.shape and abs(float(out.norm() - q.norm())) < 1e-3      # a rotation
+    assert torch.allclose(out[:, :, 0], q[:, :, 0])                                 # position 0 is not rotated
+    with pytest.raises(NotImplementedError):
+        Rotary(32, use_xpos=True)
+    t5 = T5RPE(4, bidirectional=False)
+    assert t5(torch.zeros(1, 4, 6, 9)).shape == (4, 6, 9)
+    hp = Hparams.from_dict(dict(num_layers=2, layer=dict(hidden_dim=16, activation=dict(identifier="GELU"),
+                                                         norm=dict(identifier="LayerNorm", eps=1e-5))))
+    x = TensorMask.fromlength(torch.randn(2, 5, 8, generator=g), torch.tensor([5, 3]))
+    y = LinearLayerStack(hp, 8, 4)(x)
+    assert y.value.shape == (2, 5, 4) and torch.all(y.value[1, 3:] == 0)
+    assert isinstance(LinearLayerStack(hp).layers[0], LinearBlock)
+    o = GumbelSoftMaxParameterize(8, 6, 4)(x)
+    assert o.output.value.shape == (2, 5, 4) and torch.all(o.logits.value[1, 3:] == -1000)
+    ids = TensorMask.fromlength(torch.randint(0, 10, (2, 5, 3), generator=g), torch.tensor([5, 3]))
+    assert RVQEmbedding(3, 10, 4)(ids).value.shape == (2, 5, 4)
+    if not os.path.exists(REF):
+        return
+    import importlib.util
+    import sys
+    sys.dont_write_bytecode = True
+
+    def ref_module(rel):
+        spec = importlib.util.spec_from_file_location("ref_" + os.path.basename(rel)[:-3], os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    ref_t5 = ref_module("modules/position/t5.py")
+    for bidirectional in (True, False):
+        mine, ref = T5RPE(4, bidirectional), ref_t5.T5RPE(4, bidirectional)
+        ref.load_state_dict(mine.state_dict())
+        probe = torch.zeros(1, 4, 150, 200)
+        assert torch.equal(mine(probe), ref(probe))
+    ref_rot = ref_module("modules/position/rotary.py").Rotary(32)
+    assert torch.allclose(ref_rot.rotate_queries_or_keys(q), out, atol=1e-6)
+
+
+def test_flat_adamw_bind_keeps_loaded_state():
+    """ADVICE (round 1): ``FlatAdamW.bind`` must carry optimizer state that exists before binding (a checkpoint
+    loaded first, or steps already taken) into the flat buffers instead of zeroing it."""
+    from training_lib.dp import GradReducer
+    from training_lib.optimizer import FlatAdamW
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(11))]
+    opt = FlatAdamW(params, lr=1e-3)
+    for p in params:
+        p.grad = torch.randn_like(p)
+    torch.optim.AdamW.step(opt)                      # two stock steps before binding
+    torch.optim.AdamW.step(opt)
+    before = {id(p): (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in params}
+    red = GradReducer(params)
+    opt.bind(red)
+    assert opt._steps == 2
+    for p in params:
+        m, v = before[id(p)]
+        assert torch.equal(opt.state[p]["exp_avg"], m) and torch.equal(opt.state[p]["exp_avg_sq"], v)
+        assert float(opt.state[p]["step"]) == 2.0
+        assert opt.state[p]["exp_avg"].untyped_storage().data_ptr() in {f["M"].untyped_storage().data_ptr()
+                                                                        for f in opt._flat}

@@ -486,6 +486,8 @@ extern "C" int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, 
   static const int nb_env = [] { const char* e = getenv("VG_DW_BLOCKS"); return e ? atoi(e) : 0; }();
   const int nb = min((M + 3) / 4, nb_env > 0 ? nb_env : 512);   // measured: 2048 waves balance per-wave set-up against parallelism
   const int nv = C / (64 * (dtype == VG_BF16 ? 8 : 4));
+  // algorithmic bytes: every frame read once and written once (the taps re-read neighbours from cache), + statistics
+  const int tok = vg_host::prof_begin(VG_PROF_DWNORM_FWD, (double)M * (2.0 * C * (dtype == VG_BF16 ? 2 : 4) + 8.0), stream);
   if (dtype == VG_BF16) {
     if (nv == 1) launch_fwd<bf16_t, 1>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
     else launch_fwd<bf16_t, 2>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
@@ -493,6 +495,7 @@ extern "C" int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, 
     if (nv == 1) launch_fwd<float, 1>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
     else launch_fwd<float, 2>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
   }
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_dwnorm_fwd");
 }
 
@@ -504,6 +507,9 @@ extern "C" int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, cons
   DwArgs a{M, C, T, taps, shift, 0.f};
   const int nb = vg_dwnorm_blocks(M);
   const int nv = C / (64 * (dtype == VG_BF16 ? 8 : 4));
+  // algorithmic bytes: dy, x read; du, dx written (+ the residual-path gradient when given)
+  const int tok = vg_host::prof_begin(VG_PROF_DWNORM_BWD, (double)M * ((dx_add ? 5.0 : 4.0) * C * (dtype == VG_BF16 ? 2 : 4) + 8.0),
+                                      stream);
   if (dtype == VG_BF16) {
     if (nv == 1) launch_bwd<bf16_t, 1>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
     else launch_bwd<bf16_t, 2>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
@@ -511,5 +517,6 @@ extern "C" int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, cons
     if (nv == 1) launch_bwd<float, 1>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
     else launch_bwd<float, 2>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
   }
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_dwnorm_bwd");
 }

@@ -286,7 +286,13 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
                     : (a_tr ? VG_PROF_GEMM_BF16_TN : (b_tr ? VG_PROF_GEMM_BF16_NN : VG_PROF_GEMM_BF16_NT));
   if (sizeof(T) == 2 && tile_cfg > 0) {   // LDS-DMA pipelined variant (vg_gemm_dma.hip)
     const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream, gemm_algorithmic_bytes(p, sizeof(T)));
-    const int rc = vg_host::gemm_dma_launch(p, a_tr, b_tr, tile_cfg, splits, stream);
+    int rc = -1;
+    if (tile_cfg >= 10) {     // phase-pipelined 256x256 tile (vg_gemm_ph.hip); shapes it does not take run on cfg 3
+      rc = vg_host::gemm_ph_launch(p, a_tr, b_tr, tile_cfg, splits, stream);
+      if (rc != 0) rc = vg_host::gemm_dma_launch(p, a_tr, b_tr, 3, splits, stream);
+    } else {
+      rc = vg_host::gemm_dma_launch(p, a_tr, b_tr, tile_cfg, splits, stream);
+    }
     vg_host::prof_end(tok, stream);
     if (rc == 0) return vg_host::check_launch("vg_gemm(dma)");
   }
@@ -358,7 +364,7 @@ int pick_cfg(const vg_gemm_desc* d) {
   if (d->a_tr && d->b_tr && d->colsum_out) cfg = 1;
   return cfg;
 }
-int cfg_tile_rows(int cfg) { return cfg == 9 ? 192 : (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6) ? 256 : 128; }
+int cfg_tile_rows(int cfg) { return cfg == 9 ? 192 : (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6 || cfg >= 10) ? 256 : 128; }
 }  // namespace
 
 extern "C" int vg_gemm_tile_rows(const vg_gemm_desc* d) {
@@ -403,11 +409,11 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
   const int cfg = pick_cfg(d);
   p.colpart = d->colpart;
-  p.split_ws = nullptr;
+  p.split_ws = d->tile_cfg == 13 ? d->split_ws : nullptr;      // tile_cfg 13: lab build, split_ws = stamp buffer
   p.split_cnt = nullptr;
   if (splits > 1 && cfg > 0 && d->split_ws != nullptr && d->split_cnt != nullptr) {
     // in-launch reduction of the K slices through fp32 slabs: needs splits * tiles * tile floats of workspace
-    const int rows = cfg_tile_rows(cfg), cols = (cfg == 3 || cfg == 4) ? 256 : 128;
+    const int rows = cfg_tile_rows(cfg), cols = (cfg == 3 || cfg == 4 || cfg >= 10) ? 256 : 128;
     const long tiles = (long)((d->M + rows - 1) / rows) * ((d->N + cols - 1) / cols);
     if (tiles <= 4096 && tiles * rows * cols * (long)splits <= d->split_ws_floats && d->ldc % 4 == 0 &&
         ((uintptr_t)d->C % 16) == 0) {

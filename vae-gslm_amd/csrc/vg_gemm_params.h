@@ -30,4 +30,6 @@ struct GemmParams {
 namespace vg_host {
 // LDS-DMA pipelined bf16 variant; returns 0 if launched, -1 if not applicable
 int gemm_dma_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits, hipStream_t stream);
+// phase-pipelined 256x256 tile (cfg 10: staggered wave groups, 11: in step); same return convention
+int gemm_ph_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits, hipStream_t stream);
 }

@@ -77,9 +77,12 @@ extern "C" int vg_adamw(float* param, float* grad, float* exp_avg, float* exp_av
   const long nchunks = n / 256;
   long blocks = (nchunks + 3) / 4;
   if (blocks > 4096) blocks = 4096;
+  // 28 B per parameter: p, g, m, v read; p, m, v written (16 + 12 B) + the bf16 copy (2 B) + the cleared gradient (4 B)
+  const int tok = vg_host::prof_begin(VG_PROF_ADAMW, (double)n * (28.0 + (shadow_bf16 ? 2.0 : 0.0) + (zero_grad ? 4.0 : 0.0)), stream);
   adamw_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16,
                                                                 group_of_chunk, nchunks, G, beta1, beta2, eps,
                                                                 (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale,
                                                                 zero_grad);
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_adamw");
 }

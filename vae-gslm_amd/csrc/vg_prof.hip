@@ -77,3 +77,41 @@ extern "C" int vg_prof_read_bytes(int kind, double* total_bytes) {
   if (total_bytes) *total_bytes = bytes;
   return 0;
 }
+
+// ---------------------------------------------------------------- peak probes (bench.py measures the box it runs on)
+namespace {
+__global__ __launch_bounds__(256) void probe_mfma_kernel(float* out, int iters) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (bf16_t)(0.001f * (float)threadIdx.x + (float)i);
+    b[i] = (bf16_t)(1.0f + 0.01f * (float)i);
+  }
+  f32x16 c0 = vg::zero16(), c1 = vg::zero16(), c2 = vg::zero16(), c3 = vg::zero16();
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int vg_probe_mfma(float* out, int blocks, int iters, hipStream_t stream) {
+  VG_REQUIRE(out != nullptr && blocks > 0 && iters > 0, "vg_probe_mfma: bad arguments");
+  probe_mfma_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(out, iters);
+  return vg_host::check_launch("vg_probe_mfma");
+}
+
+extern "C" int vg_probe_copy(const void* src, void* dst, int64_t bytes, int blocks, hipStream_t stream) {
+  VG_REQUIRE(src != nullptr && dst != nullptr && bytes > 0 && bytes % 16 == 0 && blocks > 0, "vg_probe_copy: bad arguments");
+  probe_copy_kernel<<<dim3(blocks), dim3(256), 0, stream>>>((const uint4*)src, (uint4*)dst, bytes / 16);
+  return vg_host::check_launch("vg_probe_copy");
+}

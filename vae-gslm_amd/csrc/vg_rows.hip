@@ -555,8 +555,11 @@ extern "C" int vg_rmsnorm_fwd(const void* x, const float* scale, void* y, float*
                               const int32_t* lengths, int T, int dtype, hipStream_t stream) {
   if (int e = check_row_shape("vg_rmsnorm_fwd", M, C, dtype)) return e;
   const int Tn = T > 0 ? T : 1;
+  const double esz = dtype == VG_BF16 ? 2.0 : 4.0;       // read x, write y (+ 4 B of rstd per row)
+  const int tok = vg_host::prof_begin(VG_PROF_RMSNORM_FWD, (double)M * (2.0 * C * esz + 4.0), stream);
   if (dtype == VG_BF16) run_rmsnorm_fwd<bf16_t>(x, scale, y, rstd, M, C, eps, lengths, Tn, stream);
   else run_rmsnorm_fwd<float>(x, scale, y, rstd, M, C, eps, lengths, Tn, stream);
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_rmsnorm_fwd");
 }
 
@@ -570,10 +573,13 @@ extern "C" int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale,
                               const int32_t* lengths, int T, int dtype, hipStream_t stream) {
   if (int e = check_row_shape("vg_rmsnorm_bwd", M, C, dtype)) return e;
   const int nb = vg_rmsnorm_bwd_blocks(M), Tn = T > 0 ? T : 1;
+  const double esz = dtype == VG_BF16 ? 2.0 : 4.0;       // read dy, x (+ the residual-path gradient), write dx
+  const int tok = vg_host::prof_begin(VG_PROF_RMSNORM_BWD, (double)M * ((dx_add ? 4.0 : 3.0) * C * esz + 4.0), stream);
   if (dtype == VG_BF16)
     run_rmsnorm_bwd<bf16_t>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, M, C, lengths, Tn, stream);
   else
     run_rmsnorm_bwd<float>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, M, C, lengths, Tn, stream);
+  vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_rmsnorm_bwd");
 }
 

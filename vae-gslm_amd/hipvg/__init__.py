@@ -102,10 +102,42 @@ SIGNATURES = {
     "vg_prof_enable": [_i],
     "vg_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
     "vg_prof_read_bytes": [_i, C.POINTER(C.c_double)],
+    "vg_probe_mfma": [_vp, _i, _i, _vp],
+    "vg_probe_copy": [_vp, _vp, _i64, _i, _vp],
 }
 
 PROF_KINDS = {"gemm_bf16_nt": 0, "gemm_bf16_nn": 1, "gemm_bf16_tn": 2, "gemm_f32": 3,
-              "attn_fwd": 4, "attn_bwd": 5}
+              "attn_fwd": 4, "attn_bwd": 5, "rmsnorm_fwd": 6, "rmsnorm_bwd": 7, "adamw": 8,
+              "dwnorm_fwd": 9, "dwnorm_bwd": 10}
+
+
+def probe_peaks(device=None) -> dict:
+    """Measured peaks of the GPU this process runs on: dense bf16 MFMA (register-fed independent chains) and a
+    streaming HBM copy.  A few hundred milliseconds; used by bench.py for ``roofline.peak_measured``."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    blocks, iters = cus * 8, 4000
+    out = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    check(lib().vg_probe_mfma(ptr(out), blocks, 100, stream()), "vg_probe_mfma")
+    torch.cuda.synchronize(dev)
+    a.record()
+    check(lib().vg_probe_mfma(ptr(out), blocks, iters, stream()), "vg_probe_mfma")
+    b.record()
+    torch.cuda.synchronize(dev)
+    mfma = blocks * 4 * iters * 4 * 32768.0 / (a.elapsed_time(b) * 1e-3) / 1e12
+    nbytes = 1 << 30
+    src = torch.ones(nbytes // 4, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    check(lib().vg_probe_copy(ptr(src), ptr(dst), nbytes, cus * 16, stream()), "vg_probe_copy")
+    torch.cuda.synchronize(dev)
+    a.record()
+    for _ in range(4):
+        check(lib().vg_probe_copy(ptr(src), ptr(dst), nbytes, cus * 16, stream()), "vg_probe_copy")
+    b.record()
+    torch.cuda.synchronize(dev)
+    copy = 4 * 2.0 * nbytes / (a.elapsed_time(b) * 1e-3) / 1e12
+    return {"mfma_bf16_dense_tflops": mfma, "hbm_copy_tb_per_s": copy, "compute_units": cus}
 
 
 def prof_enable(on: bool) -> None:

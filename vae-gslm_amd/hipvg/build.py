@@ -10,7 +10,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-SOURCES = ("vg_rows.hip", "vg_gemm.hip", "vg_gemm_dma.hip", "vg_attention.hip", "vg_conv.hip", "vg_flow.hip", "vg_optim.hip", "vg_decode.hip", "vg_prof.hip", "vg_comm.hip")
+SOURCES = ("vg_rows.hip", "vg_gemm.hip", "vg_gemm_dma.hip", "vg_gemm_ph.hip", "vg_attention.hip", "vg_conv.hip", "vg_flow.hip", "vg_optim.hip", "vg_decode.hip", "vg_prof.hip", "vg_comm.hip")
 LIB = os.path.join(CSRC, "libvaegslm_hip.so")
 ARCH = "gfx950"
 

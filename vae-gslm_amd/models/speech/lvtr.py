@@ -338,26 +338,23 @@ class LVTR(nn.Module):
 
     def likelihood(self, x: TensorMask, temperature: float = 0.0, gamma: Optional[float] = 1.0,
                    **kwargs) -> torch.Tensor:
-        """Per-sequence mean token log-likelihood (tokens model) as in reference :337-388."""
-        mask, lens = x.mask, x.lengths32
-        B, T = mask.shape
-        # token embedding + token_fuser + add as one row kernel when the configuration is the yaml's (ReLU fuser,
-        # fp32 embedding table); the module path below is the general one
-        fuser = self.token_fuser
-        fast_fuse = (diff_input is None and x.value.is_cuda and isinstance(getattr(fuser, "activation", None), nn.ReLU)
-                     and self.hp.latent_dim <= 8 and self.token_embedding.weight.dtype == torch.float32
-                     and os.environ.get("VG_EMBED_FUSE", "1") != "0")
-        if fast_fuse:
-            ids, mel = self.split_inputs(x)
-            ids = TensorMask(ids.value.long().squeeze(-1), ids.mask)
-            tokens = None
-        else:
-            ids, mel, tokens = self._embed(x)
+        """Per-sequence mean token log-likelihood, reference :337-388 (for a token model the reference returns
+        ``sum_t log softmax(logits)[token_t] / length`` and discards the latent density it also evaluates).
+        ``init_state=`` (keyword) injects the start frame, as ``noise['init_state']`` does in ``forward``."""
+        if not self.use_tokens:
+            raise NotImplementedError("HIP LVTR.likelihood implements the token model of vae-gslm.yaml")
+        mask = x.mask
+        B = mask.shape[0]
+        ids, mel, tokens = self._embed(x)
         with _side_autocast():
             enc = self.encoder[0](mel)
         q = self.encoder[1](TensorMask(enc.value.float(), enc.mask), temperature).sample
-        shifted = self.fuse_inputs(q, tokens).push(self.initial_state(B, mel.device)).pop().apply_mask()
+        init = kwargs.get("init_state")
+        if init is None:
+            init = self.initial_state(B, mel.device)
+        fused = self.fuse_inputs(q, tokens)
+        shifted = fused.push(init.to(fused.value.dtype)).pop().apply_mask()
         latent = self.transformer[0](shifted)
         logits = self._logits(latent)
-        logp = torch.log_softmax(logits, -1).gather(-1, ids.value.unsqueeze(-1)).squeeze(-1)
+        logp = torch.log_softmax(logits.float(), -1).gather(-1, ids.value.unsqueeze(-1)).squeeze(-1)
         return TensorMask.use_mask(logp, mask).sum(-1) / x.length

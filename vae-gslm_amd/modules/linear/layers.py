@@ -4,8 +4,9 @@ Drop-in for the hot-path classes of the reference ``modules/linear/layers.py``:
 ``Linear`` (:184-193), ``Embedding`` (:150-157), ``GaussianParameterize``
 (:54-148), ``TimeAggregation`` (:260-262), ``FiLM`` (:265-292).  Parameter
 names are unchanged (``linear.weight``, ``mean.weight``, ``logstd.weight`` ...).
-The Gumbel / RVQ / LinearBlock stacks of that file belong to other model
-families and are not part of the VAE-GSLM training path.
+The Gumbel / RVQ / LinearBlock classes of that file (:13-51, :160-181,
+:196-257) belong to other model families; they are kept importable with the
+same constructors and result types but run on stock PyTorch ops (no HIP kernel).
 """
 from __future__ import annotations
 
@@ -17,7 +18,9 @@ import torch.nn.functional as F
 
 import hipvg
 from hipvg import functional as HF
-from modules.activations import hip_act_id
+from hparams.hp import Hparams
+from modules.activations import get_activation, hip_act_id
+from modules.norm import get_norm_fn
 from utils.attr import AttrDict
 from utils.helpers import repeat_batch
 from utils.tensormask import TensorMask
@@ -181,3 +184,81 @@ class FiLM(nn.Module):
         if isinstance(x, TensorMask):
             return TensorMask(y, x.mask, axis=1 if self.time_first else 2)
         return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Not on the VAE-GSLM path (stock PyTorch ops): discrete / residual-VQ front ends and the residual MLP stack of the
+# reference's other model families.  Same constructors, parameter names and result types.
+class GumbelSoftMaxParameterize(nn.Module):
+    """Straight-through Gumbel-softmax code selection (reference :13-51)."""
+
+    def __init__(self, in_dim: int, num_codebooks: int, codebook_dim: int, temperature: float = 1.0):
+        super().__init__()
+        self.in_dim, self.temperature = in_dim, temperature
+        self.in_linear = nn.Linear(in_dim, num_codebooks, bias=False)
+        self.encode_linear = nn.Linear(num_codebooks, codebook_dim, bias=False)
+
+    def gumbel_softmax_sample(self, logits: torch.Tensor, temperature: float, eps: float = 1e-20) -> torch.Tensor:
+        noise = -torch.log(eps - torch.log(torch.rand_like(logits) + eps))
+        return F.softmax((logits + noise) / temperature, dim=-1)
+
+    def forward(self, x: TensorMask, temperature: Optional[float] = None) -> AttrDict:
+        logits = self.in_linear(x.value) * self.in_dim ** -0.5
+        soft = self.gumbel_softmax_sample(logits, self.temperature if temperature is None else temperature)
+        hard = F.one_hot(soft.argmax(-1), soft.shape[-1]).to(soft.dtype)
+        code = (hard - soft).detach() + soft                 # one-hot forward, soft gradient
+        return AttrDict(logits=TensorMask(logits, x.mask).apply_mask(-1000),
+                        output=TensorMask(self.encode_linear(code), x.mask).apply_mask(),
+                        gumbel_prob=TensorMask(soft, x.mask).apply_mask())
+
+
+class RVQEmbedding(nn.Module):
+    """Sum of one embedding table per residual quantizer: (B, T, n) ids -> (B, T, C) (reference :160-181)."""
+
+    def __init__(self, num_quantizers: int, codebook_size: int, dim: int) -> None:
+        super().__init__()
+        self.num_quantizers = num_quantizers
+        self.embeddings = nn.ModuleList([nn.Embedding(codebook_size, dim) for _ in range(num_quantizers)])
+
+    def forward(self, x: TensorMask) -> TensorMask:
+        total = sum(table(x.value[..., i]) for i, table in enumerate(self.embeddings))
+        return TensorMask(total, x.mask).apply_mask()
+
+
+class LinearBlock(nn.Module):
+    """Pre-norm residual MLP block: x + W2 act(norm2(W1 act(norm1 x))) (reference :196-228)."""
+
+    def __init__(self, hp: Hparams):
+        super().__init__()
+        hp.check_arg_in_hparams("hidden_dim", "activation", "norm")
+        bias, width = hp.get("bias", True), hp.hidden_dim
+        self.linear1 = nn.Linear(width, width, bias=bias)
+        self.linear2 = nn.Linear(width, width, bias=bias)
+        self.dropout = nn.Dropout(hp.get("dropout", 0.0))
+        self.norm1 = get_norm_fn(width, hp.norm)
+        self.norm2 = get_norm_fn(width, hp.norm)
+        self.activation = get_activation(hp.activation)
+
+    def forward(self, x: TensorMask) -> TensorMask:
+        r = self.linear1(self.activation(self.norm1(x.value)))
+        r = self.linear2(self.activation(self.norm2(r)))
+        return TensorMask(x.value + r, x.mask).apply_mask()
+
+
+class LinearLayerStack(nn.Module):
+    def __init__(self, hp: Hparams, input_dim: Optional[int] = None, output_dim: Optional[int] = None) -> None:
+        super().__init__()
+        hp.check_arg_in_hparams("num_layers", "layer")
+        self.hp = hp
+        self.layers = nn.ModuleList([LinearBlock(hp.layer) for _ in range(hp.num_layers)])
+        self.linear = nn.Linear(input_dim, hp.layer.hidden_dim) if input_dim is not None else None
+        self.out_linear = nn.Linear(hp.layer.hidden_dim, output_dim) if output_dim is not None else None
+
+    def forward(self, x: TensorMask) -> TensorMask:
+        if self.linear is not None:
+            x = TensorMask(self.linear(x.value), x.mask).apply_mask()
+        for layer in self.layers:
+            x = layer(x)
+        if self.out_linear is not None:
+            x = TensorMask(self.out_linear(x.value), x.mask).apply_mask()
+        return x

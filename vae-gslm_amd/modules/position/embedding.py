@@ -14,6 +14,8 @@ from hparams.hp import Hparams
 
 from .absolute import SinCos
 from .alibi import ALiBi
+from .rotary import Rotary  # noqa: F401  (importable; no attention kernel consumes it)
+from .t5 import T5RPE  # noqa: F401
 
 
 def get_positional_encoding(name: str, hp: Hparams, ndim: Optional[int] = None,

@@ -70,13 +70,18 @@ def main(argv=None):
 
     module_name, cls_name = hp.trainer.identifier.rsplit(".", 1)
     trainer = getattr(importlib.import_module(module_name), cls_name)(hp).to(device)
-    if args.resume:
-        trainer.model.load_state_dict(torch.load(args.resume, map_location=device))
+    if args.resume:          # weights first, so that rank 0's broadcast below starts from them
+        ck = torch.load(args.resume, map_location=device)
+        trainer.model.load_state_dict(ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck)
+        del ck
     if world > 1:   # identical replicas: broadcast rank 0's initial weights
         for p in trainer.model.parameters():
             dist.broadcast(p.data, 0)
     trainer.configure_optimizers()
     trainer.attach_reducer()
+    if args.resume and trainer.load_checkpoint(args.resume, map_location=device):
+        # full checkpoint: optimizer moments / step, LR schedule and global_step (hence the KL warm-up) continue
+        log.info("resumed %s at optimizer step %d", args.resume, trainer.global_step)
     torch.autograd.set_detect_anomaly(args.detect_anomaly)
 
     data_hp = hp.data.train
@@ -92,25 +97,52 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(outdir, exist_ok=True)
         trainer.save_hparams(outdir)
+    # Checkpoints: the reference saves a full and a compact checkpoint every `save_every_n_epoch` epochs and keeps
+    # the newest `save_top_k` (scripts/train.py:59-75).  Synthetic data has no epochs: `steps_per_epoch` optimizer
+    # steps (default 1000) stand in for one.
+    every = int(hp.trainer.get("save_every_n_epoch", 1)) * int(hp.trainer.get("steps_per_epoch", 1000))
+    keep = int(hp.trainer.get("save_top_k", 5))
+    saved = []
+
+    def checkpoint():
+        if rank != 0:
+            return
+        epoch = trainer.global_step // max(1, int(hp.trainer.get("steps_per_epoch", 1000)))
+        stem = os.path.join(outdir, f"epoch={epoch}-step={trainer.global_step}")
+        trainer.save_full_checkpoint(stem + ".ckpt")
+        trainer.save_checkpoint(stem + "-cpt.ckpt")
+        saved.append(stem)
+        while keep > 0 and len(saved) > keep:
+            old = saved.pop(0)
+            for suffix in (".ckpt", "-cpt.ckpt"):
+                if os.path.exists(old + suffix):
+                    os.remove(old + suffix)
+
     t0, frames = time.time(), 0
+    start_step = trainer.global_step
+    total = max(0, total - start_step)
+    first = start_step * accum            # a resumed run continues the batch stream where it stopped
     if args.device_batches:
-        feed = (make_batch(B, T, device, seed=1234 + rank * 1000 + it) for it in range(total * accum))
+        feed = (make_batch(B, T, device, seed=1234 + rank * 1000 + first + it) for it in range(total * accum))
     else:   # host batches on a worker thread -> pinned memory -> asynchronous copies two steps ahead
         from training_lib.prefetch import BackgroundLoader, DevicePrefetcher
         if getattr(trainer, "use_graph", False):
             trainer.enter_compute_stream(device)     # the copies synchronise with the stream the step runs on
-        feed = DevicePrefetcher(BackgroundLoader(lambda it: make_batch(B, T, "cpu", seed=1234 + rank * 1000 + it),
+        feed = DevicePrefetcher(BackgroundLoader(lambda it: make_batch(B, T, "cpu", seed=1234 + rank * 1000 + first + it),
                                                  total * accum), device)
     for it, batch in enumerate(feed):
-        out = trainer.training_step(batch, it)
+        before = trainer.global_step
+        out = trainer.training_step(batch, first + it)
         frames += B * T * world
+        if trainer.global_step != before and trainer.global_step % every == 0:
+            checkpoint()
         if rank == 0 and (it + 1) % (50 * accum) == 0:
             torch.cuda.synchronize()
             dt = time.time() - t0
             log.info("step %d  loss %.4f  kld/frame %.4f  tokens/s %.0f", trainer.global_step,
                      float(out["loss"]), float(trainer.logged.get("train/kld", 0.0)), frames / dt)
-    if rank == 0:
-        trainer.save_checkpoint(os.path.join(outdir, f"epoch=0-step={trainer.global_step}-cpt.ckpt"))
+    if not saved or not saved[-1].endswith(f"step={trainer.global_step}"):
+        checkpoint()
     if world > 1:
         dist.destroy_process_group()
 

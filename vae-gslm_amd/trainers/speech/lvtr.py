@@ -183,7 +183,9 @@ class LVTRTrainer(BaseTrainer):
         if self.use_tokens:
             loss = loss + out["ce_loss"] * (self.token_kld_weight * kld_weight)
         if self.reducer is not None:
-            self.reducer.new_backward()
+            # the set of inputs decides which sub-networks run how often (``cropped_mel`` sends the posterior
+            # encoder and the token fuser through a second time), hence how often each parameter reports
+            self.reducer.new_backward(signature=tuple(sorted(batch.keys())))
         # Parameters autograd still owns (stock sub-networks) get their gradient through AccumulateGrad, which ADDS
         # into the bucket view (one tiny launch per parameter, ~50 per step).  With the views taken away autograd
         # keeps the fresh gradient tensors instead, and one multi-tensor launch adds them afterwards.  Only where
@@ -280,6 +282,7 @@ class LVTRTrainer(BaseTrainer):
             if clip is not None:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
             if pipelined:      # each bucket's AdamW launch waits for that bucket's all-reduce only
+                self.reducer.flush()                   # buckets that nothing launched yet go on the wire first
                 self.optimizer.step(bucket_wait=self.reducer.wait_bucket)
                 self.reducer.finish()
             else:
@@ -348,6 +351,25 @@ class LVTRTrainer(BaseTrainer):
             from utils.tensormask import TensorMask
             static = {k: TensorMask(v.value.clone(), v.mask if getattr(v.mask, "_vg_full", False) else v.mask.clone())
                       for k, v in batch.items()}
+            # A new shape may first appear in the middle of an accumulation window: the warm-up pass and the capture
+            # below must not disturb the gradients already accumulated, so the buckets are set aside and put back.
+            saved = [b["flat"].clone() for b in self.reducer.buckets] if self.reducer is not None else None
+
+            def restore_buckets():
+                if saved is not None:
+                    for b, keep in zip(self.reducer.buckets, saved):
+                        b["flat"].copy_(keep)
+
+            def forget_lengths():
+                # The sequence lengths are cached on the mask tensors (TensorMask.lengths32 / .length).  The graph must
+                # RECOMPUTE them from the static masks on every replay, so the reductions have to be recorded inside
+                # the capture: drop what the warm-up pass cached (a graph that kept reading the first batch's lengths
+                # would mask every later batch of this shape with them).
+                for tm in static.values():
+                    if not getattr(tm.mask, "_vg_full", False):
+                        tm.mask._vg_len32 = None
+                        tm.mask._vg_len64 = None
+
             if self.reducer is not None:
                 self.reducer.sync_now = False          # collectives stay outside the graph
             side = torch.cuda.Stream(device=dev)
@@ -355,8 +377,7 @@ class LVTRTrainer(BaseTrainer):
             with torch.cuda.stream(side):              # eager pass on the capture side-stream (lazy inits)
                 self._training_loop(static, batch_idx, kld_weight=self._kw_dev)
             torch.cuda.current_stream().wait_stream(side)
-            if self.reducer is not None:
-                self.reducer.zero_grad()
+            forget_lengths()
             if getattr(self, "profile_in_graph", False):
                 import hipvg
                 hipvg.prof_enable(True)                # event-record nodes become part of the graph
@@ -384,20 +405,17 @@ class LVTRTrainer(BaseTrainer):
                 self._segmented = False
                 self.model.grad_cut_layer = None     # eager launches report gradients as they complete: no cuts
                 torch.cuda.synchronize()
+                restore_buckets()
                 if self.reducer is not None:
-                    self.reducer.zero_grad()
                     self.reducer.sync_now = last
                 return self._training_loop(batch, batch_idx, None)
-            if self.reducer is not None:
-                self.reducer.zero_grad()               # capture does not execute; start from clean buckets
+            restore_buckets()                          # capture does not execute; the warm-up pass is undone
             ent = self._graphs[key] = (graph, static, out, graph2)
         graph, static, out, graph2 = ent
         for k, v in batch.items():
             static[k].value.copy_(v.value, non_blocking=True)
             if static[k].mask is not v.mask and not getattr(static[k].mask, "_vg_full", False):
-                static[k].mask.copy_(v.mask, non_blocking=True)
-                static[k].mask._vg_len32 = None
-                static[k].mask._vg_len64 = None
+                static[k].mask.copy_(v.mask, non_blocking=True)     # lengths are recomputed inside the graph
         graph.replay()
         reduce_now = last and self.reducer is not None and self.reducer.world > 1
         if graph2 is not None:
@@ -411,10 +429,94 @@ class LVTRTrainer(BaseTrainer):
         res["kld_weight"] = self.current_kld_weight()
         return res
 
+    # ------------------------------------------------------------ validation
+    def on_validation_start(self) -> None:
+        self.sampled = 0
+        self._val_acc = None
+
+    @torch.no_grad()
+    def validation_step(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
+        """Reference ``validation_step`` (trainers/speech/lvtr.py:182-286) without its audio logging (vocoder,
+        sampler and TensorBoard are outside this build): the same forward, ``val/kld``, ``val/rec_loss`` and
+        ``val/token_kld`` per valid frame, averaged over the epoch with weight ``len(batch)`` and, at
+        ``on_validation_end``, over ranks -- Lightning's ``log(on_epoch=True, sync_dist=True, batch_size=...)``."""
+        kwargs = {}
+        if self.model.utterance_encoder is not None:
+            kwargs["utterance"] = batch["cropped_mel_utt"]
+        if "cropped_mel" in batch:
+            kwargs["diff_input"] = batch["cropped_mel"]
+        model_input = batch["mel"]
+        if self.use_tokens:
+            model_input = batch["tokens"].expand().cat(batch["mel"])
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            out = self.model(model_input, noise=noise, **kwargs)
+        finally:
+            self.model.train(was_training)
+        n = out["log_p"].length.sum()
+        vals = [out["kld"] / n, out["decoder_output"] / n]
+        if self.use_tokens:
+            vals.append(out["ce_loss"] / n)
+        bs = float(len(batch["mel"]))
+        step = torch.stack([v.detach().float().reshape(()) for v in vals] + [torch.ones((), device=n.device)]) * bs
+        self._val_acc = step if getattr(self, "_val_acc", None) is None else self._val_acc + step
+        res = {"kld": vals[0], "rec_loss": vals[1], "length": n}
+        if self.use_tokens:
+            res["token_kld"] = vals[2]
+        return res
+
+    def on_validation_end(self, group=None) -> Mapping[str, float]:
+        """One all-reduce of the epoch sums (three scalars and their weight) over the ranks; logs and returns the
+        means under the reference's names."""
+        import torch.distributed as dist
+        self.sampled = 0
+        acc = getattr(self, "_val_acc", None)
+        if acc is None:
+            return {}
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            # Lightning reduces each rank's epoch MEAN with equal weights (sync_dist=True)
+            mean = acc[:-1] / acc[-1]
+            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=group)
+            mean = mean / world
+        else:
+            mean = acc[:-1] / acc[-1]
+        names = ["val/kld", "val/rec_loss"] + (["val/token_kld"] if self.use_tokens else [])
+        out = {k: float(v) for k, v in zip(names, mean.cpu())}
+        for k, v in out.items():
+            self.log(k, v)
+        self._val_acc = None
+        return out
+
     # ------------------------------------------------------------ checkpoints
     def save_checkpoint(self, filepath: str) -> None:
         """Compact checkpoint = ``LVTR.state_dict()`` (reference :294-296)."""
         torch.save(self.model.state_dict(), filepath)
+
+    def save_full_checkpoint(self, filepath: str) -> None:
+        """Everything a resumed run needs (what Lightning's ``ModelCheckpoint`` keeps for the reference,
+        scripts/train.py:59-66): weights, optimizer moments and step, LR schedule, ``global_step``."""
+        torch.save({"state_dict": self.model.state_dict(),
+                    "optimizer": self.optimizer.state_dict() if self.optimizer is not None else None,
+                    "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None,
+                    "global_step": int(self.global_step)}, filepath)
+
+    def load_checkpoint(self, filepath: str, map_location=None) -> bool:
+        """Load a full or a compact checkpoint.  Call after ``configure_optimizers`` / ``attach_reducer`` so the
+        optimizer state lands in the bound flat buffers.  Returns True when training state was restored too
+        (``fit(ckpt_path=...)`` of the reference, scripts/train.py:104)."""
+        ckpt = torch.load(filepath, map_location=map_location)
+        if not (isinstance(ckpt, dict) and "state_dict" in ckpt and "global_step" in ckpt):
+            self.model.load_state_dict(ckpt)
+            return False
+        self.model.load_state_dict(ckpt["state_dict"])
+        if ckpt.get("optimizer") is not None and self.optimizer is not None:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+        if ckpt.get("scheduler") is not None and self.scheduler is not None:
+            self.scheduler.load_state_dict(ckpt["scheduler"])
+        self.global_step = int(ckpt["global_step"])
+        return True
 
     def save_hparams(self, directory: str) -> None:
         with open(os.path.join(directory, "hp.yaml"), "w") as f:

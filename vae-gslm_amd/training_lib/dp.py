@@ -47,6 +47,14 @@ class GradReducer:
         self.overlap = overlap
         self.sync_now = True           # set False on non-final micro-batches
         self._epoch = 0                # backward passes announced through new_backward()
+        self._expected = {}            # signature -> {id(param): reports per backward pass}
+        self._calibrating, self._in_pass, self._surprise, self._sig = False, False, None, None
+        self._counts, self._remaining = {}, {}
+        # measurement hooks (bench.py): event pairs around every collective on the stream it runs on, and a switch
+        # that skips the collectives (the same step without its exchange: what is left is the exposed part)
+        self.time_collectives = False
+        self.stub_collectives = False
+        self._comm_events = []
         dev = self.params[0].device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         limit = int(bucket_mb * (1 << 20) / 4)
@@ -87,34 +95,108 @@ class GradReducer:
             off += self._padded(p.numel())
         self.buckets.append(dict(params=plist, offsets=offsets, flat=flat, pending=len(plist), need=len(plist)))
 
-    def new_backward(self) -> None:
-        """Call before every backward pass.  A parameter can report "gradient ready" twice in one pass: once from
-        hipvg's gradient sink and once from autograd, whose post-accumulate hooks also run when a custom backward
-        returned None for that parameter (torch >= 2.x).  From the first call on, only the first report of a
-        parameter per pass is counted; without it every report counts (plain autograd modules)."""
+    def new_backward(self, signature=None) -> None:
+        """Call before every backward pass.  A parameter can report "gradient ready" several times in one pass: once
+        per use from hipvg's gradient sink (a sunk parameter used twice in one forward reports after EACH
+        contribution) and once from autograd, whose post-accumulate hooks also run when a custom backward returned
+        None for that parameter (torch >= 2.x).  The reducer therefore learns how many reports each parameter
+        makes: the first pass of every ``signature`` (anything hashable that identifies the structure of the step,
+        e.g. the batch's keys) only counts -- nothing is launched before ``flush()`` -- and later passes launch a
+        bucket when every parameter has made its LAST expected report.  Parameters that made none (no gradient in
+        this structure) are not waited for; their buckets go on the wire in ``flush()``.  Without any call to this
+        method every report counts once (plain autograd modules)."""
+        self._end_pass()
         self._epoch += 1
+        self._sig = signature
+        exp = self._expected.get(signature)
+        self._calibrating = exp is None
+        self._in_pass = True
+        if self._calibrating:
+            self._counts = {}
+        else:
+            self._remaining = dict(exp)
+            for b in self.buckets:
+                b["pending"] = sum(1 for p in b["params"] if exp.get(id(p), 0) > 0)
+
+    def _end_pass(self) -> None:
+        if getattr(self, "_in_pass", False):
+            self._in_pass = False
+            if self._calibrating:
+                self._expected[self._sig] = self._counts
+            if self._surprise is not None:
+                name, self._surprise = self._surprise, None
+                self._expected.pop(self._sig, None)
+                raise RuntimeError(
+                    "GradReducer: a parameter reported 'gradient ready' more often than in the first pass with this "
+                    f"signature ({self._sig!r}; parameter of shape {name}); its bucket may have been all-reduced before "
+                    "the last contribution.  Pass a signature that distinguishes the two step structures.")
 
     def _make_hook(self, bi: int):
         def hook(param):
-            if self._epoch:
-                if getattr(param, "_vg_fired_epoch", 0) == self._epoch:
-                    return
-                param._vg_fired_epoch = self._epoch
-            b = self.buckets[bi]
-            b["pending"] -= 1
-            if b["pending"] == 0:
-                b["pending"] = b["need"]
+            if not self._epoch:            # plain autograd use: every report counts
+                b = self.buckets[bi]
+                b["pending"] -= 1
+                if b["pending"] == 0:
+                    b["pending"] = b["need"]
+                    if self.sync_now and self.world > 1:
+                        self._launch(b)
+                return
+            key = id(param)
+            if self._calibrating:
+                self._counts[key] = self._counts.get(key, 0) + 1
+                return
+            rem = self._remaining.get(key, 0)
+            if rem <= 0:
                 if self.sync_now and self.world > 1:
+                    self._surprise = tuple(param.shape)
+                return
+            self._remaining[key] = rem - 1
+            if rem == 1:
+                b = self.buckets[bi]
+                b["pending"] -= 1
+                if b["pending"] == 0 and self.sync_now and self.world > 1:
                     self._launch(b)
         return hook
+
+    def _timed_allreduce(self, flat):
+        if self.stub_collectives:
+            return None
+        if not (self.time_collectives and flat.is_cuda):
+            return self._allreduce(flat)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        h = self._allreduce(flat)
+        b.record()
+        self._comm_events.append((a, b, flat.numel() * flat.element_size()))
+        return h
+
+    def comm_stats(self, reset: bool = True) -> dict:
+        """Summed duration (ms, events on the communication stream) and bytes of the collectives recorded since the
+        last call; the duration of overlapping collectives on one stream adds up, so this is wire time, not
+        exposed time."""
+        ms = sum(a.elapsed_time(b) for a, b, _ in self._comm_events)
+        out = {"allreduce_ms": ms, "allreduce_bytes": sum(n for _, _, n in self._comm_events),
+               "collectives": len(self._comm_events)}
+        if reset:
+            self._comm_events = []
+        return out
+
+    def communicator_ranks(self) -> int:
+        """Size of the communicator the collectives actually run on (not the launcher's environment)."""
+        if self.world == 1:
+            return 1
+        if self.comm == "abi":
+            import hipvg
+            return int(hipvg.lib().vg_comm_world())
+        return int(dist.get_world_size(self.group))
 
     def _launch(self, b):
         if self.comm_stream is not None and self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                h = self._allreduce(b["flat"])
+                h = self._timed_allreduce(b["flat"])
         else:
-            h = self._allreduce(b["flat"])
+            h = self._timed_allreduce(b["flat"])
         b["handle"], b["launched"] = h, True
         self._handles.append(h)
 
@@ -165,14 +247,23 @@ class GradReducer:
         ids = {id(p) for p in params}
         return [i for i, b in enumerate(self.buckets) if all(id(p) in ids for p in b["params"])]
 
+    def flush(self) -> None:
+        """End of the window's last backward: every bucket not yet on the wire is launched now (the counting pass of
+        a new signature, buckets whose parameters received no gradient, hipGraph replays)."""
+        self._end_pass()
+        if self.sync_now and self.world > 1:
+            self.reduce_all()
+
     def finish(self) -> None:
         """Call after the last backward of the window, before ``optimizer.step()``."""
+        self.flush()
         for h in self._handles:
             if h is not None:
                 h.wait()
         self._handles.clear()
         for b in self.buckets:
             b["handle"], b["launched"] = None, False
+            b["pending"] = b["need"]
         if self.comm_stream is not None and self.overlap and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 

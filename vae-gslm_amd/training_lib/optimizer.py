@@ -63,6 +63,11 @@ class FlatAdamW(optim.AdamW):
                 p.data = P[off: off + k].view(p.shape)
                 p._vg_flat_shadow = S[off: off + k].view(p.shape)
                 chunk_group[off // 256: (off + k + 255) // 256] = group_of[p]
+                old = self.state.get(p)
+                if old:                    # state loaded (or steps taken) before binding moves into the flat buffers
+                    M[off: off + k].copy_(old["exp_avg"].reshape(-1))
+                    V[off: off + k].copy_(old["exp_avg_sq"].reshape(-1))
+                    self._steps = max(self._steps, int(float(old["step"])))
                 self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": M[off: off + k].view(p.shape),
                                  "exp_avg_sq": V[off: off + k].view(p.shape)}
             S.copy_(P)
