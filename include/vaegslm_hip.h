@@ -78,7 +78,8 @@ typedef struct vg_gemm_desc {
   int split_k;
   float alpha;
   const void* pre_add;  /* [M][ldc] added before the activation (conditioning term of the conv blocks) or NULL */
-  int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..5 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 / 256x128 with a 3-stage ring */
+  int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..5 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 / 256x128 with a 3-stage ring;
+                           11 / 12 = phase-pipelined 256x256 (ring / complementary schedule, vg_gemm_ph.hip) */
   float* colsum_out;    /* a_tr = b_tr = 1 only (weight gradient dY^T X): colsum_out[m] += sum_k A(m,k), i.e. the bias
                            gradient of the same Linear (modules/linear/layers.py:192) from the tiles already in LDS; NULL = off */
   float* colpart;       /* [ceil(M / vg_gemm_tile_rows(desc))][N] fp32 or NULL: per-row-tile column sums of the stored result
@@ -92,6 +93,15 @@ typedef struct vg_gemm_desc {
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 /* rows per output tile the launch for `desc` will use (128 or 256), 0 if it takes the register-staged kernel */
 int vg_gemm_tile_rows(const vg_gemm_desc* desc);
+/* Several weight-gradient products in ONE launch: every desc must be bf16, a_tr = b_tr = 1, fp32 C, K and K / split_k
+ * multiples of 64, no epilogue beyond alpha / accumulate (split_k == 1: C += result when accumulate, else C = result;
+ * split_k > 1: fp32 atomics into a C that already holds its initial value).  Replaces the four dW = dY^T X launches
+ * of one Transformer layer's backward (the nn.Linear weight gradients autograd computes for
+ * modules/transformer/layers.py:52,79,82,151 of the reference): 176 unsplit 256x256 tiles + 16 tiles split 4 ways fill
+ * 240 CUs without the memory-side atomics that four split-K launches pay.  Returns non-zero (nothing launched) if a
+ * desc does not qualify -- launch them through vg_gemm then. */
+enum { VG_GROUP_MAX = 8 };
+int vg_gemm_grouped(const vg_gemm_desc* descs, int n, vg_stream_t stream);
 
 /* ---------------------------------------------------------------- RMSNorm
  * modules/norm.py:28-32 fused with the re-mask of

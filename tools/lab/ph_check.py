@@ -71,6 +71,20 @@ def check():
         cp = (outs[3][2].sum(0) - outs[cfg][2].sum(0)).abs().max().item()
         print(f"cfg {cfg} epilogue (bias, GELU + derivative, residual, mask) bitwise equal to cfg 3: {same}; colpart diff {cp:g}")
         bad += not same
+    # grouped weight gradients (vg_gemm_grouped): exact integers, accumulation into non-zero gradients
+    for Mf in (1024, 16000):
+        shapes = [(4096, 1024), (1024, 4096), (3072, 1024), (1024, 1024)]
+        items, refs = [], []
+        for N, K in shapes:
+            w = torch.nn.Parameter(torch.zeros(N, K, device=dev))
+            w.grad = ints((N, K), g).to(dev)
+            dy, x = ints((Mf, N), g, -2, 3).to(dev).bfloat16(), ints((Mf, K), g, -2, 3).to(dev).bfloat16()
+            refs.append(w.grad.double() + dy.double().t() @ x.double())
+            items.append((w, dy, x))
+        F.sink_wgrad_group(items)
+        err = max((it[0].grad.double() - r).abs().max().item() for it, r in zip(items, refs))
+        print(f"grouped wgrad M={Mf}: max err {err:g} {'ok' if err == 0 else 'FAIL'}", flush=True)
+        bad += err != 0
     print("CHECK", "PASSED" if bad == 0 else f"FAILED ({bad})", flush=True)
     return bad == 0
 
@@ -105,6 +119,29 @@ def bench():
         "wgrad Wo     TN 1024x1024 K=M": (2.0 * M * D * D, lambda i, c: F.gemm(ys[i], xs[i], D, D, M, a_tr=True, b_tr=True, out=wgo[i], split_k=6 if c == 1 else 10, tile_cfg=c)),
     }
     cfgs = [1] + CFGS if 1 not in CFGS else CFGS
+    # the layer's four weight gradients: one by one (library's own split and tile choice) against one grouped launch
+    ws = [torch.nn.Parameter(torch.zeros(n, k, device=dev)) for n, k in ((Fd, D), (D, Fd), (3 * D, D), (D, D))]
+    for w in ws:
+        w.grad = torch.zeros_like(w)
+    def one_by_one(i):
+        F.sink_wgrad(ws[0], hs[i], xs[i]); F.sink_wgrad(ws[1], ys[i], hs[i]); F.sink_wgrad(ws[2], q3[i], xs[i]); F.sink_wgrad(ws[3], ys[i], xs[i])
+    def grouped(i):
+        F.sink_wgrad_group([(ws[0], hs[i], xs[i]), (ws[1], ys[i], hs[i]), (ws[2], q3[i], xs[i]), (ws[3], ys[i], xs[i])])
+    for name, fn in (("layer wgrads one by one", one_by_one), ("layer wgrads grouped", grouped)):
+        for i in range(R):
+            fn(i)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(ITERS):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(R):
+                fn(i)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / R * 1e-3)
+        t = sorted(ts)[len(ts) // 2]
+        print(f"{name:40s} {t * 1e6:7.1f} us {2.0 * M * 12 * D * D / t / 1e12:6.0f} TF", flush=True)
     for name, (flop, fn) in cases.items():
         res = {c: [] for c in cfgs}
         for c in cfgs:

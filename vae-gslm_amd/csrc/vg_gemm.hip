@@ -347,6 +347,11 @@ int pick_cfg(const vg_gemm_desc* d) {
   // faster than either square tile; M = 16000 keeps 256x256 (252 tiles), M = 8000 keeps 128x128 (504).
   // Weight gradients: 128x128 + split-K (tools/wgrad_cold_sweep.py).
   cfg = 1;
+  // phase-pipelined 256x256 kernels (vg_gemm_ph.hip) need whole 64-deep K tiles in every split
+  const int splits = d->split_k > 0 ? d->split_k : 1;
+  int kps = (d->K + splits - 1) / splits;
+  kps = ((kps + 63) / 64) * 64;
+  const bool ph_ok = d->K % 64 == 0 && kps % 64 == 0;
   if (!d->a_tr) {
     auto cost = [&](int rows, int cols, int per_cu, double shape) {
       const long tiles = (long)((d->M + rows - 1) / rows) * ((d->N + cols - 1) / cols), slots = 256L * per_cu;
@@ -355,13 +360,22 @@ int pick_cfg(const vg_gemm_desc* d) {
       return rounds * rows * cols * per_cu * shape;
     };
     const double longk_pen = 0.10 * fmin(1.0, fmax(0.0, (d->K - 1024) / 3072.0));   // 128x128 falls behind at long K
-    const double c1 = cost(128, 128, 2, 1.08 + longk_pen), c3 = cost(256, 256, 1, 1.0), c9 = cost(192, 256, 1, 0.97);
+    // the phase-pipelined 256x256 loop is 8-35 % faster than the 2-stage one it replaces (tools/lab/ph_check.py)
+    const double f256 = ph_ok ? (d->b_tr ? 0.80 : 0.92) : 1.0;
+    const double c1 = cost(128, 128, 2, 1.08 + longk_pen), c3 = cost(256, 256, 1, f256), c9 = cost(192, 256, 1, 0.97);
     cfg = c3 <= c1 ? 3 : 1;
     if (c9 < 0.95 * fmin(c1, c3)) cfg = 9;      // the odd shape must win clearly (model error ~5 %)
+    if (cfg == 3 && ph_ok) cfg = d->b_tr ? 11 : 12;     // NN: ring schedule, NT: complementary schedule
+  } else if (d->b_tr && ph_ok && !d->colsum_out) {
+    // weight gradients: 256x256 ring tiles once they can fill a good part of the chip with the caller's split
+    const long tiles = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splits;
+    if (tiles >= 96) cfg = 11;
   }
   static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
   if (cfg == 1 && !d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;
   if (d->a_tr && d->b_tr && d->colsum_out) cfg = 1;
+  static const int no_ph = [] { const char* e = getenv("VG_NO_PH"); return e ? atoi(e) : 0; }();
+  if (no_ph && cfg >= 10) cfg = d->a_tr ? 1 : 3;     // A/B switch: the round-1 kernels
   return cfg;
 }
 int cfg_tile_rows(int cfg) { return cfg == 9 ? 192 : (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6 || cfg >= 10) ? 256 : 128; }
@@ -373,20 +387,21 @@ extern "C" int vg_gemm_tile_rows(const vg_gemm_desc* d) {
   return cfg > 0 ? cfg_tile_rows(cfg) : 0;
 }
 
-extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
-  VG_REQUIRE(d != nullptr, "vg_gemm: null descriptor");
-  VG_REQUIRE(d->dtype == VG_F32 || d->dtype == VG_BF16, "vg_gemm: bad dtype %d", d->dtype);
-  VG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vg_gemm: empty problem %d %d %d", d->M, d->N, d->K);
+namespace {
+// checks a descriptor and fills the kernel parameter block; returns 0 or an error code (message set)
+int fill_params(const vg_gemm_desc* d, GemmParams& p, int& splits, const char* who) {
+  VG_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  VG_REQUIRE(d->dtype == VG_F32 || d->dtype == VG_BF16, "%s: bad dtype %d", who, d->dtype);
+  VG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "%s: empty problem %d %d %d", who, d->M, d->N, d->K);
   const int vec = d->dtype == VG_BF16 ? 8 : 4;
   const int bk = d->dtype == VG_BF16 ? 64 : 32;
-  VG_REQUIRE(d->lda % vec == 0 && d->ldb % vec == 0, "vg_gemm: lda/ldb must be multiples of %d", vec);
-  if (!d->a_tr || !d->b_tr) VG_REQUIRE(d->K % vec == 0, "vg_gemm: K must be a multiple of %d", vec);
-  if (d->a_tr) VG_REQUIRE(d->M % vec == 0, "vg_gemm: M must be a multiple of %d for a_tr", vec);
-  if (d->b_tr) VG_REQUIRE(d->N % vec == 0, "vg_gemm: N must be a multiple of %d for b_tr", vec);
-  VG_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "vg_gemm: A/B must be 16-byte aligned");
-  int splits = d->split_k > 0 ? d->split_k : 1;
-  VG_REQUIRE(splits == 1 || d->out_f32, "vg_gemm: split-K needs an fp32 (pre-zeroed) C");
-  GemmParams p;
+  VG_REQUIRE(d->lda % vec == 0 && d->ldb % vec == 0, "%s: lda/ldb must be multiples of %d", who, vec);
+  if (!d->a_tr || !d->b_tr) VG_REQUIRE(d->K % vec == 0, "%s: K must be a multiple of %d", who, vec);
+  if (d->a_tr) VG_REQUIRE(d->M % vec == 0, "%s: M must be a multiple of %d for a_tr", who, vec);
+  if (d->b_tr) VG_REQUIRE(d->N % vec == 0, "%s: N must be a multiple of %d for b_tr", who, vec);
+  VG_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "%s: A/B must be 16-byte aligned", who);
+  splits = d->split_k > 0 ? d->split_k : 1;
+  VG_REQUIRE(splits == 1 || d->out_f32, "%s: split-K needs an fp32 (pre-zeroed) C", who);
   p.A = d->A; p.B = d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
@@ -401,16 +416,24 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   // tools/gemm_rotate.py + bench.py, same box: bands of 4 row-tiles +0.9 % end to end over n-fastest (8: +0.6 %)
   static const int group_m = [] { const char* e = getenv("VG_GEMM_GROUP_M"); return e ? atoi(e) : 4; }();
   p.group_m = group_m;
-  VG_REQUIRE(d->colsum_out == nullptr || (d->a_tr && d->b_tr), "vg_gemm: colsum_out needs a_tr = b_tr = 1");
+  VG_REQUIRE(d->colsum_out == nullptr || (d->a_tr && d->b_tr), "%s: colsum_out needs a_tr = b_tr = 1", who);
   int kps = (d->K + splits - 1) / splits;
   kps = ((kps + bk - 1) / bk) * bk;
   splits = (d->K + kps - 1) / kps;
   p.k_per_split = kps;
+  p.colpart = d->colpart;
+  p.split_ws = nullptr;
+  p.split_cnt = nullptr;
+  return 0;
+}
+}  // namespace
+
+extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
+  GemmParams p;
+  int splits = 1;
+  if (int e = fill_params(d, p, splits, "vg_gemm")) return e;
   // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
   const int cfg = pick_cfg(d);
-  p.colpart = d->colpart;
-  p.split_ws = d->tile_cfg == 13 ? d->split_ws : nullptr;      // tile_cfg 13: lab build, split_ws = stamp buffer
-  p.split_cnt = nullptr;
   if (splits > 1 && cfg > 0 && d->split_ws != nullptr && d->split_cnt != nullptr) {
     // in-launch reduction of the K slices through fp32 slabs: needs splits * tiles * tile floats of workspace
     const int rows = cfg_tile_rows(cfg), cols = (cfg == 3 || cfg == 4 || cfg >= 10) ? 256 : 128;
@@ -429,4 +452,32 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
              "vg_gemm: colpart needs the bf16 LDS-DMA path without split-K (ask vg_gemm_tile_rows first)");
   if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, cfg, stream);
   return launch<float>(p, d->a_tr, d->b_tr, splits, -1, stream);
+}
+
+extern "C" int vg_gemm_grouped(const vg_gemm_desc* descs, int n, hipStream_t stream) {
+  VG_REQUIRE(descs != nullptr && n >= 1 && n <= VG_GROUP_MAX, "vg_gemm_grouped: n = %d (1..%d)", n, VG_GROUP_MAX);
+  GemmParams ps[VG_GROUP_MAX];
+  int splits[VG_GROUP_MAX];
+  double work = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const vg_gemm_desc* d = descs + i;
+    if (int e = fill_params(d, ps[i], splits[i], "vg_gemm_grouped")) return e;
+    VG_REQUIRE(d->dtype == VG_BF16 && d->a_tr && d->b_tr && d->out_f32, "vg_gemm_grouped: problem %d is not a bf16 TN product with fp32 C", i);
+    VG_REQUIRE(d->K % 64 == 0 && ps[i].k_per_split % 64 == 0, "vg_gemm_grouped: problem %d: K = %d / split %d is not in whole 64-deep tiles",
+               i, d->K, splits[i]);
+    VG_REQUIRE(!d->bias && !d->residual && !d->aux_in && !d->aux_out && !d->pre_add && !d->lengths && d->act == VG_ACT_NONE &&
+                   d->dact == VG_ACT_NONE && !d->colsum_out && !d->colpart,
+               "vg_gemm_grouped: problem %d carries an epilogue", i);
+    VG_REQUIRE((long)d->K * d->lda * 2 < 0x7ffffff0L && (long)d->K * d->ldb * 2 < 0x7ffffff0L, "vg_gemm_grouped: problem %d is too large", i);
+    work += 2.0 * d->M * d->N * d->K;
+    bytes += gemm_algorithmic_bytes(ps[i], 2);
+  }
+  const int tok = vg_host::prof_begin(VG_PROF_GEMM_BF16_TN, work, stream, bytes);
+  const int rc = vg_host::gemm_group_launch(ps, splits, n, stream);
+  vg_host::prof_end(tok, stream);
+  if (rc != 0) {
+    vg_host::set_error("vg_gemm_grouped: launch failed");
+    return 3;
+  }
+  return vg_host::check_launch("vg_gemm_grouped");
 }

@@ -30,6 +30,8 @@ struct GemmParams {
 namespace vg_host {
 // LDS-DMA pipelined bf16 variant; returns 0 if launched, -1 if not applicable
 int gemm_dma_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits, hipStream_t stream);
-// phase-pipelined 256x256 tile (cfg 10: staggered wave groups, 11: in step); same return convention
+// phase-pipelined 256x256 tile (cfg 11: ring schedule, 12: complementary schedule); same return convention
 int gemm_ph_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits, hipStream_t stream);
+// grouped TN products on the ring schedule (weight gradients)
+int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_t stream);
 }

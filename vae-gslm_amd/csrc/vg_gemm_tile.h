@@ -172,7 +172,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
 // (c / (WCOLS/2)) * BN/2 + wn * (WCOLS/2) + c % (WCOLS/2); otherwise one contiguous (BM/WM) x (BN/WN) block.
 template <int BM, int BN, int WM, int WN, bool ILV = false>
 VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0,
-                             int wg, int nwg) {
+                             int wg, int nwg, int nsplit = (int)gridDim.z, int zidx = (int)blockIdx.z) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int WCOLS = TN * 16;
@@ -189,7 +189,7 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
     if constexpr (ILV) return (c / (WCOLS / 2)) * (BN / 2) + wn * (WCOLS / 2) + c % (WCOLS / 2);
     else return bcol + c;
   };
-  const bool split = gridDim.z > 1;
+  const bool split = nsplit > 1;
   __syncthreads();                         // every wave is done reading the last stage
   float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
   float cp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of this lane's 8 columns (colpart)
@@ -207,10 +207,10 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
       // write-through (sc1) stores: the slab is in memory once vmcnt drains, so publishing it needs no
       // release fence (an agent-scope release would write back the XCD's whole L2 once per block)
       typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-      const long slab_floats = (long)gridDim.z * nwg * (BM * BN);
+      const long slab_floats = (long)nsplit * nwg * (BM * BN);
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.split_ws, 0, (int)min(slab_floats * 4, 0x7fffffffL),
                                                                     0x00020000);
-      const long slab = ((long)blockIdx.z * nwg + wg) * (BM * BN);
+      const long slab = ((long)zidx * nwg + wg) * (BM * BN);
       constexpr int CPR = WCOLS / 8, RPP = 64 / CPR;
       const int crow = lane / CPR, cch = lane % CPR;
       for (int ps = 0; ps < (16 + RPP - 1) / RPP; ++ps) {
@@ -262,7 +262,7 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
       bcast[0] = __hip_atomic_fetch_add(p.split_cnt + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int ticket = bcast[0];
-    if (ticket != (int)gridDim.z - 1) return;
+    if (ticket != nsplit - 1) return;
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -282,7 +282,7 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
         if (m >= p.M || n >= p.N) continue;
         const long off = (long)(band_row(i) + rloc) * BN + strip_col(cch * 8);
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < (int)gridDim.z; ++z) {
+        for (int z = 0; z < nsplit; ++z) {
           const f32x4* src = reinterpret_cast<const f32x4*>(slab0 + z * slab_stride + off);
           lo += src[0];
           hi += src[1];

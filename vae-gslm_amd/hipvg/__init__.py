@@ -50,6 +50,7 @@ SIGNATURES = {
     "vg_last_error": [C.c_char_p, _i],
     "vg_gemm": [C.POINTER(GemmDesc), _vp],
     "vg_gemm_tile_rows": [C.POINTER(GemmDesc)],
+    "vg_gemm_grouped": [C.POINTER(GemmDesc), _i, _vp],
     "vg_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp],
     "vg_rmsnorm_bwd_blocks": [_i],
     "vg_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],

@@ -39,6 +39,8 @@ _COLPART = _flag("VG_COLPART", "1")             # dgrad launches also reduce the
 # (64 KiB of slab per slice; write-through slabs + ticket: 80 vs 67 us per wgrad launch, 289k vs 305k tokens/s;
 # with an agent-scope release fence per block instead of write-through stores: 90 us)
 _SPLIT_SLABS = _flag("VG_SPLIT_SLABS", "0")
+_PH_WGRAD = _flag("VG_PH_WGRAD", "1")           # weight gradients on 256x256 ring tiles (split sized for one block per CU)
+_PH_GROUP = _flag("VG_PH_GROUP", "1")           # a layer's four weight gradients as one grouped launch
 _GRAD_SINK = _flag("VG_GRAD_SINK", "1")         # wgrad / column sums write straight into param.grad
 # sunk weight gradients of a layer on a second stream (parallel graph branch): measured slower, 55.4 vs 53.2 ms
 # per step -- both branches are machine-filling GEMMs and only thrash each other's L2 / LDS residency
@@ -143,15 +145,21 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
 
 
 def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -> int:
-    """Split the reduction (frame) dimension of a weight-gradient GEMM so that the grid fills
-    256 CUs x 2 blocks (partial sums are combined with fp32 atomics).  The exact-f32 kernel is
-    only split for the tiny latent-side weights (a single tile would otherwise walk all 8000
-    frames serially)."""
+    """Split the reduction (frame) dimension of a weight-gradient GEMM so that the grid fills the 256 CUs (partial
+    sums are combined with fp32 atomics).  The exact-f32 kernel is only split for the tiny latent-side weights (a
+    single tile would otherwise walk all 8000 frames serially)."""
     tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
     if dtype == torch.float32:
         return 1 if tiles > 4 else max(1, min(32, k_red // 256))
-    # measured on MI355X (tools/wgrad_split_sweep.py): 2 for the big layer weights, ~6 for 64-tile
-    # outputs, up to 12 for the small ones
+    tiles256 = ((rows_out + 255) // 256) * ((cols_out + 255) // 256)
+    if _PH_WGRAD and k_red % 64 == 0 and tiles256 >= 12 and k_red >= 2048:
+        # 256x256 ring tiles (vg_gemm_ph.hip): one block per CU; every slice keeps >= 16 whole K tiles
+        s = max(1, min(10, round(256 / tiles256), k_red // 1024))
+        while s > 1 and (-(-k_red // s) + 63) // 64 * 64 * (s - 1) >= k_red:      # the library's rounding must keep s slices
+            s -= 1
+        return s
+    # 128x128 tiles, two blocks per CU; measured on MI355X (tools/wgrad_split_sweep.py): 2 for the big layer
+    # weights, ~6 for 64-tile outputs, up to 12 for the small ones
     if tiles >= 128:
         s = 2
     elif tiles >= 48:
@@ -159,6 +167,41 @@ def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -
     else:
         s = min(12, max(1, 768 // max(tiles, 1)))
     return max(1, min(s, k_red // 256))
+
+
+def sink_wgrad_group(items) -> None:
+    """``items``: (weight, dy[M, N], x[M, K]) triples of one backward node.  The weight gradients
+    ``weight.grad[N, K] += dy^T x`` of all of them in ONE launch (``vg_gemm_grouped``: 256x256 ring tiles, the big
+    products unsplit, so no memory-side atomics) when every product qualifies; one launch each otherwise."""
+    items = [it for it in items if it is not None]
+    if not items:
+        return
+    ok = _PH_GROUP and len(items) <= 8
+    total = 0
+    for w, dy, x in items:
+        N, K, M = w.shape[0], w.numel() // w.shape[0], x.shape[0]
+        ok = ok and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and M % 64 == 0 and M >= 1024
+        ok = ok and N % 8 == 0 and K % 8 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and w.is_contiguous()
+        ok = ok and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+        total += ((N + 255) // 256) * ((K + 255) // 256)
+    if not ok or total < 96:
+        for w, dy, x in items:
+            sink_wgrad(w, dy, x, None)
+        return
+    # blocks of equal length fill 256 CUs in whole rounds: 96..256 tiles run unsplit (one round), more tiles mean more
+    # rounds; fewer than 96 went the other way above
+    descs = (GemmDesc * len(items))()
+    for d, (w, dy, x) in zip(descs, items):
+        N, K, M = w.shape[0], w.numel() // w.shape[0], x.shape[0]
+        g = _grad_buffer(w).view(N, K)
+        d.A, d.B, d.C = ptr(dy), ptr(x), ptr(g)
+        d.M, d.N, d.K = N, K, M
+        d.lda, d.ldb, d.ldc = dy.stride(0), x.stride(0), g.stride(0)
+        d.a_tr, d.b_tr, d.dtype = 1, 1, dtype_id(torch.bfloat16)
+        d.out_f32, d.accumulate, d.split_k, d.alpha = 1, 1, 1, 1.0
+    check(lib().vg_gemm_grouped(descs, len(items), stream()), "vg_gemm_grouped")
+    for w, _, _ in items:
+        _fire(w)
 
 
 def colsum(x: Tensor, into: Optional[Tensor] = None) -> Tensor:
@@ -813,32 +856,43 @@ class TransformerLayerFn(torch.autograd.Function):
         du = gemm(dy, s2, M, F_, D, b_tr=True, dact=ACT_STORED if _STORED_DERIV else ACT_GELU, aux_in=u,
                   colpart=parts)                 # + column sums of du per row tile (b1's gradient) for free
         ws = WgradStream(x.device, _WGRAD_STREAM)
-        g_w2, g_b2 = ws.wgrad(w2, b2, dy, h)
+        # the layer's four weight gradients run as ONE grouped launch at the end of this node when they can be sunk
+        group = [] if (_PH_GROUP and not ws.enabled and dt == torch.bfloat16 and
+                       all(_sinkable(w) and w.is_contiguous() for w in (w1, w2, wo, wqkv))) else None
+
+        def wgrad(weight, bias, g_out, inp):
+            if group is None:
+                return ws.wgrad(weight, bias, g_out, inp)
+            group.append((weight, g_out, inp))
+            return None, vec_grad(bias, g_out)
+        g_w2, g_b2 = wgrad(w2, b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
         small = []                               # (parameter, fp32 partial sums): folded by one launch at the end
         g_b1 = None
         if want_part and parts[0] is not None:
-            g_w1, _ = ws.wgrad(w1, None, du, n3)
+            g_w1, _ = wgrad(w1, None, du, n3)
             small.append((b1, parts[0]))
         else:
-            g_w1, g_b1 = ws.wgrad(w1, b1, du, n3)
+            g_w1, g_b1 = wgrad(w1, b1, du, n3)
         dx1, ds3 = rmsnorm_bwd_raw(dn3, x1, sc3, rstd3, dy, lengths, T)
         small.append((n3s, ds3))
         # ---- attention
         datt = gemm(dx1, so, M, D, D, b_tr=True)
-        g_wo, g_bo = ws.wgrad(wo, bo, dx1, att)
+        g_wo, g_bo = wgrad(wo, bo, dx1, att)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
         check(lib().vg_attn_bwd(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
                                 B, T, H, ptr(lengths), dtype_id(dt), stream()), "vg_attn_bwd")
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
-        g_wq, g_bq = ws.wgrad(wqkv, bqkv, dqkv, n1)
+        g_wq, g_bq = wgrad(wqkv, bqkv, dqkv, n1)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
         small.append((n1s, ds1))
         folded = dict(zip((id(p) for p, _ in small), vec_grads(small)))
         g_n1, g_n3 = folded[id(n1s)], folded[id(n3s)]
         if b1 is not None and id(b1) in folded:
             g_b1 = folded[id(b1)]
+        if group is not None:
+            sink_wgrad_group(group)
         ws.join()                                # before qkv / att / du ... can be released
         return (dx, g_n1, g_wq, g_bq, g_wo, g_bo, g_n3, g_w1, g_b1, g_w2, g_b2,
                 None, None, None, None, None, None)
