@@ -253,17 +253,17 @@ def main():
             ms, work, n = hipvg.prof_read(k)
             if n:
                 kinds[k] = {"launches": n, "avg_us": 1e3 * ms / n, "tflops": work / (ms * 1e-3) / 1e12}
+            if k.startswith("gemm_bf16"):
+                tot_ms += ms
+                tot_work += work
+                tot_bytes += hipvg.prof_read_bytes(k)
+                tot_n += n
         # HBM-bound row kernels: algorithmic bytes / launch time, against the copy rate measured below
         hbm_kernels = {}
         for k in ("rmsnorm_fwd", "rmsnorm_bwd", "adamw", "dwnorm_fwd", "dwnorm_bwd"):
             ms, nbytes, n = hipvg.prof_read(k)
             if n:
                 hbm_kernels[k] = {"launches": n, "avg_us": 1e3 * ms / n, "gb_per_s": nbytes / (ms * 1e-3) / 1e9}
-            if k.startswith("gemm_bf16"):
-                tot_ms += ms
-                tot_work += work
-                tot_bytes += hipvg.prof_read_bytes(k)
-                tot_n += n
         hipvg.prof_enable(False)
         achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
         peaks = hipvg.probe_peaks(device)          # this box, this run: register-fed MFMA chains and a 1 GiB copy

@@ -150,7 +150,7 @@ def test_module_objects_match_reference_module_vectors(golden):
     xm = TensorMask(x, mask).apply_mask()
     # RMSNorm (modules/norm.py:22-32)
     rn = _fill(RMSNorm(D, eps=1e-6), 11)
-    np.testing.assert_allclose(rn(x).cpu().numpy(), g["rmsnorm_y"], atol=2e-6, rtol=2e-6)
+    np.testing.assert_allclose(rn(x).detach().cpu().numpy(), g["rmsnorm_y"], atol=2e-6, rtol=2e-6)
     # SelfAttention with ALiBi (modules/attention/attention.py:36-93)
     sa = _fill(SelfAttention(D, Hparams.from_dict(dict(nheads=H, causal=True))), 12)
     alibi = ALiBi(H, 64).cuda()
@@ -294,13 +294,6 @@ def test_ragged_graph_replay_uses_each_batch_lengths(full_cfg, monkeypatch):
             table[key] = gen_fn().to(d)
         return table[key].clone()
 
-    cpu = torch.Generator().manual_seed(11)
-    monkeypatch.setattr(torch, "randn", lambda *s, **kw: fixed("randn", s if not isinstance(s[0], (tuple, list, torch.Size)) else s[0],
-                                                               lambda: torch.randn(*s, generator=cpu)))
-    monkeypatch.setattr(torch, "randn_like", lambda x, **kw: fixed("randn", x.shape, lambda: torch.randn(*x.shape, generator=cpu)).to(x.dtype))
-    monkeypatch.setattr(torch, "rand", lambda *s, **kw: fixed("rand", s, lambda: torch.rand(*s, generator=cpu)))
-    monkeypatch.setattr(torch, "randint", lambda lo, hi, size, **kw: fixed("randint", size, lambda: torch.randint(lo, hi, size, generator=cpu)))
-
     def ragged(seed, lens, T=128):
         b = make_batch(len(lens), T, d, seed=seed)
         mask = torch.arange(T, device=d)[None] < torch.tensor(lens, device=d)[:, None]
@@ -308,6 +301,17 @@ def test_ragged_graph_replay_uses_each_batch_lengths(full_cfg, monkeypatch):
                 "cropped_mel_utt": b["cropped_mel_utt"]}
 
     batches = [ragged(1, [128, 90, 64]), ragged(2, [70, 128, 33]), ragged(3, [128, 5, 101])]
+    cpu = torch.Generator().manual_seed(11)
+    o_randn, o_rand, o_randint = torch.randn, torch.rand, torch.randint
+
+    def shape_of(s):
+        return tuple(s[0]) if len(s) == 1 and isinstance(s[0], (tuple, list, torch.Size)) else tuple(s)
+
+    monkeypatch.setattr(torch, "randn", lambda *s, **kw: fixed("randn", shape_of(s), lambda: o_randn(*shape_of(s), generator=cpu)))
+    monkeypatch.setattr(torch, "randn_like", lambda x, **kw: fixed("randn", x.shape, lambda: o_randn(*x.shape, generator=cpu)).to(x.dtype))
+    monkeypatch.setattr(torch, "rand", lambda *s, **kw: fixed("rand", shape_of(s), lambda: o_rand(*shape_of(s), generator=cpu)))
+    monkeypatch.setattr(torch, "randint", lambda lo, hi, size, **kw: fixed("randint", size, lambda: o_randint(lo, hi, tuple(size), generator=cpu)))
+
     results = {}
     for mode in ("eager", "graph"):
         tr = _trainer_c1(full_cfg, graph=(mode == "graph"))

@@ -42,7 +42,7 @@ def read(directory, counter):
 
 
 def is_bf16_gemm(name):
-    return "gemm_dma_kernel" in name
+    return any(k in name for k in ("gemm_dma_kernel", "gemm_dma32_kernel", "gemm_ph_kernel", "gemm_ring_group_kernel"))
 
 
 def short(name):

@@ -361,15 +361,15 @@ int pick_cfg(const vg_gemm_desc* d) {
     };
     const double longk_pen = 0.10 * fmin(1.0, fmax(0.0, (d->K - 1024) / 3072.0));   // 128x128 falls behind at long K
     // the phase-pipelined 256x256 loop is 8-35 % faster than the 2-stage one it replaces (tools/lab/ph_check.py)
-    const double f256 = ph_ok ? (d->b_tr ? 0.80 : 0.92) : 1.0;
+    const double f256 = ph_ok ? (d->b_tr ? 0.75 : 0.92) : 1.0;
     const double c1 = cost(128, 128, 2, 1.08 + longk_pen), c3 = cost(256, 256, 1, f256), c9 = cost(192, 256, 1, 0.97);
     cfg = c3 <= c1 ? 3 : 1;
     if (c9 < 0.95 * fmin(c1, c3)) cfg = 9;      // the odd shape must win clearly (model error ~5 %)
-    if (cfg == 3 && ph_ok) cfg = d->b_tr ? 11 : 12;     // NN: ring schedule, NT: complementary schedule
+    if (cfg == 3 && ph_ok) cfg = d->b_tr ? 13 : 12;     // NN: complementary schedule with long phases, NT: with short ones
   } else if (d->b_tr && ph_ok && !d->colsum_out) {
     // weight gradients: 256x256 ring tiles once they can fill a good part of the chip with the caller's split
     const long tiles = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splits;
-    if (tiles >= 96) cfg = 11;
+    if (tiles >= 96) cfg = 13;
   }
   static const int longk = [] { const char* e = getenv("VG_CFG_LONGK"); return e ? atoi(e) : 5; }();
   if (cfg == 1 && !d->a_tr && !d->b_tr && d->K >= 4096 && d->N <= 1024 && d->M >= 2048 && longk > 0) cfg = longk;

@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM, phase-pipelined 256x256 tile (vg_gemm tile_cfg 11 / 12, vg_gemm_grouped): the main loops the large
+// bf16 MFMA GEMM, phase-pipelined 256x256 tile (vg_gemm tile_cfg 11 / 12 / 13, vg_gemm_grouped): the main loops the large
 // products of the training step run on.
 //
 // Why other main loops than gemm_dma_kernel.  That kernel keeps ONE 64 KB K tile in flight, requested after the
@@ -17,11 +17,13 @@
 //           past the last K tile have an empty window and become zero fills of slots nobody reads, so every phase
 //           keeps the same counted wait and there is no tail code.  K must be a multiple of 64 per split.
 //
-// Two schedules, measured per operand mode at the layer shapes (tools/lab/ph_check.py, one box, cold operands;
-// TFLOP/s of 2-stage 256x256 / staggered 4-phase / ring / complementary):
-//   NT (row images)            FFN-out fwd 1041 / 1087-1135 / 1036-1092 / 1114     -> complementary (gemm_px_kernel)
-//   NN (B k-major)             FFN-in dgrad 787 / 1069-1084 / 1165-1179 / 1005     -> ring          (gemm_ring_kernel)
-//   TN (both k-major, split-K) W1 wgrad 722 / 755-765 / 834-840 / 776              -> ring
+// Three schedules, measured per operand mode at the layer shapes (tools/lab/ph_check.py, one box, cold operands;
+// TFLOP/s of 2-stage 256x256 / ring (cfg 11) / complementary (12) / complementary with long phases (13)):
+//   NT (row images)            FFN-out fwd 1041 / 1033-1092 / 1107-1162 / 1105     -> complementary
+//   NN (B k-major)             FFN-in dgrad 787 / 1154-1181 / 992-1005 / 1244      -> complementary, long phases
+//   TN (both k-major, split-K) W1 wgrad 722 / 825-840 / 774-778 / 868              -> complementary, long phases
+// (a first version with two barriers per 16-MFMA phase and the second group one barrier behind reached 1087-1135 /
+// 1069-1084 / 755-765 and was dropped)
 // In-kernel stamps of the complementary loop (tools/lab/ph_stamp.py): an interval is ~650 cycles for 2 x 256 cycles
 // of MFMA issue (79 %), the chip holds ~2.0 GHz under it; entry to first MFMA 2.0 us; the plain bf16 store epilogue
 // of a 256x256 tile takes 8.7 us = 3.8 TB/s over 256 CUs, i.e. it runs at the HBM write rate and only overlapping
@@ -111,14 +113,19 @@ struct TileCtx {
 
   // `tile` = this block's tile index before the XCD-aware remap, `z` = its K slice
   VG_DEVICE void init(const GemmParams& p, int tile, int z, int wave, int lane) {
+    const int kbeg = z * p.k_per_split;
+    init_range(p, tile, kbeg, (min(p.K, kbeg + p.k_per_split) - kbeg) / BK, true, wave, lane);
+  }
+  // K tiles [kbeg / 64, kbeg / 64 + ntiles) of output tile `tile` (`remap`: apply the XCD-aware tile order)
+  VG_DEVICE void init_range(const GemmParams& p, int tile, int kbeg, int ntiles, bool remap, int wave, int lane) {
     constexpr int BM = 256, BN = 256;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     nwg = ntn * ntm;
     // blocks that share an XCD get a contiguous run of tiles (bijective remap) ...
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = tile & 7;
-    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+    wg = remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3) : tile;
     int mt = wg / ntn, nt = wg % ntn;
-    if (p.group_m > 0) {    // ... walked m-fastest inside bands of group_m row-tiles (fewer distinct operand panels per XCD)
+    if (remap && p.group_m > 0) {    // ... walked m-fastest inside bands of group_m row-tiles (fewer distinct operand panels per XCD)
       const int gsz = p.group_m * ntn, gid = wg / gsz, first = gid * p.group_m;
       const int gm = min(ntm - first, p.group_m), rem = wg - gid * gsz;
       mt = first + rem % gm;
@@ -126,9 +133,7 @@ struct TileCtx {
     }
     m0 = mt * BM;
     n0 = nt * BN;
-    const int kbeg = z * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    nkt = (kend - kbeg) / BK;          // whole K tiles only (the host checks)
+    nkt = ntiles;                      // whole K tiles only (the host checks)
     // The descriptor base advances with the K tile and its size shrinks by the same amount, so the hardware range
     // check stays exact (rows past M / N and k-rows past K read zeros) and the per-lane offsets never change.
     const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
@@ -363,6 +368,109 @@ VG_DEVICE void ring_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Complementary schedule with long phases (tile_cfg 13): the opposite-order wave groups and the single barrier per
+// phase of px_main_loop, but TWO phases of 32 MFMAs per K tile (a barrier every 2 x 512 MFMA cycles instead of
+// every 2 x 256) on the 10-slot image ring of ring_main_loop:
+//   phase A  reads b0, a0, b1 (16 fragments), MFMA a0 x b0, a0 x b1;   phase B  reads a1 (8), MFMA a1 x b1, a1 x b0
+//   interval k (one phase): group X issues MFMA_k, then reads the fragments of phase k + 1; group Y reads the
+//   fragments of phase k, then issues MFMA_k.  Both request images 2 k + 8 and 2 k + 9 in their read segment -- the
+//   slots they take (images 2 k - 2, 2 k - 1) were last read by Y in interval k - 1, behind the barrier -- and wait
+//   before the closing barrier for what interval k + 1 reads: images <= 2 k + 6 after a phase A (vmcnt(6)),
+//   <= 2 k + 5 after a phase B (vmcnt(8)).
+template <bool A_TR, bool B_TR>
+VG_DEVICE void px2_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
+  constexpr int NSLOT = 10;
+  const int wr = wave >> 2, wc = wave & 3;
+  BlockReader<A_TR, 4> rda;
+  BlockReader<B_TR, 2> rdb;
+  rda.init(wr * 64, lane);
+  rdb.init(wc * 32, lane);
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  const int nkt = c.nkt;
+  auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
+  auto request = [&](int t, int h, int slot) { c.request(t, h, smem + slot * HALF_BYTES + wave * 1024); };
+  // fragments of phase A (images in slots s0 = B half 0, s0 + 1 = A half 0, s0 + 2 = B half 1) / phase B (s0 + 3)
+  auto reads_a = [&](int s0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fb0[j][s] = rdb.get(smem + s0 * HALF_BYTES, j, s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fa[i][s] = rda.get(smem + wrap(s0 + 1) * HALF_BYTES, i, s);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fb1[j][s] = rdb.get(smem + wrap(s0 + 2) * HALF_BYTES, j, s);
+  };
+  auto reads_b = [&](int s0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fa[i][s] = rda.get(smem + wrap(s0 + 3) * HALF_BYTES, i, s);
+  };
+  auto mfmas = [&](auto halfc) {
+    constexpr int A0 = decltype(halfc)::value * 4;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int b = A0 == 0 ? bb : 1 - bb;          // phase B starts with b1 (b0 stays for the end)
+            acc[A0 + i][2 * b + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], b == 0 ? fb0[j][s] : fb1[j][s],
+                                                                             acc[A0 + i][2 * b + j], 0, 0, 0);
+          }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // requests of interval k: images 2 k + 8, 2 k + 9 = K tile t + 2, h = 0, 1 (phase A) / 2, 3 (phase B); ws0 = slot of 4 t + 8
+  auto req = [&](auto halfc, int t, int ws0) {
+    constexpr int H0 = decltype(halfc)::value * 2;
+    request(t + 2, H0, wrap(ws0 + H0));
+    request(t + 2, H0 + 1, wrap(ws0 + H0 + 1));
+  };
+  auto close = [&](auto halfc) {
+    if constexpr (decltype(halfc)::value == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    phase_barrier();
+  };
+
+  // ---- prologue: images 0..7 (K tiles 0 and 1); images 0..2 visible at the first barrier, image 3 at the second
+#pragma unroll
+  for (int s = 0; s < 8; ++s) request(s >> 2, s & 3, s);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  phase_barrier();
+  int rs0 = 0, ws0 = 8;            // ring slots of image 4 t and of image 4 t + 8
+  if (wr == 0) {
+    // ------------------------------------------------ group X: MFMA_k, then the fragments of phase k + 1
+    reads_a(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    phase_barrier();
+    for (int t = 0; t < nkt; ++t) {
+      mfmas(P0{}); __builtin_amdgcn_sched_barrier(0); reads_b(rs0); req(P0{}, t, ws0); close(P0{});
+      mfmas(P1{}); __builtin_amdgcn_sched_barrier(0); reads_a(wrap(rs0 + 4)); req(P1{}, t, ws0); close(P1{});
+      rs0 = wrap(rs0 + 4);
+      ws0 = wrap(ws0 + 4);
+    }
+  } else {
+    // ------------------------------------------------ group Y: the fragments of phase k, then MFMA_k
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    phase_barrier();
+    for (int t = 0; t < nkt; ++t) {
+      reads_a(rs0); req(P0{}, t, ws0); __builtin_amdgcn_sched_barrier(0); mfmas(P0{}); close(P0{});
+      reads_b(rs0); req(P1{}, t, ws0); __builtin_amdgcn_sched_barrier(0); mfmas(P1{}); close(P1{});
+      rs0 = wrap(rs0 + 4);
+      ws0 = wrap(ws0 + 4);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
+}
+
 VG_DEVICE void zero_acc(f32x4 (&acc)[8][4]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -370,7 +478,8 @@ VG_DEVICE void zero_acc(f32x4 (&acc)[8][4]) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-template <bool A_TR, bool B_TR, bool RING>
+// SCHED: 0 = complementary (px), 1 = ring, 2 = complementary with long phases (px2)
+template <bool A_TR, bool B_TR, int SCHED>
 __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -379,21 +488,26 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
   c.init(p, blockIdx.x, blockIdx.z, wave, lane);
   f32x4 acc[8][4];                 // [a * 4 + i][b * 2 + j]
   zero_acc(acc);
-  if constexpr (RING) ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
+  if constexpr (SCHED == 1) ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
+  else if constexpr (SCHED == 2) px2_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
   else px_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
   tile_epilogue<256, 256, 2, 4, true>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Grouped launch (vg_gemm_grouped): up to VG_GROUP_MAX products of one operand mode in ONE grid.  Written for the
-// weight gradients of a Transformer layer: dW1, dW2, dWqkv, dWo are 64 + 64 + 48 + 16 tiles of 256x256 whose
-// reduction runs over all M frames (250 K tiles at M = 16000).  Launched one by one each needs split-K to fill the
-// chip (x4, x4, x5, x10) and pays for it with fp32 atomics at the memory side's 1.3 TB/s (67 MB for dW1 alone); in
-// one grid the 176 big tiles run unsplit next to the 16 small ones split 4 ways -- 240 blocks, one per CU.
+// Grouped launch (vg_gemm_grouped): up to VG_GROUP_MAX weight-gradient products in ONE persistent grid.
+// Written for the weight gradients of a Transformer layer: dW1, dW2, dWqkv, dWo are 64 + 64 + 48 + 16 output tiles of
+// 256x256 whose reduction runs over all M frames (250 K tiles at M = 16000).  Launched one by one each needs split-K
+// to fill the chip (x4, x4, x5, x10), whose equal slices all reach their fp32 atomics together (67 MB for dW1 alone
+// at the memory side's 1.3 TB/s); launched as whole tiles they are 192 equal blocks for 256 CUs.  Here the
+// (tile, K tile) pairs of all problems form one line of work that is cut into 256 EQUAL ranges (stream-K): a block
+// walks its range, finishing one tile and starting the next; a segment that covers a tile's whole K adds to the
+// gradient with plain 16-byte accesses, a partial one with fp32 atomics.  Every CU gets the same number of K
+// tiles, and the segment ends -- hence the atomic bursts -- fall at a different time on every CU.
 struct GroupParams {
   GemmParams p[VG_GROUP_MAX];
-  int first_block[VG_GROUP_MAX + 1];     // first block of problem g; [n] = grid size
-  int splits[VG_GROUP_MAX];
+  int unit0[VG_GROUP_MAX + 1];      // first work unit (one K tile of one output tile) of problem g; [n] = total
+  int nkt[VG_GROUP_MAX];            // K tiles per output tile
   int n;
 };
 
@@ -402,21 +516,32 @@ __global__ __launch_bounds__(512) void gemm_ring_group_kernel(GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bid = blockIdx.x;
-  int g = 0;
+  // blocks that share an XCD (blockIdx % 8 under round-robin placement: speed only) take neighbouring ranges
+  const int P = gridDim.x;
+  const int q8 = P >> 3, r8 = P & 7, xcd = blockIdx.x & 7;
+  const int b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const long total = gp.unit0[gp.n];
+  int u = (int)(total * b / P);
+  const int uend = (int)(total * (b + 1) / P);
+  while (u < uend) {
+    int g = 0;
 #pragma unroll
-  for (int i = 1; i < VG_GROUP_MAX; ++i)
-    if (i < gp.n && bid >= gp.first_block[i]) g = i;
-  const GemmParams& p = gp.p[g];
-  const int local = bid - gp.first_block[g];
-  const int ntiles = ((p.N + 255) / 256) * ((p.M + 255) / 256);
-  const int z = local / ntiles, tile = local - z * ntiles;
-  TileCtx<A_TR, B_TR> c;
-  c.init(p, tile, z, wave, lane);
-  f32x4 acc[8][4];
-  zero_acc(acc);
-  ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-  tile_epilogue<256, 256, 2, 4, true>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg, gp.splits[g], z);
+    for (int i = 1; i < VG_GROUP_MAX; ++i)
+      if (i < gp.n && u >= gp.unit0[i]) g = i;
+    const GemmParams& p = gp.p[g];
+    const int nkt = gp.nkt[g];
+    const int local = u - gp.unit0[g];
+    const int tile = local / nkt, kt = local - tile * nkt;
+    const int count = min(nkt - kt, uend - u);
+    TileCtx<A_TR, B_TR> c;
+    c.init_range(p, tile, kt * BK, count, false, wave, lane);
+    f32x4 acc[8][4];
+    zero_acc(acc);
+    px2_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
+    tile_epilogue<256, 256, 2, 4, true>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg, count == nkt ? 1 : 2, 0);
+    u += count;
+    __syncthreads();               // the strips are read out before the next segment's images land in them
+  }
 }
 
 template <typename K>
@@ -424,10 +549,10 @@ void set_lds(K k, size_t lds) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <bool A_TR, bool B_TR, bool RING>
+template <bool A_TR, bool B_TR, int SCHED>
 int launch_ph(const GemmParams& p, int splits, hipStream_t stream) {
-  constexpr size_t lds = RING ? 10 * HALF_BYTES : 2 * BUF_BYTES;
-  auto k = gemm_ph_kernel<A_TR, B_TR, RING>;
+  constexpr size_t lds = SCHED != 0 ? 10 * HALF_BYTES : 2 * BUF_BYTES;
+  auto k = gemm_ph_kernel<A_TR, B_TR, SCHED>;
   static bool attr_done = false;
   if (!attr_done) {
     set_lds(k, lds);
@@ -446,27 +571,44 @@ int gemm_ph_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits,
   if (a_tr && !b_tr) return -1;
   if (p.k_per_split % BK != 0 || p.K % BK != 0) return -1;       // whole K tiles in every split
   if (cfg == 12) {
-    if (!a_tr && !b_tr) return launch_ph<false, false, false>(p, splits, stream);
-    if (!a_tr && b_tr) return launch_ph<false, true, false>(p, splits, stream);
-    return launch_ph<true, true, false>(p, splits, stream);
+    if (!a_tr && !b_tr) return launch_ph<false, false, 0>(p, splits, stream);
+    if (!a_tr && b_tr) return launch_ph<false, true, 0>(p, splits, stream);
+    return launch_ph<true, true, 0>(p, splits, stream);
   }
-  if (!a_tr && !b_tr) return launch_ph<false, false, true>(p, splits, stream);
-  if (!a_tr && b_tr) return launch_ph<false, true, true>(p, splits, stream);
-  return launch_ph<true, true, true>(p, splits, stream);
+  if (cfg == 13) {
+    if (!a_tr && !b_tr) return launch_ph<false, false, 2>(p, splits, stream);
+    if (!a_tr && b_tr) return launch_ph<false, true, 2>(p, splits, stream);
+    return launch_ph<true, true, 2>(p, splits, stream);
+  }
+  if (!a_tr && !b_tr) return launch_ph<false, false, 1>(p, splits, stream);
+  if (!a_tr && b_tr) return launch_ph<false, true, 1>(p, splits, stream);
+  return launch_ph<true, true, 1>(p, splits, stream);
 }
 
-// grouped TN products (weight gradients); every problem: bf16, a_tr = b_tr = 1, whole K tiles per split
+// grouped TN products (weight gradients); every problem: bf16, a_tr = b_tr = 1, whole K tiles, split_k = 1
 int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_t stream) {
   GroupParams gp;
   gp.n = n;
-  int blocks = 0;
+  long units = 0, tiles = 0;
   for (int i = 0; i < n; ++i) {
+    if (splits[i] != 1) return -1;
     gp.p[i] = ps[i];
-    gp.splits[i] = splits[i];
-    gp.first_block[i] = blocks;
-    blocks += ((ps[i].N + 255) / 256) * ((ps[i].M + 255) / 256) * splits[i];
+    gp.nkt[i] = ps[i].K / BK;
+    gp.unit0[i] = (int)units;
+    const long t = (long)((ps[i].N + 255) / 256) * ((ps[i].M + 255) / 256);
+    tiles += t;
+    units += t * gp.nkt[i];
+    if (units > 0x3fffffffL) return -1;
   }
-  for (int i = n; i <= VG_GROUP_MAX; ++i) gp.first_block[i] = blocks;
+  for (int i = n; i <= VG_GROUP_MAX; ++i) gp.unit0[i] = (int)units;
+  // one block per CU; fewer when there is less than ~8 K tiles of work for each
+  static const int cus = [] {
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return n_cu > 0 ? n_cu : 256;
+  }();
+  const int blocks = (int)max(1L, min((long)cus, units / 8));
+  (void)tiles;
   constexpr size_t lds = 10 * HALF_BYTES;
   auto k = gemm_ring_group_kernel<true, true>;
   static bool attr_done = false;
