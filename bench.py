@@ -52,13 +52,15 @@ def cpu_model_name() -> str:
 
 def cpu_baseline(threads_note=True):
     """Oracle (CPU port of the reference fp32 path): full config, B=2, T=1000,
-    forward+backward after a short warm-up at T=64, on every host core."""
+    forward+backward after a short warm-up at T=64.  `cores` reports the host's core count; the run itself uses at
+    most 32 intra-op threads (`threads`): on these shapes more threads only add synchronisation cost -- a 256-thread
+    pool made the same sample take minutes instead of seconds."""
     import yaml
     from oracle import lvtr_oracle as O
     from oracle.weights import fill_like
     with open(CONFIG) as f:
         cfg = yaml.safe_load(f)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     mcfg = cfg["model"]
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in fill_like(O.param_shapes(mcfg), 1).items()}
 
@@ -100,8 +102,65 @@ def cpu_baseline(threads_note=True):
             "sample": f"oracle fp32 fwd+bwd, full config, B={B}, T={T}, {steps} step(s) ({dt:.1f} s) after a warm-up"}
 
 
+def decode_main(args):
+    """``--mode decode``: BASELINE config 4 (3 s prompt -> 10 s continuation, hipGraph-captured decode step, 1 GPU).
+    A "step" is one generated frame for every sequence of the batch; the JSON line keeps the training line's shape
+    with an HBM roofline: the step streams the bf16 weights of the stack and heads once plus the live key/value
+    cache, so achieved = (weight bytes + mean cache bytes per frame) / measured time per frame."""
+    import hipvg
+    from hparams.hp import Hparams
+    from inference.speech.session import DecodeSession
+    from models.speech.lvtr import LVTR
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    if args.gpus != 1:
+        raise SystemExit("--mode decode is a single-GPU measurement (replicas only: sequences are independent)")
+    hipvg.lib()
+    hipvg.set_precision("bf16")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = LVTR(Hparams.from_yamlfile(CONFIG).model, input_dim=80).to(dev).eval()
+    B, Tp = args.decode_batch, args.prompt_frames
+    frames, warm = max(args.steps, 8), max(args.warmup, 2)
+    stack = model.transformer[0]
+    n_params = sum(p.numel() for p in stack.parameters()) + sum(
+        p.numel() for m in (model.q_spliter, model.token_spliter, model.token_predictor, model.transformer[1])
+        for p in m.parameters()) + sum(l.film.linear.weight.numel() for l in model.transformer_flow.layers)
+    wbytes = 2.0 * n_params
+    prior = torch.cat([torch.randint(0, 200, (B, Tp, 1), device=dev).float(), torch.randn(B, Tp, 4, device=dev)], -1)
+    sess = DecodeSession(model, B, Tp + frames + warm + 8, temperature=0.85, token_temperature=0.85, use_graph=True)
+    sess.prefill(prior)
+    for _ in range(warm):                # eager first frame, capture, first replay
+        sess.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sess.generate(frames)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    L, D = len(stack.layers), stack.hp.layer.dim
+    mean_ctx = Tp + 1 + warm + frames / 2.0
+    kv_bytes = 2.0 * L * B * mean_ctx * D * 2            # K and V rows of every layer, bf16
+    peaks = hipvg.probe_peaks(dev)
+    achieved = (wbytes + kv_bytes) / dt / 1e9
+    line = {"metric": "decode frames/sec (50 Hz frames), 3 s prompt -> continuation, hipGraph-captured step",
+            "value": B / dt, "unit": "frames/s", "n_gpus": 1, "steps": frames, "warmup": warm, "ms_per_step": 1e3 * dt,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"vae-gslm.yaml full config autoregressive decode (LVTR.step path), batch {B}, "
+                                   f"prompt {Tp} frames, {frames} generated frames", "batch": B, "prompt_frames": Tp},
+            "roofline": {"bound": "hbm", "kernel": "decode step (gemm_rows weight streaming + cache attention)",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "frac_of_measured_copy": achieved / (1e3 * peaks["hbm_copy_tb_per_s"]),
+                         "hbm_copy_measured_tb_per_s": peaks["hbm_copy_tb_per_s"],
+                         "weight_bytes_per_frame": wbytes, "kv_cache_bytes_per_frame": kv_bytes, "traffic": None}}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="train", choices=("train", "decode"),
+                    help="train: the headline training step (default); decode: BASELINE config 4, the AR decode step")
+    ap.add_argument("--decode-batch", type=int, default=8)
+    ap.add_argument("--prompt-frames", type=int, default=150)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -122,6 +181,10 @@ def main():
                     help="sequence lengths ~ U{T/2..T} (right-padded batches, SURVEY 8d): shows the cost of masking; "
                          "tokens/s then counts valid frames only")
     args = ap.parse_args()
+    if args.mode == "decode":
+        if args.steps == 5 and args.warmup == 2:        # the training defaults: a decode run wants more frames
+            args.steps, args.warmup = 400, 4
+        return decode_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

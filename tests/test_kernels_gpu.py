@@ -253,18 +253,27 @@ def test_attention_fwd_bwd(F, dtype, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_softmax_rescale_branch(F, dtype):
-    """Force the running max to jump late in the sequence (spiked key) so the
-    online-softmax rescale path is exercised against a full fp64 reference."""
+    """Force the running max to jump in the middle of the key sweep (a spiked key) so the online-softmax rescale
+    path is exercised against a full fp64 reference.  The forward sweeps the key tiles from the diagonal DOWN to
+    tile 0, so the spike sits on an EARLY key (tile 0) for late queries: their maximum jumps at the last tile of
+    the sweep; a second spike on a late key covers an ascending sweep as well."""
     B_, T, H = 1, 256, 4
     D = H * 64
     slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
-    qkv = rnd(B_ * T, 3 * D, dtype=dtype, scale=0.5)
-    with torch.no_grad():
-        qkv[200, D:D + 64] = 6.0          # key 200 of head 0 spikes
-        qkv[201:, 0:64] = 1.5             # later queries align with it
-    out = F.attention(qkv, slopes, B_, T, H, None)
-    ref = attn_reference(qkv, B_, T, H, torch.tensor([T], device=dev()), slopes)
-    torch.testing.assert_close(out.double(), ref, **tol(dtype))
+    for spike, queries in ((10, slice(200, None)), (200, slice(201, None))):
+        qkv = rnd(B_ * T, 3 * D, dtype=dtype, scale=0.5)
+        with torch.no_grad():
+            qkv[spike, D + 192:D + 256] = 12.0        # key `spike` of head 3 (the flattest ALiBi slope) stands out ...
+            qkv[queries, 192:256] = 1.5               # ... for these queries
+        out = F.attention(qkv, slopes, B_, T, H, None)
+        ref = attn_reference(qkv, B_, T, H, torch.tensor([T], device=dev()), slopes)
+        # the spiked key must actually dominate those rows (otherwise the branch under test was not taken late)
+        q, k = qkv[queries, 192:256].double(), qkv[:, D + 192:D + 256].double()
+        sc = q @ k.t() / 8.0 - float(slopes[3]) * (torch.arange(T, device=dev())[queries][:, None]
+                                                    - torch.arange(T, device=dev())[None]).clamp_min(0).double()
+        causal = torch.arange(T, device=dev())[None] <= torch.arange(T, device=dev())[queries][:, None]
+        assert bool((sc.masked_fill(~causal, -1e9).argmax(-1) == spike).all())
+        torch.testing.assert_close(out.double(), ref, **tol(dtype))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

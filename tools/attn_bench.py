@@ -32,7 +32,10 @@ def main():
     hipvg.lib()
     H = 16
     D = H * 64
-    for (B, T) in [(8, 250), (8, 500), (8, 1000), (16, 1000), (4, 2000), (8, 2000)]:
+    shapes = [(8, 250), (8, 500), (8, 1000), (16, 1000), (4, 2000), (8, 2000)]
+    if os.environ.get("SHAPES"):          # e.g. SHAPES=16x1000,8x2000
+        shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(",")]
+    for (B, T) in shapes:
         g = torch.Generator(device="cpu").manual_seed(0)
         qkv = torch.randn(B * T, 3 * D, generator=g).to(dev).bfloat16()
         dout = torch.randn(B * T, D, generator=g).to(dev).bfloat16()

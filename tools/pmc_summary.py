@@ -93,8 +93,28 @@ def mfma(directory):
             "bf16_gemm_family_mfma_busy_share": fam_b / max(fam_a, 1), "kernels": rows[:40]}
 
 
+def sq(directory, counters):
+    """Per kernel: each SQ counter summed over the launches, as a share of SQ_WAVE_CYCLES where that makes sense."""
+    data = {c: read(directory, c) for c in counters}
+    base = data.get("SQ_WAVE_CYCLES") or next(iter(data.values()))
+    rows = []
+    for key in sorted(base, key=lambda k: -sum(base[k])):
+        wc = sum(base[key])
+        row = {"kernel": short(key[0])[:90], "grid_threads": key[1], "launches": len(base[key])}
+        for c in counters:
+            v = sum(data[c].get(key, [0.0]))
+            row[c] = v
+            if c != "SQ_WAVE_CYCLES" and wc > 0:
+                row[c + "/WAVE_CYCLES"] = round(v / wc, 4)
+        rows.append(row)
+    return {"note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES counts cycles "
+                    "(MI355X_MICROARCH.md, cycle constants)", "kernels": rows[:30]}
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] == "traffic":
+    if len(sys.argv) >= 4 and sys.argv[1] == "sq":
+        json.dump(sq(sys.argv[2], sys.argv[3].split(",")), sys.stdout, indent=1)
+    elif len(sys.argv) >= 4 and sys.argv[1] == "traffic":
         json.dump(traffic(sys.argv[2], sys.argv[3]), sys.stdout, indent=1)
     elif len(sys.argv) >= 3 and sys.argv[1] == "mfma":
         json.dump(mfma(sys.argv[2]), sys.stdout, indent=1)

@@ -147,17 +147,23 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
   }
 }
 
-// one block of 4 waves per (b, h): append this step's k/v, then softmax(q.k/8 - slope (n-1-j)) v over
-// the cache; the 256 lanes stride over the cached frames (few dependent iterations per lane), partial
-// (max, sum, weighted value) triples meet in LDS
+// one block of 4 waves per (b, h): append this step's k/v rows to the cache at pos[b], then
+// softmax(q.k / 8 - slope (n - 1 - j)) v over the n = pos[b] + 1 cached frames.
+//  lanes = 8 cached frames x 8 chunks of 8 head channels: one wave-instruction reads 8 whole 128-byte cache rows
+//  (16 bytes per lane), a score is 8 FMAs per lane + 3 shuffles over the chunk lanes, and the weighted value sum
+//  keeps 8 channels per lane and folds the 8 frame lanes once at the end.  Two passes (scores to LDS, exact max
+//  and sum, then the value sum): the softmax is the plain one, not an online rescaling chain.
+//  dynamic LDS: Tmax scores + 4 x 64 partial outputs + 8 reduction words
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
                                                                  T* __restrict__ vc, T* __restrict__ out,
                                                                  const float* __restrict__ slopes,
                                                                  const int* __restrict__ pos, int Tmax, int H) {
   constexpr int DH = 64;
-  __shared__ float red[4][DH][65];      // [wave][d][lane] (+1: conflict-free column sums)
-  __shared__ float wl[4], wm[4];
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* sc = dsm;                       // [Tmax] scores, then probabilities
+  float* part = dsm + Tmax;              // [4][64] per-wave value sums
+  float* red = part + 4 * DH;            // [8] block reductions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x, b = blockIdx.y;
   const int D = H * DH;
   const int p0 = min(pos[b], Tmax - 1);
@@ -169,54 +175,72 @@ __global__ __launch_bounds__(256) void attn_decode_append_kernel(const T* __rest
   }
   __syncthreads();                                  // the new cache rows are visible to the whole block
   const int n = p0 + 1;
-  float qv[DH];
+  const int sub = lane >> 3, ch = lane & 7;         // cached frame inside a group of 8, channel chunk
+  float q8[8];
+  Ld8<T>::get(row + ch * 8, q8);
 #pragma unroll
-  for (int d = 0; d < DH; ++d) qv[d] = to_f32<T>(row[d]);
+  for (int e = 0; e < 8; ++e) q8[e] *= 0.125f;
   const float slope = slopes[h];
-  float m = -INFINITY, l = 0.f, acc[DH];
-#pragma unroll
-  for (int d = 0; d < DH; ++d) acc[d] = 0.f;
-  for (int j = tid; j < n; j += 256) {
-    const T* kr = kc + cbase + (long)j * D;
-    const T* vr = vc + cbase + (long)j * D;
+  // ---- scores
+  float mloc = -INFINITY;
+  for (int j0 = wave * 8; j0 < n; j0 += 32) {
+    const int j = j0 + sub;
     float s = 0.f;
+    if (j < n) {
+      float k8[8];
+      Ld8<T>::get(kc + cbase + (long)j * D + ch * 8, k8);
 #pragma unroll
-    for (int d = 0; d < DH; ++d) s += qv[d] * to_f32<T>(kr[d]);
-    s = s * 0.125f - slope * (float)(n - 1 - j);
-    const float mn = fmaxf(m, s);
-    const float a = expf(m - mn), pw = expf(s - mn);
-    l = l * a + pw;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) acc[d] = acc[d] * a + pw * to_f32<T>(vr[d]);
-    m = mn;
-  }
-  const float mg = wave_max(m);
-  const float wgt = (m == -INFINITY) ? 0.f : expf(m - mg);
-  const float lg = wave_sum(l * wgt);
-#pragma unroll
-  for (int d = 0; d < DH; ++d) red[wave][d][lane] = acc[d] * wgt;
-  if (lane == 0) {
-    wl[wave] = lg;
-    wm[wave] = mg;
-  }
-  __syncthreads();
-  // thread (wave, lane = d): sum its wave's 64 partial values of dimension d, then merge the 4 waves
-  float o = 0.f;
-  for (int r = 0; r < 64; ++r) o += red[wave][lane][r];
-  __syncthreads();
-  red[wave][0][lane] = o;
-  __syncthreads();
-  if (wave == 0) {
-    const float M4 = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    float num = 0.f, den = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float f = (wm[w] == -INFINITY) ? 0.f : expf(wm[w] - M4);
-      num += red[w][0][lane] * f;
-      den += wl[w] * f;
+      for (int e = 0; e < 8; ++e) s = fmaf(q8[e], k8[e], s);
     }
-    out[(long)b * D + h * DH + lane] = from_f32<T>(num / den);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (j < n) {
+      s -= slope * (float)(n - 1 - j);
+      if (ch == 0) sc[j] = s;
+      mloc = fmaxf(mloc, s);
+    }
   }
+  mloc = wave_max(mloc);
+  if (lane == 0) red[wave] = mloc;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  // ---- probabilities and their sum
+  float lsum = 0.f;
+  for (int j = tid; j < n; j += 256) {
+    const float pj = expf(sc[j] - mx);
+    sc[j] = pj;
+    lsum += pj;
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[4 + wave] = lsum;
+  __syncthreads();
+  const float den = red[4] + red[5] + red[6] + red[7];
+  // ---- weighted value sum
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = wave * 8; j0 < n; j0 += 32) {
+    const int j = j0 + sub;
+    if (j < n) {
+      const float pj = sc[j];
+      float v8[8];
+      Ld8<T>::get(vc + cbase + (long)j * D + ch * 8, v8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, v8[e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] += __shfl_xor(acc[e], 8, 64);
+    acc[e] += __shfl_xor(acc[e], 16, 64);
+    acc[e] += __shfl_xor(acc[e], 32, 64);
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave * DH + ch * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < DH)
+    out[(long)b * D + h * DH + tid] = from_f32<T>((part[tid] + part[DH + tid] + part[2 * DH + tid] + part[3 * DH + tid]) / den);
 }
 
 // frame embedding of the step: out[b][c] = E[id_b][c] + relu(Wf[c][:] . z_b + bf[c])   (one wave per
@@ -320,13 +344,20 @@ extern "C" int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache
                                      const int32_t* pos, int B, int Tmax, int H, int dtype, hipStream_t stream) {
   VG_REQUIRE(B > 0 && Tmax > 0 && H > 0, "vg_attn_decode_append: empty problem");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_decode_append: bad dtype %d", dtype);
+  VG_REQUIRE(Tmax <= 32000, "vg_attn_decode_append: Tmax = %d frames exceed the score buffer (32000)", Tmax);
   dim3 grid(H, B);
-  if (dtype == VG_BF16)
-    attn_decode_append_kernel<bf16_t><<<grid, dim3(256), 0, stream>>>((const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
-                                                                    (bf16_t*)out, slopes, pos, Tmax, H);
-  else
-    attn_decode_append_kernel<float><<<grid, dim3(256), 0, stream>>>((const float*)qkv, (float*)kcache, (float*)vcache,
-                                                                   (float*)out, slopes, pos, Tmax, H);
+  const size_t lds = ((size_t)Tmax + 4 * 64 + 8) * sizeof(float);
+  if (dtype == VG_BF16) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_append_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    attn_decode_append_kernel<bf16_t><<<grid, dim3(256), lds, stream>>>((const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+                                                                      (bf16_t*)out, slopes, pos, Tmax, H);
+  } else {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_append_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    attn_decode_append_kernel<float><<<grid, dim3(256), lds, stream>>>((const float*)qkv, (float*)kcache, (float*)vcache,
+                                                                     (float*)out, slopes, pos, Tmax, H);
+  }
   return vg_host::check_launch("vg_attn_decode_append");
 }
 
