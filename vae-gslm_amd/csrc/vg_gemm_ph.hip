@@ -103,13 +103,18 @@ struct BlockReader {
 };
 
 // What a block needs to know about its tile: origin, K range, operand windows, per-lane piece offsets.
+// The operand windows are kept as RUNNING scalars (base pointer and bytes left of K tile `tcur`, moved by advance()
+// once per K tile): a request is then a descriptor of four ready words plus the M0 write -- recomputing the window
+// from the tile index cost ~16 scalar instructions per request, eight requests per wave and K tile, inside segments
+// whose length is what bounds the loop.
 template <bool A_TR, bool B_TR>
 struct TileCtx {
   int m0, n0, wg, nwg, nkt;
-  long a_bytes, b_bytes, a_step, b_step, a_first, b_first;
+  int a_step, b_step;          // bytes from one K tile to the next
+  int a_left, b_left;          // bytes from the window base of K tile `tcur` to the end of the operand (may go <= 0)
+  const char* a_cur;
+  const char* b_cur;
   unsigned va[2][2], vb[2][2];
-  const char* A;
-  const char* B;
 
   // `tile` = this block's tile index before the XCD-aware remap, `z` = its K slice
   VG_DEVICE void init(const GemmParams& p, int tile, int z, int wave, int lane) {
@@ -136,26 +141,35 @@ struct TileCtx {
     nkt = ntiles;                      // whole K tiles only (the host checks)
     // The descriptor base advances with the K tile and its size shrinks by the same amount, so the hardware range
     // check stays exact (rows past M / N and k-rows past K read zeros) and the per-lane offsets never change.
+    // The host guarantees that both operands span less than 2^31 bytes.
     const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
-    a_bytes = A_TR ? (long)(p.K - 1) * lda_b + (long)p.M * 2 : (long)(p.M - 1) * lda_b + (long)p.K * 2;
-    b_bytes = B_TR ? (long)(p.K - 1) * ldb_b + (long)p.N * 2 : (long)(p.N - 1) * ldb_b + (long)p.K * 2;
-    a_step = A_TR ? (long)BK * lda_b : (long)BK * 2;
-    b_step = B_TR ? (long)BK * ldb_b : (long)BK * 2;
-    a_first = A_TR ? (long)kbeg * lda_b : (long)kbeg * 2;
-    b_first = B_TR ? (long)kbeg * ldb_b : (long)kbeg * 2;
+    const long a_bytes = A_TR ? (long)(p.K - 1) * lda_b + (long)p.M * 2 : (long)(p.M - 1) * lda_b + (long)p.K * 2;
+    const long b_bytes = B_TR ? (long)(p.K - 1) * ldb_b + (long)p.N * 2 : (long)(p.N - 1) * ldb_b + (long)p.K * 2;
+    a_step = (int)(A_TR ? (long)BK * lda_b : (long)BK * 2);
+    b_step = (int)(B_TR ? (long)BK * ldb_b : (long)BK * 2);
+    const long a_first = A_TR ? (long)kbeg * lda_b : (long)kbeg * 2, b_first = B_TR ? (long)kbeg * ldb_b : (long)kbeg * 2;
+    a_cur = reinterpret_cast<const char*>(p.A) + a_first;
+    b_cur = reinterpret_cast<const char*>(p.B) + b_first;
+    a_left = (int)(a_bytes - a_first);
+    b_left = (int)(b_bytes - b_first);
     piece_offsets<A_TR>(va, lda_b, m0, wave, lane);
     piece_offsets<B_TR>(vb, ldb_b, n0, wave, lane);
-    A = reinterpret_cast<const char*>(p.A);
-    B = reinterpret_cast<const char*>(p.B);
   }
-  // image (t, h) -> `dst` (this wave's first piece of the slot)
-  VG_DEVICE void request(int t, int h, char* dst) const {
+  // move the windows by `n` K tiles
+  VG_DEVICE void advance(int n = 1) {
+    a_cur += (long)n * a_step;
+    b_cur += (long)n * b_step;
+    a_left -= n * a_step;
+    b_left -= n * b_step;
+  }
+  // image h of the K tile `back` tiles before the current windows -> `dst` (this wave's first piece of the slot)
+  VG_DEVICE void request(int h, char* dst, int back = 0) const {
     const bool is_a = h & 1;
     const int half = h >> 1;
-    const long adv = (is_a ? a_first : b_first) + (long)t * (is_a ? a_step : b_step);
-    const long left = (is_a ? a_bytes : b_bytes) - adv;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((is_a ? A : B) + adv), 0,
-                                                                  (int)max(0L, min(left, 0x7fffffffL)), 0x00020000);
+    const int step = is_a ? a_step : b_step;
+    const char* base = (is_a ? a_cur : b_cur) - (long)back * step;
+    const int left = (is_a ? a_left : b_left) + back * step;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, max(left, 0), 0x00020000);
     const unsigned o0 = is_a ? va[half][0] : vb[half][0], o1 = is_a ? va[half][1] : vb[half][1];
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst), 16, o0, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst + 8 * 1024), 16, o1, 0, 0, 0);
@@ -185,7 +199,7 @@ VG_DEVICE void phase_barrier() {
 //   phase k + 1, i.e. images <= k + 3.  Image (t, h) lives in slot (t & 1, h); its successor is requested >= 1
 //   interval after the last interval that reads the slot, behind the barrier every reader has passed.
 template <bool A_TR, bool B_TR>
-VG_DEVICE void px_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
+VG_DEVICE void px_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
   const int wr = wave >> 2, wc = wave & 3;
   BlockReader<A_TR, 4> rda;
   BlockReader<B_TR, 2> rdb;
@@ -193,7 +207,8 @@ VG_DEVICE void px_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], ch
   rdb.init(wc * 32, lane);
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
   const int nkt = c.nkt;
-  auto request = [&](int t, int h) { c.request(t, h, smem + (t & 1) * BUF_BYTES + h * HALF_BYTES + wave * 1024); };
+  // the windows of `c` stand at K tile t + 2 inside the loop (`back` = 1 reaches K tile t + 1)
+  auto request = [&](int t, int h, int back) { c.request(h, smem + (t & 1) * BUF_BYTES + h * HALF_BYTES + wave * 1024, back); };
   auto reads = [&](auto phc, const char* buf) {
     constexpr int PH = decltype(phc)::value;
     if constexpr (PH == 0) {
@@ -235,8 +250,8 @@ VG_DEVICE void px_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], ch
   // request of interval k = 4 t + PH: image k + 7 = (K tile t + 1, h = 3) for PH = 0, (t + 2, h = PH - 1) else
   auto req = [&](auto phc, int t) {
     constexpr int PH = decltype(phc)::value;
-    if constexpr (PH == 0) request(t + 1, 3);
-    else request(t + 2, PH - 1);
+    if constexpr (PH == 0) request(t + 1, 3, 1);
+    else request(t + 2, PH - 1, 0);
   };
   auto close = [&]() {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -245,7 +260,11 @@ VG_DEVICE void px_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], ch
 
   // ---- prologue: images 0..6; images 0 and 1 visible at the first barrier, image 2 at the second
 #pragma unroll
-  for (int s = 0; s < 7; ++s) request(s >> 2, s & 3);
+  for (int s = 0; s < 4; ++s) request(0, s, 0);
+  c.advance();
+#pragma unroll
+  for (int s = 0; s < 3; ++s) request(1, s, 0);
+  c.advance();                     // windows at K tile 2 = t + 2 for the first loop iteration
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   phase_barrier();
   if (wr == 0) {
@@ -259,6 +278,7 @@ VG_DEVICE void px_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], ch
       mfmas(P1{}); __builtin_amdgcn_sched_barrier(0); reads(P2{}, buf); req(P1{}, t); close();
       mfmas(P2{}); __builtin_amdgcn_sched_barrier(0); req(P2{}, t); close();
       mfmas(P3{}); __builtin_amdgcn_sched_barrier(0); reads(P0{}, nxt); req(P3{}, t); close();
+      c.advance();
     }
   } else {
     // ------------------------------------------------ group Y: the fragments of phase k, then MFMA_k
@@ -269,6 +289,7 @@ VG_DEVICE void px_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], ch
       reads(P1{}, buf); req(P1{}, t); __builtin_amdgcn_sched_barrier(0); mfmas(P1{}); close();
       reads(P2{}, buf); req(P2{}, t); __builtin_amdgcn_sched_barrier(0); mfmas(P2{}); close();
       req(P3{}, t); __builtin_amdgcn_sched_barrier(0); mfmas(P3{}); close();
+      c.advance();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
@@ -286,7 +307,7 @@ VG_DEVICE void px_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], ch
 // With k-major operands every fragment is two transposing LDS reads: their read segments are twice as long as a
 // row image's, and keeping the LDS-DMA requests out of them is what makes this schedule the faster one there.
 template <bool A_TR, bool B_TR>
-VG_DEVICE void ring_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
+VG_DEVICE void ring_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
   constexpr int NSLOT = 10;
   const int wr = wave >> 2, wc = wave & 3;
   BlockReader<A_TR, 4> rda;
@@ -295,12 +316,17 @@ VG_DEVICE void ring_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], 
   rdb.init(wc * 32, lane);
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
   const int nkt = c.nkt;
-  auto request = [&](int t, int h, int slot) { c.request(t, h, smem + slot * HALF_BYTES + wave * 1024); };
+  // requests always address the K tile the windows of `c` stand at (t + 2 inside the loop)
+  auto request = [&](int, int h, int slot) { c.request(h, smem + slot * HALF_BYTES + wave * 1024); };
   auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
 
   // ---- prologue: images 0..7 (K tiles 0 and 1); phase A of tile 0 reads images 0, 1, 2
 #pragma unroll
-  for (int s = 0; s < 8; ++s) request(s >> 2, s & 3, s);
+  for (int s = 0; s < 4; ++s) request(0, s, s);
+  c.advance();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) request(1, s, 4 + s);
+  c.advance();
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   phase_barrier();
   if (wr == 1) phase_barrier();    // second wave group runs half a phase behind the first
@@ -363,6 +389,7 @@ VG_DEVICE void ring_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], 
     phase_barrier();
     rs0 = wrap(rs0 + 4);
     ws0 = wrap(ws0 + 4);
+    c.advance();
   }
   if (wr == 0) phase_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
@@ -379,7 +406,7 @@ VG_DEVICE void ring_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], 
 //   before the closing barrier for what interval k + 1 reads: images <= 2 k + 6 after a phase A (vmcnt(6)),
 //   <= 2 k + 5 after a phase B (vmcnt(8)).
 template <bool A_TR, bool B_TR>
-VG_DEVICE void px2_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
+VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
   constexpr int NSLOT = 10;
   const int wr = wave >> 2, wc = wave & 3;
   BlockReader<A_TR, 4> rda;
@@ -389,7 +416,8 @@ VG_DEVICE void px2_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], c
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
   const int nkt = c.nkt;
   auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
-  auto request = [&](int t, int h, int slot) { c.request(t, h, smem + slot * HALF_BYTES + wave * 1024); };
+  // requests always address the K tile the windows of `c` stand at (t + 2 inside the loop)
+  auto request = [&](int, int h, int slot) { c.request(h, smem + slot * HALF_BYTES + wave * 1024); };
   // fragments of phase A (images in slots s0 = B half 0, s0 + 1 = A half 0, s0 + 2 = B half 1) / phase B (s0 + 3)
   auto reads_a = [&](int s0) {
 #pragma unroll
@@ -442,7 +470,11 @@ VG_DEVICE void px2_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], c
 
   // ---- prologue: images 0..7 (K tiles 0 and 1); images 0..2 visible at the first barrier, image 3 at the second
 #pragma unroll
-  for (int s = 0; s < 8; ++s) request(s >> 2, s & 3, s);
+  for (int s = 0; s < 4; ++s) request(0, s, s);
+  c.advance();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) request(1, s, 4 + s);
+  c.advance();
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   phase_barrier();
   int rs0 = 0, ws0 = 8;            // ring slots of image 4 t and of image 4 t + 8
@@ -456,6 +488,7 @@ VG_DEVICE void px2_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], c
       mfmas(P1{}); __builtin_amdgcn_sched_barrier(0); reads_a(wrap(rs0 + 4)); req(P1{}, t, ws0); close(P1{});
       rs0 = wrap(rs0 + 4);
       ws0 = wrap(ws0 + 4);
+      c.advance();
     }
   } else {
     // ------------------------------------------------ group Y: the fragments of phase k, then MFMA_k
@@ -466,6 +499,7 @@ VG_DEVICE void px2_main_loop(const TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], c
       reads_b(rs0); req(P1{}, t, ws0); __builtin_amdgcn_sched_barrier(0); mfmas(P1{}); close(P1{});
       rs0 = wrap(rs0 + 4);
       ws0 = wrap(ws0 + 4);
+      c.advance();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
