@@ -155,6 +155,36 @@ def test_wgrad_with_fused_bias_gradient(F, dtype, frames):
         torch.testing.assert_close(gb.double(), ref_b + 2.0, **wt)
 
 
+GROUPED_CASES = {
+    # name: [((out features, in features), frames)]   -- frames = the reduction length of that product
+    "layer (192 tiles: heads + tails in lockstep)": [((4096, 1024), 2048), ((1024, 4096), 2048), ((3072, 1024), 2048),
+                                                     ((1024, 1024), 2048)],
+    "three whole rounds": [((8192, 4096), 1024), ((4096, 4096), 1024)],
+    "two rounds and 22 tiles left": [((8192, 4096), 1024), ((1024, 1024), 1024), ((520, 768), 1024)],
+    "mixed reduction lengths (stream plan)": [((4096, 1024), 2048), ((1024, 4096), 1024), ((3072, 1024), 1088)],
+    "ragged tile edges": [((2000, 1016), 1024), ((3072, 1024), 1024), ((1000, 2040), 1024)],
+}
+
+
+@pytest.mark.parametrize("case", list(GROUPED_CASES))
+def test_grouped_weight_gradients_exact(F, case):
+    """vg_gemm_grouped (one persistent launch for the weight gradients of one backward node): small-integer operands,
+    gradients that already hold a value, so every (tile, K range) segment must be added exactly once -- plain
+    accumulate for whole-K segments, fp32 atomics for the head / tail pieces of either work plan."""
+    g = torch.Generator().manual_seed(11)
+    items, refs = [], []
+    for (N, K), frames in GROUPED_CASES[case]:
+        w = torch.nn.Parameter(torch.zeros(N, K, device=dev()))
+        w.grad = torch.randint(-3, 4, (N, K), generator=g).float().to(dev())
+        dy = torch.randint(-2, 3, (frames, N), generator=g).float().to(dev()).bfloat16()
+        x = torch.randint(-2, 3, (frames, K), generator=g).float().to(dev()).bfloat16()
+        refs.append(w.grad.double() + dy.double().T @ x.double())
+        items.append((w, dy, x))
+    F.sink_wgrad_group(items)
+    for (w, _, _), ref in zip(items, refs):
+        assert torch.equal(w.grad.double(), ref)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_and_ffn_autograd(F, dtype):
     B_, T, D, Fd = 2, 75, 256, 512

@@ -72,10 +72,15 @@ def check():
         print(f"cfg {cfg} epilogue (bias, GELU + derivative, residual, mask) bitwise equal to cfg 3: {same}; colpart diff {cp:g}")
         bad += not same
     # grouped weight gradients (vg_gemm_grouped): exact integers, accumulation into non-zero gradients
-    for Mf in (1024, 16000):
-        shapes = [(4096, 1024), (1024, 4096), (3072, 1024), (1024, 1024)]
+    layer = [(4096, 1024), (1024, 4096), (3072, 1024), (1024, 1024)]
+    scenarios = [("layer M=1024", [(s, 1024) for s in layer]), ("layer M=16000", [(s, 16000) for s in layer]),
+                 ("3 full rounds", [((8192, 4096), 1024), ((4096, 4096), 1024)]),
+                 ("2 rounds + 22 left", [((8192, 4096), 1024), ((1024, 1024), 1024), ((520, 768), 1024)]),
+                 ("mixed K (stream)", [((4096, 1024), 2048), ((1024, 4096), 1024), ((3072, 1024), 1088)]),
+                 ("100 ragged tiles", [((2000, 1016), 4096), ((3072, 1024), 4096), ((1000, 2040), 4096)])]
+    for name, probs in scenarios:
         items, refs = [], []
-        for N, K in shapes:
+        for (N, K), Mf in probs:
             w = torch.nn.Parameter(torch.zeros(N, K, device=dev))
             w.grad = ints((N, K), g).to(dev)
             dy, x = ints((Mf, N), g, -2, 3).to(dev).bfloat16(), ints((Mf, K), g, -2, 3).to(dev).bfloat16()
@@ -83,7 +88,7 @@ def check():
             items.append((w, dy, x))
         F.sink_wgrad_group(items)
         err = max((it[0].grad.double() - r).abs().max().item() for it, r in zip(items, refs))
-        print(f"grouped wgrad M={Mf}: max err {err:g} {'ok' if err == 0 else 'FAIL'}", flush=True)
+        print(f"grouped wgrad {name}: max err {err:g} {'ok' if err == 0 else 'FAIL'}", flush=True)
         bad += err != 0
     print("CHECK", "PASSED" if bad == 0 else f"FAILED ({bad})", flush=True)
     return bad == 0
@@ -142,6 +147,8 @@ def bench():
             ts.append(a.elapsed_time(b) / R * 1e-3)
         t = sorted(ts)[len(ts) // 2]
         print(f"{name:40s} {t * 1e6:7.1f} us {2.0 * M * 12 * D * D / t / 1e12:6.0f} TF", flush=True)
+    if os.environ.get("BENCH") == "group":
+        return
     for name, (flop, fn) in cases.items():
         res = {c: [] for c in cfgs}
         for c in cfgs:

@@ -119,10 +119,12 @@ struct TileCtx {
   // `tile` = this block's tile index before the XCD-aware remap, `z` = its K slice
   VG_DEVICE void init(const GemmParams& p, int tile, int z, int wave, int lane) {
     const int kbeg = z * p.k_per_split;
-    init_range(p, tile, kbeg, (min(p.K, kbeg + p.k_per_split) - kbeg) / BK, true, wave, lane);
+    init_range(p, tile, kbeg, (min(p.K, kbeg + p.k_per_split) - kbeg) / BK, 1, wave, lane);
   }
-  // K tiles [kbeg / 64, kbeg / 64 + ntiles) of output tile `tile` (`remap`: apply the XCD-aware tile order)
-  VG_DEVICE void init_range(const GemmParams& p, int tile, int kbeg, int ntiles, bool remap, int wave, int lane) {
+  // K tiles [kbeg / 64, kbeg / 64 + ntiles) of output tile `tile`; order 1: apply the XCD-aware tile order of a plain
+  // launch, 0: tile = mt * ntn + nt, 2: the same line walked along the shorter of the two tile dimensions
+  VG_DEVICE void init_range(const GemmParams& p, int tile, int kbeg, int ntiles, int order, int wave, int lane) {
+    const bool remap = order == 1;
     constexpr int BM = 256, BN = 256;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     nwg = ntn * ntm;
@@ -130,6 +132,10 @@ struct TileCtx {
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = tile & 7;
     wg = remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3) : tile;
     int mt = wg / ntn, nt = wg % ntn;
+    if (order == 2 && ntm < ntn) {
+      nt = wg / ntm;
+      mt = wg - nt * ntm;
+    }
     if (remap && p.group_m > 0) {    // ... walked m-fastest inside bands of group_m row-tiles (fewer distinct operand panels per XCD)
       const int gsz = p.group_m * ntn, gid = wg / gsz, first = gid * p.group_m;
       const int gm = min(ntm - first, p.group_m), rem = wg - gid * gsz;
@@ -533,16 +539,113 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
 // Written for the weight gradients of a Transformer layer: dW1, dW2, dWqkv, dWo are 64 + 64 + 48 + 16 output tiles of
 // 256x256 whose reduction runs over all M frames (250 K tiles at M = 16000).  Launched one by one each needs split-K
 // to fill the chip (x4, x4, x5, x10), whose equal slices all reach their fp32 atomics together (67 MB for dW1 alone
-// at the memory side's 1.3 TB/s); launched as whole tiles they are 192 equal blocks for 256 CUs.  Here the
-// (tile, K tile) pairs of all problems form one line of work that is cut into 256 EQUAL ranges (stream-K): a block
-// walks its range, finishing one tile and starting the next; a segment that covers a tile's whole K adds to the
-// gradient with plain 16-byte accesses, a partial one with fp32 atomics.  Every CU gets the same number of K
-// tiles, and the segment ends -- hence the atomic bursts -- fall at a different time on every CU.
+// at the memory side's 1.3 TB/s); launched as whole tiles they are 192 equal blocks for 256 CUs.  Here every CU gets
+// the same number of (tile, K tile) units; a segment that covers a tile's whole K adds to the gradient with plain
+// 16-byte accesses, a partial one with fp32 atomics.
+//
+// Two ways of cutting the work:
+//  * stream (plan.lockstep = 0): the units of all problems form one line that is cut into equal ranges; a block
+//    walks its range, finishing one tile and starting the next.  Any mix of K extents.  The blocks of an XCD stand
+//    at unrelated K offsets of unrelated tiles, so every block streams its own two operand panels from HBM
+//    (measured: 2.08 GB fetched per layer for 0.53 GB of operands; 381 us).
+//  * lockstep (all problems share K): tiles are dealt to XCDs in runs that are compact rectangles of the output
+//    (walked along the problem's shorter tile dimension).  Whole rounds of one tile per block first; of the R < P
+//    tiles left over, XCD x owns T_x and its 32 blocks split into T_x "head" blocks, which reduce K tiles
+//    [0, kh) of one tile each, and 32 - T_x "tail" blocks, which share the K tiles [kh, nkt) of those same tiles
+//    (kh = T_x nkt / 32 gives everyone the same number of units -- plus `epi` K tiles per epilogue a tail block ends
+//    beyond the first; tail block j takes tiles j, j + n_tail, ... when that divides).  All head blocks start at K tile 0 together and all tail blocks at kh, so at any moment the
+//    blocks of an XCD read the SAME K slice of a few dY / X panels: one HBM fetch serves a whole row / column of
+//    the rectangle out of that XCD's L2 (6 x 4 heads + 2 x 4 tails: 16 panel slices per 32 units instead of 64;
+//    measured 0.81 GB fetched per layer, 339 us).
+struct GroupPlan {
+  int lockstep;
+  int rounds;                       // whole rounds of one full-K tile per block
+  int first[9];                     // XCD x owns leftover tiles [first[x], first[x + 1]) of the tile line
+  int epi;                          // what one segment's epilogue costs a block, in K tiles (balances heads and tails)
+};
 struct GroupParams {
   GemmParams p[VG_GROUP_MAX];
   int unit0[VG_GROUP_MAX + 1];      // first work unit (one K tile of one output tile) of problem g; [n] = total
+  int tile0[VG_GROUP_MAX + 1];      // first tile of problem g on the tile line
   int nkt[VG_GROUP_MAX];            // K tiles per output tile
   int n;
+  GroupPlan plan;
+};
+
+// the next segment of this block: problem g, tile (problem-local), first K tile, K tile count; false when done
+struct GroupWalk {
+  int stage, u, uend;               // stream: unit cursor; lockstep: stage = rounds done (+1 head done), tail cursor
+  int xcd, slot, per;
+  int kh, ktail, tx, ntail;
+  VG_DEVICE void init(const GroupParams& gp) {
+    const int P = gridDim.x;
+    per = P >> 3;
+    xcd = blockIdx.x & 7;
+    slot = blockIdx.x >> 3;
+    stage = 0;
+    if (!gp.plan.lockstep) {
+      const int r8 = P & 7;
+      const int b = (xcd < r8 ? xcd * (per + 1) : r8 * (per + 1) + (xcd - r8) * per) + slot;
+      const long total = gp.unit0[gp.n];
+      u = (int)(total * b / P);
+      uend = (int)(total * (b + 1) / P);
+    } else {
+      const int nkt = gp.nkt[0];
+      tx = gp.plan.first[xcd + 1] - gp.plan.first[xcd];
+      ntail = per - tx;
+      kh = ntail > 0 ? min(nkt, (int)(((long)tx * nkt + (long)max(tx - ntail, 0) * gp.plan.epi) / per)) : nkt;
+      ktail = nkt - kh;
+      u = uend = 0;
+      if (slot >= tx && ntail > 0) {
+        const long U = (long)tx * ktail;
+        const int j = slot - tx;
+        u = (int)(U * j / ntail);
+        uend = (int)(U * (j + 1) / ntail);
+      }
+    }
+  }
+  VG_DEVICE bool next(const GroupParams& gp, int& g, int& tile, int& kt, int& count) {
+    int line;                       // index on the tile line (lockstep) / unit line (stream)
+    if (!gp.plan.lockstep) {
+      if (u >= uend) return false;
+      g = 0;
+#pragma unroll
+      for (int i = 1; i < VG_GROUP_MAX; ++i)
+        if (i < gp.n && u >= gp.unit0[i]) g = i;
+      const int nkt = gp.nkt[g], local = u - gp.unit0[g];
+      tile = local / nkt;
+      kt = local - tile * nkt;
+      count = min(nkt - kt, uend - u);
+      u += count;
+      return true;
+    }
+    if (stage < gp.plan.rounds) {
+      line = stage * (per * 8) + xcd * per + slot;
+      kt = 0;
+      count = gp.nkt[0];
+      ++stage;
+    } else if (stage == gp.plan.rounds && slot < tx) {
+      ++stage;
+      if (kh == 0) return false;
+      line = gp.plan.first[xcd] + slot;
+      kt = 0;
+      count = kh;
+    } else {
+      if (u >= uend) return false;
+      const int q = u / ktail, off = u - q * ktail;
+      count = min(ktail - off, uend - u);
+      kt = kh + off;
+      const int c = tx / ntail;
+      line = gp.plan.first[xcd] + (tx % ntail == 0 ? (q % c) * ntail + q / c : q);
+      u += count;
+    }
+    g = 0;
+#pragma unroll
+    for (int i = 1; i < VG_GROUP_MAX; ++i)
+      if (i < gp.n && line >= gp.tile0[i]) g = i;
+    tile = line - gp.tile0[g];
+    return true;
+  }
 };
 
 template <bool A_TR, bool B_TR>
@@ -550,30 +653,17 @@ __global__ __launch_bounds__(512) void gemm_ring_group_kernel(GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // blocks that share an XCD (blockIdx % 8 under round-robin placement: speed only) take neighbouring ranges
-  const int P = gridDim.x;
-  const int q8 = P >> 3, r8 = P & 7, xcd = blockIdx.x & 7;
-  const int b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const long total = gp.unit0[gp.n];
-  int u = (int)(total * b / P);
-  const int uend = (int)(total * (b + 1) / P);
-  while (u < uend) {
-    int g = 0;
-#pragma unroll
-    for (int i = 1; i < VG_GROUP_MAX; ++i)
-      if (i < gp.n && u >= gp.unit0[i]) g = i;
+  GroupWalk walk;
+  walk.init(gp);
+  int g, tile, kt, count;
+  while (walk.next(gp, g, tile, kt, count)) {
     const GemmParams& p = gp.p[g];
-    const int nkt = gp.nkt[g];
-    const int local = u - gp.unit0[g];
-    const int tile = local / nkt, kt = local - tile * nkt;
-    const int count = min(nkt - kt, uend - u);
     TileCtx<A_TR, B_TR> c;
-    c.init_range(p, tile, kt * BK, count, false, wave, lane);
+    c.init_range(p, tile, kt * BK, count, gp.plan.lockstep ? 2 : 0, wave, lane);
     f32x4 acc[8][4];
     zero_acc(acc);
     px2_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-    tile_epilogue<256, 256, 2, 4, true>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg, count == nkt ? 1 : 2, 0);
-    u += count;
+    tile_epilogue<256, 256, 2, 4, true>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg, count == gp.nkt[g] ? 1 : 2, 0);
     __syncthreads();               // the strips are read out before the next segment's images land in them
   }
 }
@@ -624,25 +714,60 @@ int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_
   GroupParams gp;
   gp.n = n;
   long units = 0, tiles = 0;
+  bool same_k = true;
   for (int i = 0; i < n; ++i) {
     if (splits[i] != 1) return -1;
     gp.p[i] = ps[i];
     gp.nkt[i] = ps[i].K / BK;
     gp.unit0[i] = (int)units;
+    gp.tile0[i] = (int)tiles;
+    same_k = same_k && gp.nkt[i] == gp.nkt[0];
     const long t = (long)((ps[i].N + 255) / 256) * ((ps[i].M + 255) / 256);
     tiles += t;
     units += t * gp.nkt[i];
     if (units > 0x3fffffffL) return -1;
   }
-  for (int i = n; i <= VG_GROUP_MAX; ++i) gp.unit0[i] = (int)units;
+  for (int i = n; i <= VG_GROUP_MAX; ++i) {
+    gp.unit0[i] = (int)units;
+    gp.tile0[i] = (int)tiles;
+  }
   // one block per CU; fewer when there is less than ~8 K tiles of work for each
   static const int cus = [] {
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int dev = 0, n_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     return n_cu > 0 ? n_cu : 256;
   }();
   const int blocks = (int)max(1L, min((long)cus, units / 8));
-  (void)tiles;
+  // lockstep plan: all problems share K, a full grid, and tails that are not a long string of tiny segments
+  static const int mode = [] {
+    const char* e = getenv("VG_GROUP_PLAN");      // 0 = always stream, 1 = default
+    return e ? atoi(e) : 1;
+  }();
+  gp.plan.lockstep = 0;
+  gp.plan.rounds = 0;
+  // a tail block ends tx / n_tail segments (each an atomic epilogue of ~25 us when 64 blocks end together), a head
+  // block one: the heads take that many more K tiles.  Measured on the layer's four products (M = 16000): 0 -> 362 us,
+  // 10 -> 349, 40 -> 339, 60 -> 361
+  gp.plan.epi = 40;
+  for (int x = 0; x <= 8; ++x) gp.plan.first[x] = 0;
+  if (mode != 0 && same_k && blocks == cus && cus % 8 == 0 && n > 0) {
+    const int per = cus / 8;
+    const int rounds = (int)(tiles / cus), left = (int)(tiles - (long)rounds * cus);
+    bool ok = true;
+    for (int x = 0; x <= 8; ++x) gp.plan.first[x] = rounds * cus + (int)((long)left * x / 8);
+    for (int x = 0; x < 8 && ok; ++x) {
+      const int tx = gp.plan.first[x + 1] - gp.plan.first[x], ntail = per - tx;
+      // a tail block walks tx / ntail tile tails: keep that short (each ends in an atomic epilogue), and every
+      // tail segment long enough to pay for its epilogue
+      if (ntail > 0 && tx > 4 * ntail) ok = false;
+      if (ntail > 0 && tx > 0 && (long)(gp.nkt[0] - (long)tx * gp.nkt[0] / per) < 8) ok = false;
+    }
+    if (ok) {
+      gp.plan.lockstep = 1;
+      gp.plan.rounds = rounds;
+    }
+  }
   constexpr size_t lds = 10 * HALF_BYTES;
   auto k = gemm_ring_group_kernel<true, true>;
   static bool attr_done = false;
