@@ -24,7 +24,7 @@
 //   TN (both k-major, split-K) W1 wgrad 722 / 825-840 / 774-778 / 868              -> complementary, long phases
 // (a first version with two barriers per 16-MFMA phase and the second group one barrier behind reached 1087-1135 /
 // 1069-1084 / 755-765 and was dropped)
-// In-kernel stamps of the complementary loop (tools/lab/ph_stamp.py): an interval is ~650 cycles for 2 x 256 cycles
+// In-kernel stamps of the complementary loop (a diagnostic build of round 2, not kept): an interval is ~650 cycles for 2 x 256 cycles
 // of MFMA issue (79 %), the chip holds ~2.0 GHz under it; entry to first MFMA 2.0 us; the plain bf16 store epilogue
 // of a 256x256 tile takes 8.7 us = 3.8 TB/s over 256 CUs, i.e. it runs at the HBM write rate and only overlapping
 // it with another tile's main loop can hide it.
