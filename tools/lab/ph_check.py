@@ -71,6 +71,43 @@ def check():
         cp = (outs[3][2].sum(0) - outs[cfg][2].sum(0)).abs().max().item()
         print(f"cfg {cfg} epilogue (bias, GELU + derivative, residual, mask) bitwise equal to cfg 3: {same}; colpart diff {cp:g}")
         bad += not same
+        # the lean epilogues of the long-phase schedule (plain / GELU + stored derivative / times stored derivative)
+        M2, N2 = 1003, 520                      # ragged edges; N a multiple of 8
+        A2 = torch.randn(M2, K, generator=g).to(dev).bfloat16()
+        B2 = (torch.randn(N2, K, generator=g) * K ** -0.5).to(dev).bfloat16()
+        bias2 = torch.randn(N2, generator=g).to(dev)
+        res2 = torch.randn(M2, N2, generator=g).to(dev).bfloat16()
+        der2 = torch.randn(M2, N2, generator=g).to(dev).bfloat16()
+        lens2 = torch.tensor([17, 16, 1, 0, 16], dtype=torch.int32, device=dev)       # T = 17 -> 5 sequences = 85 rows
+        variants = {
+            "plain": dict(),
+            "bias + residual + mask + colpart": dict(bias=bias2, residual=res2, lengths=None, colpart=True),
+            "GELU + stored derivative": dict(bias=bias2, act=2 | 16, aux=True),
+            "times stored derivative + colpart": dict(dact=4, aux_in=der2, colpart=True),
+        }
+        for vname, kw in variants.items():
+            for masked in (False, True):
+                Mv = 85 if masked else M2
+                outs = {}
+                for c in (3, cfg):
+                    args = dict(tile_cfg=c)
+                    if "bias" in kw: args["bias"] = kw["bias"]
+                    if "residual" in kw: args["residual"] = kw["residual"][:Mv]
+                    if "act" in kw: args["act"] = kw["act"]
+                    if "dact" in kw: args.update(dact=kw["dact"], aux_in=kw["aux_in"][:Mv].contiguous())
+                    aux = torch.zeros(Mv, N2, device=dev, dtype=torch.bfloat16) if kw.get("aux") else None
+                    if aux is not None: args["aux_out"] = aux
+                    part = [] if kw.get("colpart") else None
+                    if part is not None: args["colpart"] = part
+                    if masked: args.update(lengths=lens2, T=17)
+                    if "residual" in args: args["residual"] = args["residual"].contiguous()
+                    o = F.gemm(A2[:Mv].contiguous(), B2, Mv, N2, K, **args)
+                    outs[c] = (o, aux, part[0] if part else None)
+                same = torch.equal(outs[3][0], outs[cfg][0]) and (outs[3][1] is None or torch.equal(outs[3][1], outs[cfg][1]))
+                cpd = 0.0 if outs[3][2] is None else (outs[3][2].sum(0) - outs[cfg][2].sum(0)).abs().max().item()
+                ok = same and cpd < 1e-2
+                bad += not ok
+                print(f"cfg {cfg} lean epilogue [{vname}{', masked' if masked else ''}]: bitwise {same}, colpart diff {cpd:g} {'ok' if ok else 'FAIL'}")
     # grouped weight gradients (vg_gemm_grouped): exact integers, accumulation into non-zero gradients
     layer = [(4096, 1024), (1024, 4096), (3072, 1024), (1024, 1024)]
     scenarios = [("layer M=1024", [(s, 1024) for s in layer]), ("layer M=16000", [(s, 16000) for s in layer]),

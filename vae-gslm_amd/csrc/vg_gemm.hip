@@ -337,15 +337,11 @@ int pick_cfg(const vg_gemm_desc* d) {
                       (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7ffffff0L;
   if (!dma_ok) return -1;
   if (cfg != 0) return cfg;
-  // Forward / dgrad products: the tile shape with the least estimated time among 128x128 (two blocks per CU),
-  // 256x256 and 192x256 (one block per CU; 192 rows only exist for a row-image A).  A launch runs in rounds of
-  // 256 x blocks-per-CU tiles; a round costs its tile area (a K-step is bound by the operand fill, which scales
-  // with the area a CU works on) times a measured per-shape factor, and a partly filled last round is a little
-  // cheaper (fewer CUs share the memory system).  Calibrated on cold operands at M = 5120 / 8000 / 10240 / 16000
-  // (tools/tile_cold_sweep.py with CFGS=1,3,9; tools/gemm_rotate.py): e.g. the N = 1024 products of the yaml's own
-  // step shape (M = 2 x 8 x 640 = 10240) take 192x256 -- 216 tiles on 256 CUs instead of 160 -- and run 17-20 %
-  // faster than either square tile; M = 16000 keeps 256x256 (252 tiles), M = 8000 keeps 128x128 (504).
-  // Weight gradients: 128x128 + split-K (tools/wgrad_cold_sweep.py).
+  // Forward / dgrad products: the tile shape with the least estimated time.  A launch runs in rounds of
+  // 256 x blocks-per-CU tiles; a round costs its tile area times a measured per-shape factor, a partly filled last
+  // round a little less.  With whole 64-deep K tiles the choice is between 128x128 (two blocks per CU) and the
+  // long-phase 256x256 schedule; other K keep the round-1 model (128x128 / 2-stage 256x256 / 192x256).
+  // Weight gradients: 256x256 once the caller's split fills a good part of the chip, else 128x128 + split-K.
   cfg = 1;
   // phase-pipelined 256x256 kernels (vg_gemm_ph.hip) need whole 64-deep K tiles in every split
   const int splits = d->split_k > 0 ? d->split_k : 1;
@@ -353,19 +349,26 @@ int pick_cfg(const vg_gemm_desc* d) {
   kps = ((kps + 63) / 64) * 64;
   const bool ph_ok = d->K % 64 == 0 && kps % 64 == 0;
   if (!d->a_tr) {
-    auto cost = [&](int rows, int cols, int per_cu, double shape) {
+    auto cost = [&](int rows, int cols, int per_cu, double shape, double part) {
       const long tiles = (long)((d->M + rows - 1) / rows) * ((d->N + cols - 1) / cols), slots = 256L * per_cu;
       const long full = tiles / slots, rem = tiles % slots;
-      const double rounds = (double)full + (rem ? 0.85 + 0.15 * (double)rem / (double)slots : 0.0);
+      const double rounds = (double)full + (rem ? part + (1.0 - part) * (double)rem / (double)slots : 0.0);
       return rounds * rows * cols * per_cu * shape;
     };
     const double longk_pen = 0.10 * fmin(1.0, fmax(0.0, (d->K - 1024) / 3072.0));   // 128x128 falls behind at long K
-    // the phase-pipelined 256x256 loop is 8-35 % faster than the 2-stage one it replaces (tools/lab/ph_check.py)
-    const double f256 = ph_ok ? (d->b_tr ? 0.75 : 0.92) : 1.0;
-    const double c1 = cost(128, 128, 2, 1.08 + longk_pen), c3 = cost(256, 256, 1, f256), c9 = cost(192, 256, 1, 0.97);
-    cfg = c3 <= c1 ? 3 : 1;
-    if (c9 < 0.95 * fmin(c1, c3)) cfg = 9;      // the odd shape must win clearly (model error ~5 %)
-    if (cfg == 3 && ph_ok) cfg = d->b_tr ? 13 : 12;     // NN: complementary schedule with long phases, NT: with short ones
+    if (ph_ok) {
+      // the long-phase 256x256 schedule with the lean epilogues against 128x128 (tools/tile_cold_sweep.py at M = 5120 /
+      // 8000 / 10240 / 16000 / 32000, CFGS=1,9,12,13): it wins wherever its tiles cover about half the CUs or more
+      // (M = 10240: 160 tiles, 25 % faster than 128x128 or 192x256; M = 8000, N = 1024: 128 tiles, a tie; M = 5120,
+      // N = 1024: 80 tiles, 128x128 is 15 % faster).  A partly filled round of one-block-per-CU tiles costs a whole one.
+      const double c1 = cost(128, 128, 2, 1.08 + longk_pen, 0.85), c13 = cost(256, 256, 1, 0.62, 0.93);
+      cfg = c13 <= c1 ? 13 : 1;
+    } else {
+      const double c1 = cost(128, 128, 2, 1.08 + longk_pen, 0.85), c3 = cost(256, 256, 1, 1.0, 0.85),
+                   c9 = cost(192, 256, 1, 0.97, 0.85);
+      cfg = c3 <= c1 ? 3 : 1;
+      if (c9 < 0.95 * fmin(c1, c3)) cfg = 9;      // the odd shape must win clearly (model error ~5 %)
+    }
   } else if (d->b_tr && ph_ok && !d->colsum_out) {
     // weight gradients: 256x256 ring tiles once they can fill a good part of the chip with the caller's split
     const long tiles = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splits;
@@ -436,7 +439,7 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   const int cfg = pick_cfg(d);
   if (splits > 1 && cfg > 0 && d->split_ws != nullptr && d->split_cnt != nullptr) {
     // in-launch reduction of the K slices through fp32 slabs: needs splits * tiles * tile floats of workspace
-    const int rows = cfg_tile_rows(cfg), cols = (cfg == 3 || cfg == 4 || cfg >= 10) ? 256 : 128;
+    const int rows = cfg_tile_rows(cfg), cols = (cfg == 3 || cfg == 4 || (cfg >= 10 && cfg != 14)) ? 256 : 128;
     const long tiles = (long)((d->M + rows - 1) / rows) * ((d->N + cols - 1) / cols);
     if (tiles <= 4096 && tiles * rows * cols * (long)splits <= d->split_ws_floats && d->ldc % 4 == 0 &&
         ((uintptr_t)d->C % 16) == 0) {

@@ -405,7 +405,7 @@ VG_DEVICE void ring_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* 
 // Complementary schedule with long phases (tile_cfg 13): the opposite-order wave groups and the single barrier per
 // phase of px_main_loop, but TWO phases of 32 MFMAs per K tile (a barrier every 2 x 512 MFMA cycles instead of
 // every 2 x 256) on the 10-slot image ring of ring_main_loop:
-//   phase A  reads b0, a0, b1 (16 fragments), MFMA a0 x b0, a0 x b1;   phase B  reads a1 (8), MFMA a1 x b1, a1 x b0
+//   phase A  reads b (the wave's B half), a0 (16 fragments), MFMA a0 x b;   phase B  reads a1 (8), MFMA a1 x b
 //   interval k (one phase): group X issues MFMA_k, then reads the fragments of phase k + 1; group Y reads the
 //   fragments of phase k, then issues MFMA_k.  Both request images 2 k + 8 and 2 k + 9 in their read segment -- the
 //   slots they take (images 2 k - 2, 2 k - 1) were last read by Y in interval k - 1, behind the barrier -- and wait
@@ -415,11 +415,14 @@ template <bool A_TR, bool B_TR>
 VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
   constexpr int NSLOT = 10;
   const int wr = wave >> 2, wc = wave & 3;
+  // this schedule gives a wave 64 CONTIGUOUS columns (all of them inside one B half image): its rows of C are whole
+  // 128-byte lines for the epilogue's stores and for the residual / stored-derivative reads
+  const int bh = (wc >> 1) << 1;   // slot offset of this wave's B half inside a K tile's four images (0 or 2)
   BlockReader<A_TR, 4> rda;
-  BlockReader<B_TR, 2> rdb;
+  BlockReader<B_TR, 4> rdb;
   rda.init(wr * 64, lane);
-  rdb.init(wc * 32, lane);
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  rdb.init((wc & 1) * 64, lane);
+  bf16x8 fa[4][2], fb[4][2];
   const int nkt = c.nkt;
   auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
   // requests always address the K tile the windows of `c` stand at (t + 2 inside the loop)
@@ -427,17 +430,13 @@ VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* s
   // fragments of phase A (images in slots s0 = B half 0, s0 + 1 = A half 0, s0 + 2 = B half 1) / phase B (s0 + 3)
   auto reads_a = [&](int s0) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) fb0[j][s] = rdb.get(smem + s0 * HALF_BYTES, j, s);
+      for (int s = 0; s < 2; ++s) fb[j][s] = rdb.get(smem + wrap(s0 + bh) * HALF_BYTES, j, s);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int s = 0; s < 2; ++s) fa[i][s] = rda.get(smem + wrap(s0 + 1) * HALF_BYTES, i, s);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) fb1[j][s] = rdb.get(smem + wrap(s0 + 2) * HALF_BYTES, j, s);
   };
   auto reads_b = [&](int s0) {
 #pragma unroll
@@ -449,17 +448,12 @@ VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* s
     constexpr int A0 = decltype(halfc)::value * 4;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int b = A0 == 0 ? bb : 1 - bb;          // phase B starts with b1 (b0 stays for the end)
-            acc[A0 + i][2 * b + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], b == 0 ? fb0[j][s] : fb1[j][s],
-                                                                             acc[A0 + i][2 * b + j], 0, 0, 0);
-          }
+        for (int j = 0; j < 4; ++j)
+          acc[A0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], fb[j][s], acc[A0 + i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
   // requests of interval k: images 2 k + 8, 2 k + 9 = K tile t + 2, h = 0, 1 (phase A) / 2, 3 (phase B); ws0 = slot of 4 t + 8
@@ -519,19 +513,226 @@ VG_DEVICE void zero_acc(f32x4 (&acc)[8][4]) {
 }
 
 // SCHED: 0 = complementary (px), 1 = ring, 2 = complementary with long phases (px2)
-template <bool A_TR, bool B_TR, int SCHED>
+#ifdef VG_LAB_STAMPS
+__device__ long long* g_lab_stamps = nullptr;     // diagnostic build only (tools/lab/variant.sh ... -DVG_LAB_STAMPS)
+#endif
+
+template <bool A_TR, bool B_TR, int SCHED, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef VG_LAB_STAMPS
+  long long st0 = wall_clock64();
+#endif
   TileCtx<A_TR, B_TR> c;
   c.init(p, blockIdx.x, blockIdx.z, wave, lane);
-  f32x4 acc[8][4];                 // [a * 4 + i][b * 2 + j]
+  f32x4 acc[8][4];                 // [a * 4 + i][b * 2 + j]; SCHED 2: [a * 4 + i][j]
   zero_acc(acc);
   if constexpr (SCHED == 1) ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
   else if constexpr (SCHED == 2) px2_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
   else px_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-  tile_epilogue<256, 256, 2, 4, true>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
+#ifdef VG_LAB_STAMPS
+  long long st1 = wall_clock64();
+#endif
+  constexpr bool ILVC = SCHED != 2;
+  if constexpr (EPI == EPI_GENERIC) tile_epilogue<256, 256, 2, 4, true, ILVC>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
+  else tile_epilogue_lean<256, 256, 2, 4, true, ILVC, EPI>(p, acc, smem, c.m0, c.n0);
+#ifdef VG_LAB_STAMPS
+  if (g_lab_stamps && tid == 0 && blockIdx.x < 4096) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long* o = g_lab_stamps + blockIdx.x * 8;
+    o[0] = st0; o[1] = st1; o[2] = wall_clock64();
+    o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Two blocks per CU (tile_cfg 14): 256x128x64 tile, 4 waves as 2 x 2 (one per SIMD), 80 KB of LDS, <= 256 VGPRs.
+// Why.  With one 8-wave block per CU nothing runs on the matrix pipe while that block fills its ring (2-3 us) or
+// writes its tile out (9 us plain, ~20 us with the GELU epilogue): at K = 1024 (22 us of main loop per tile) that is
+// half of the launch.  Two INDEPENDENT blocks per CU -- each SIMD holds one wave of each -- fall out of step by
+// themselves: one block's prologue, epilogue VALU work and store drain run under the other's MFMAs, and inside the
+// main loops one wave's fragment reads and LDS-DMA issue run under its partner's MFMAs (what the complementary
+// schedules arrange by hand between the two wave groups of one block).
+//   images   3 per K tile, 16 KB each: B (128 columns), A half 0, A half 1 (rows 0..127 / 128..255 of the tile);
+//            image s = 3 t + h lives in slot s mod 5.  Wave (wr, wc) owns rows {wr*64 .. +63} of BOTH A halves and
+//            columns {wc*64 .. +63}: phase A reads B and A half 0 (32 MFMAs), phase B reads A half 1 (32 MFMAs, the B
+//            fragments stay in registers), so an image is dead after its one reading phase.
+//   phase    s_waitcnt vmcnt(8) (all but the two youngest images), ONE s_barrier, the requests whose slots that barrier
+//            freed (phase A: image 3 t + 4; phase B: 3 t + 5 and 3 t + 6), fragment reads, MFMAs.
+//   tails    as above: requests past the last K tile are zero fills of slots nobody reads.
+template <bool TR>
+VG_DEVICE void duo_piece_offsets(unsigned (&voff)[4], long ld_bytes, int rc0, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int piece = j * 4 + wave;
+    if constexpr (!TR) {
+      const int row = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      voff[j] = (unsigned)((long)(rc0 + row) * ld_bytes + chunk * 16);
+    } else {
+      const int krow = piece * 4 + (lane >> 4);
+      const int p16 = lane & 15;
+      const int gran = (p16 >> 2) ^ (krow & 3);
+      const int hf = ((p16 >> 1) & 1) ^ ((krow >> 3) & 1);
+      const int col = gran * 32 + hf * 16 + (p16 & 1) * 8;
+      voff[j] = (unsigned)((long)krow * ld_bytes + (long)(rc0 + col) * 2);
+    }
+  }
+}
+
+template <bool A_TR, bool B_TR>
+struct DuoCtx {
+  int m0, n0, wg, nwg, nkt;
+  int a_step, b_step;          // bytes from one K tile to the next
+  int a_left, b_left;          // bytes from the current window base to the end of the operand (may go <= 0)
+  int a_half;                  // bytes from A half 0 to A half 1
+  const char* a_cur;
+  const char* b_cur;
+  unsigned va[4], vb[4];
+
+  VG_DEVICE void init(const GemmParams& p, int tile, int z, int wave, int lane) {
+    constexpr int BM = 256, BN = 128;
+    const int kbeg = z * p.k_per_split;
+    nkt = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    nwg = ntn * ntm;
+    // blocks that share an XCD get a contiguous run of tiles, walked m-fastest inside bands of group_m row-tiles
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = tile & 7;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+    int mt = wg / ntn, nt = wg % ntn;
+    if (p.group_m > 0) {
+      const int gsz = p.group_m * ntn, gid = wg / gsz, first = gid * p.group_m;
+      const int gm = min(ntm - first, p.group_m), rem = wg - gid * gsz;
+      mt = first + rem % gm;
+      nt = rem / gm;
+    }
+    m0 = mt * BM;
+    n0 = nt * BN;
+    const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+    const long a_bytes = A_TR ? (long)(p.K - 1) * lda_b + (long)p.M * 2 : (long)(p.M - 1) * lda_b + (long)p.K * 2;
+    const long b_bytes = B_TR ? (long)(p.K - 1) * ldb_b + (long)p.N * 2 : (long)(p.N - 1) * ldb_b + (long)p.K * 2;
+    a_step = (int)(A_TR ? (long)BK * lda_b : (long)BK * 2);
+    b_step = (int)(B_TR ? (long)BK * ldb_b : (long)BK * 2);
+    a_half = (int)(A_TR ? 256L : 128L * lda_b);
+    const long a_first = A_TR ? (long)kbeg * lda_b : (long)kbeg * 2, b_first = B_TR ? (long)kbeg * ldb_b : (long)kbeg * 2;
+    a_cur = reinterpret_cast<const char*>(p.A) + a_first;
+    b_cur = reinterpret_cast<const char*>(p.B) + b_first;
+    a_left = (int)(a_bytes - a_first);
+    b_left = (int)(b_bytes - b_first);
+    duo_piece_offsets<A_TR>(va, lda_b, m0, wave, lane);
+    duo_piece_offsets<B_TR>(vb, ldb_b, n0, wave, lane);
+  }
+  VG_DEVICE void advance() {
+    a_cur += a_step;
+    b_cur += b_step;
+    a_left -= a_step;
+    b_left -= b_step;
+  }
+  // image h (0 B, 1 A half 0, 2 A half 1) of the K tile `back` tiles before the current windows -> slot `dst`
+  VG_DEVICE void request(int h, char* dst, int wave, int back = 0) const {
+    const bool is_a = h != 0;
+    const int shift = (is_a ? a_step : b_step) * back - (h == 2 ? a_half : 0);
+    const char* base = (is_a ? a_cur : b_cur) - shift;
+    const int left = (is_a ? a_left : b_left) + shift;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, max(left, 0), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst + (j * 4 + wave) * 1024), 16, is_a ? va[j] : vb[j],
+                                               0, 0, 0);
+  }
+};
+
+template <bool A_TR, bool B_TR>
+VG_DEVICE void duo_main_loop(DuoCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
+  constexpr int NSLOT = 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  BlockReader<A_TR, 4> rda;
+  BlockReader<B_TR, 4> rdb;
+  rda.init(wr * 64, lane);
+  rdb.init(wc * 64, lane);
+  bf16x8 fa[4][2], fb[4][2];
+  auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
+  auto slot = [&](int s) { return smem + s * HALF_BYTES; };
+  auto mfmas = [&](auto halfc) {
+    constexpr int A0 = decltype(halfc)::value * 4;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[A0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], fb[j][s], acc[A0 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // prologue: images 0..3 (K tile 0 and the B image of K tile 1); the windows then stand at K tile t + 2
+  c.request(0, slot(0), wave);
+  c.request(1, slot(1), wave);
+  c.request(2, slot(2), wave);
+  c.advance();
+  c.request(0, slot(3), wave);
+  c.advance();
+  int rs = 0;                      // slot of image 3 t
+  const int nkt = c.nkt;
+  for (int t = 0; t < nkt; ++t) {
+    // ---- phase A: images 3 t (B), 3 t + 1 (A half 0)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    phase_barrier();
+    c.request(1, slot(wrap(rs + 4)), wave, 1);                 // image 3 t + 4: A half 0 of K tile t + 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fb[j][s] = rdb.get(slot(rs), j, s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fa[i][s] = rda.get(slot(wrap(rs + 1)), i, s);
+    mfmas(P0{});
+    // ---- phase B: image 3 t + 2 (A half 1)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    phase_barrier();
+    c.request(2, slot(rs), wave, 1);                           // image 3 t + 5: A half 1 of K tile t + 1
+    c.request(0, slot(wrap(rs + 1)), wave, 0);                 // image 3 t + 6: B of K tile t + 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fa[i][s] = rda.get(slot(wrap(rs + 2)), i, s);
+    mfmas(P1{});
+    rs = wrap(rs + 3);
+    c.advance();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
+}
+
+template <bool A_TR, bool B_TR>
+__global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DuoCtx<A_TR, B_TR> c;
+  c.init(p, blockIdx.x, blockIdx.z, wave, lane);
+  f32x4 acc[8][4];                 // [A half * 4 + i][j]
+  zero_acc(acc);
+  duo_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
+  tile_epilogue<256, 128, 2, 2, true, false>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
+}
+
+template <bool A_TR, bool B_TR>
+int launch_duo(const GemmParams& p, int splits, hipStream_t stream) {
+  constexpr size_t lds = 5 * HALF_BYTES;
+  auto k = gemm_duo_kernel<A_TR, B_TR>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int ntn = (p.N + 127) / 128, ntm = (p.M + 255) / 256;
+  hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(256), lds, stream, p);
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -663,7 +864,7 @@ __global__ __launch_bounds__(512) void gemm_ring_group_kernel(GroupParams gp) {
     f32x4 acc[8][4];
     zero_acc(acc);
     px2_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-    tile_epilogue<256, 256, 2, 4, true>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg, count == gp.nkt[g] ? 1 : 2, 0);
+    tile_epilogue<256, 256, 2, 4, true, false>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg, count == gp.nkt[g] ? 1 : 2, 0);
     __syncthreads();               // the strips are read out before the next segment's images land in them
   }
 }
@@ -673,10 +874,10 @@ void set_lds(K k, size_t lds) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <bool A_TR, bool B_TR, int SCHED>
+template <bool A_TR, bool B_TR, int SCHED, int EPI = EPI_GENERIC>
 int launch_ph(const GemmParams& p, int splits, hipStream_t stream) {
   constexpr size_t lds = SCHED != 0 ? 10 * HALF_BYTES : 2 * BUF_BYTES;
-  auto k = gemm_ph_kernel<A_TR, B_TR, SCHED>;
+  auto k = gemm_ph_kernel<A_TR, B_TR, SCHED, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     set_lds(k, lds);
@@ -685,6 +886,33 @@ int launch_ph(const GemmParams& p, int splits, hipStream_t stream) {
   const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
   hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(512), lds, stream, p);
   return 0;
+}
+
+// which lean epilogue (vg_gemm_tile.h) covers this problem; EPI_GENERIC when none does
+int lean_epilogue_of(const GemmParams& p, int splits) {
+  static const int off = [] { const char* e = getenv("VG_NO_LEAN_EPI"); return e ? atoi(e) : 0; }();
+  if (off) return EPI_GENERIC;
+  if (p.out_f32 || p.accumulate || splits != 1 || p.pre_add || p.alpha != 1.0f || p.split_ws || p.colsum_out) return EPI_GENERIC;
+  if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.lengths != nullptr && p.T < 16)) return EPI_GENERIC;
+  const int act = p.act & 15;
+  const bool save = (p.act & VG_ACT_SAVE_DERIV) != 0;
+  if (act == VG_ACT_NONE && !save && !p.aux_out && p.dact == VG_ACT_NONE) return EPI_PLAIN;
+  if (act == VG_ACT_GELU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE) return EPI_GELU_SAVE;
+  if (act == VG_ACT_NONE && !save && !p.aux_out && p.dact == VG_ACT_STORED && p.aux_in && !p.residual) return EPI_DACT;
+  return EPI_GENERIC;
+}
+
+template <bool A_TR, bool B_TR>
+int launch_px2(const GemmParams& p, int splits, hipStream_t stream) {
+  if constexpr (!A_TR) {           // forward / dgrad products end in bf16 rows; the TN products are fp32 gradients
+    switch (lean_epilogue_of(p, splits)) {
+      case EPI_PLAIN: return launch_ph<A_TR, B_TR, 2, EPI_PLAIN>(p, splits, stream);
+      case EPI_GELU_SAVE: return launch_ph<A_TR, B_TR, 2, EPI_GELU_SAVE>(p, splits, stream);
+      case EPI_DACT: return launch_ph<A_TR, B_TR, 2, EPI_DACT>(p, splits, stream);
+      default: break;
+    }
+  }
+  return launch_ph<A_TR, B_TR, 2>(p, splits, stream);
 }
 
 }  // namespace
@@ -699,10 +927,15 @@ int gemm_ph_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits,
     if (!a_tr && b_tr) return launch_ph<false, true, 0>(p, splits, stream);
     return launch_ph<true, true, 0>(p, splits, stream);
   }
+  if (cfg == 14) {
+    if (!a_tr && !b_tr) return launch_duo<false, false>(p, splits, stream);
+    if (!a_tr && b_tr) return launch_duo<false, true>(p, splits, stream);
+    return launch_duo<true, true>(p, splits, stream);
+  }
   if (cfg == 13) {
-    if (!a_tr && !b_tr) return launch_ph<false, false, 2>(p, splits, stream);
-    if (!a_tr && b_tr) return launch_ph<false, true, 2>(p, splits, stream);
-    return launch_ph<true, true, 2>(p, splits, stream);
+    if (!a_tr && !b_tr) return launch_px2<false, false>(p, splits, stream);
+    if (!a_tr && b_tr) return launch_px2<false, true>(p, splits, stream);
+    return launch_px2<true, true>(p, splits, stream);
   }
   if (!a_tr && !b_tr) return launch_ph<false, false, 1>(p, splits, stream);
   if (!a_tr && b_tr) return launch_ph<false, true, 1>(p, splits, stream);
@@ -779,3 +1012,9 @@ int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_
   return 0;
 }
 }  // namespace vg_host
+
+#ifdef VG_LAB_STAMPS
+extern "C" int vg_lab_set_stamps(long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_stamps), &buf, sizeof(buf));
+}
+#endif

@@ -170,7 +170,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
 // ILV: the wave's rows / columns are two interleaved blocks (gemm_ph_kernel): 16-row band i sits at tile row
 // (i / (TM/2)) * BM/2 + wm * (BM/WM/2) + (i % (TM/2)) * 16, strip column c at tile column
 // (c / (WCOLS/2)) * BN/2 + wn * (WCOLS/2) + c % (WCOLS/2); otherwise one contiguous (BM/WM) x (BN/WN) block.
-template <int BM, int BN, int WM, int WN, bool ILV = false>
+template <int BM, int BN, int WM, int WN, bool ILV = false, bool ILVC = ILV>
 VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0,
                              int wg, int nwg, int nsplit = (int)gridDim.z, int zidx = (int)blockIdx.z) {
   constexpr int NW = WM * WN;
@@ -186,7 +186,7 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
     else return arow + i * 16;
   };
   auto strip_col = [&](int c) {     // tile-local column of strip column c (c a multiple of 8 or of 32)
-    if constexpr (ILV) return (c / (WCOLS / 2)) * (BN / 2) + wn * (WCOLS / 2) + c % (WCOLS / 2);
+    if constexpr (ILVC) return (c / (WCOLS / 2)) * (BN / 2) + wn * (WCOLS / 2) + c % (WCOLS / 2);
     else return bcol + c;
   };
   const bool split = nsplit > 1;
@@ -316,6 +316,168 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
         for (int w2 = 0; w2 < WM; ++w2) t += cred[(w2 * WN + wn) * WCOLS + lane * 8 + e];
         const int n = n0 + strip_col(lane * 8) + e;
         if (n < p.N) p.colpart[(long)(m0 / BM) * p.N + n] = t;
+      }
+    }
+  }
+}
+
+
+// ---- lean epilogues for the three shapes almost every large product of the step ends in.  tile_epilogue above is
+// one body for every option of the C ABI, unrolled over the wave's 8 row bands: ~15,000 instructions, of which a
+// plain bf16 store walks a few thousand -- measured per 256x256 tile (in-kernel stamps, 4 tiles per CU, nothing else
+// in the way): 7-8.6 us for a plain store (the same with the store itself removed: it is instruction issue, not
+// memory), 19 us with GELU + stored derivative, 19.5 us when the result is multiplied by a stored derivative (a
+// dependent 16-byte load inside every 8-column step).  Here the variant is a compile-time constant, the band's global
+// operands (residual / stored derivative) are requested before its LDS transpose, and the row mask is worked out once
+// per band (a band's 16 rows span at most two sequences).  Same arithmetic in the same order: results are bitwise
+// those of tile_epilogue.
+//   EPI_PLAIN      C = mask(acc + bias + residual)                         (bias, residual, lengths optional)
+//   EPI_GELU_SAVE  C = mask(GELU(acc + bias)), aux_out = GELU'(acc + bias) (act = GELU | SAVE_DERIV)
+//   EPI_DACT       C = mask((acc + bias) * aux_in)                         (dact = STORED)
+// Host-side preconditions (gemm_ph_launch): bf16 C, alpha = 1, one K slice, no pre_add / accumulate / colsum_out,
+// N % 8 == 0, T >= 16 when lengths are given.  colpart is supported (the dgrad that also reduces the bias gradient).
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3 };
+
+template <int BM, int BN, int WM, int WN, bool ILV, bool ILVC, int EPI>
+VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int WCOLS = TN * 16;
+  constexpr int SW = WCOLS + 4;
+  constexpr int CPR = WCOLS / 8, RPP = 64 / CPR;
+  static_assert(RPP * 2 == 16, "two passes of 8 rows per band");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  auto band_row = [&](int i) {
+    if constexpr (ILV) return (i / (TM / 2)) * (BM / 2) + wm * (BM / WM / 2) + (i % (TM / 2)) * 16;
+    else return wm * (BM / WM) + i * 16;
+  };
+  auto strip_col = [&](int c) {
+    if constexpr (ILVC) return (c / (WCOLS / 2)) * (BN / 2) + wn * (WCOLS / 2) + c % (WCOLS / 2);
+    else return wn * (BN / WN) + c;
+  };
+  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
+  const int crow = lane / CPR, cch = lane % CPR;
+  const int n = n0 + strip_col(cch * 8);
+  const bool col_ok = n < p.N;
+  const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.residual);
+  const bf16_t* __restrict__ ain = reinterpret_cast<const bf16_t*>(p.aux_in);
+  bf16_t* __restrict__ aout = reinterpret_cast<bf16_t*>(p.aux_out);
+  bf16_t* __restrict__ cout = reinterpret_cast<bf16_t*>(p.C);
+  float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias && col_ok) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias[e] = b0[e]; bias[4 + e] = b1[e]; }
+  }
+  float cp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // the tile's global operands (residual / stored derivative: 16 x 16 bytes per lane) are all requested here, ahead
+  // of the barrier and of the first LDS transpose: one exposed memory round trip per tile instead of one per band
+  bf16x8 g[TM][2];
+  if constexpr (EPI == EPI_PLAIN || EPI == EPI_DACT) {
+    const bf16_t* __restrict__ src = EPI == EPI_PLAIN ? res : ain;
+    if (src != nullptr) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int m = m0 + band_row(i) + ps * RPP + crow;
+          if (col_ok && m < p.M) g[i][ps] = *reinterpret_cast<const bf16x8*>(src + (long)m * p.ldc + n);
+        }
+    }
+  }
+  __syncthreads();                         // every wave is done reading the last stage
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mband = m0 + band_row(i);            // wave-uniform
+    bool ok[2];
+    long idx[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = mband + ps * RPP + crow;
+      ok[ps] = col_ok && m < p.M;
+      idx[ps] = (long)m * p.ldc + n;
+    }
+    // the band's rows sit in sequence b0 from frame t0 on and, past its end, in sequence b0 + 1
+    int t0 = 0, len0 = 0x7fffffff, len1 = 0x7fffffff;
+    if (p.lengths != nullptr) {
+      const int b0 = mband / p.T;
+      t0 = mband - b0 * p.T;
+      len0 = (long)b0 * p.T < p.M ? p.lengths[b0] : 0;
+      len1 = (long)(b0 + 1) * p.T < p.M ? p.lengths[b0 + 1] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        strip[(4 * (lane >> 4) + rr) * SW + j * 16 + (lane & 15)] = acc[i][j][rr];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int rloc = ps * RPP + crow;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
+      if (!ok[ps]) continue;
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      if constexpr (EPI == EPI_GELU_SAVE) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          f32x2_t cdf, px;
+          gelu_parts_pk(f32x2_t{v[e], v[e + 1]}, cdf, px);
+          o[e] = (bf16_t)(cdf[0] + px[0]);
+          o[e + 1] = (bf16_t)(cdf[1] + px[1]);
+          v[e] *= cdf[0];
+          v[e + 1] *= cdf[1];
+        }
+        *reinterpret_cast<bf16x8*>(aout + idx[ps]) = o;
+      } else if constexpr (EPI == EPI_DACT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= (float)g[i][ps][e];
+      } else {
+        if (res != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)g[i][ps][e];
+        }
+      }
+      const int t = t0 + rloc;
+      const bool keep = t < p.T ? t < len0 : t - p.T < len1;
+      if (!keep) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8*>(cout + idx[ps]) = o;
+      if (p.colpart) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cp[e] += v[e];
+      }
+    }
+  }
+  if (p.colpart) {
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cp[e] += __shfl_xor(cp[e], o, 64);
+    __syncthreads();
+    float* cred = reinterpret_cast<float*>(smem);          // [NW][WCOLS]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cred[wave * WCOLS + lane * 8 + e] = cp[e];
+    }
+    __syncthreads();
+    if (wm == 0 && lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WM; ++w2) t += cred[(w2 * WN + wn) * WCOLS + lane * 8 + e];
+        const int nn = n0 + strip_col(lane * 8) + e;
+        if (nn < p.N) p.colpart[(long)(m0 / BM) * p.N + nn] = t;
       }
     }
   }
