@@ -285,6 +285,13 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
   const int kind = sizeof(T) == 4 ? VG_PROF_GEMM_F32
                     : (a_tr ? VG_PROF_GEMM_BF16_TN : (b_tr ? VG_PROF_GEMM_BF16_NN : VG_PROF_GEMM_BF16_NT));
   if (sizeof(T) == 2 && tile_cfg > 0) {   // LDS-DMA pipelined variant (vg_gemm_dma.hip)
+    static const int sig_debug = [] { const char* e = getenv("VG_DEBUG_GEMM"); return e ? atoi(e) : 0; }();
+    if (sig_debug == 2)          // one line per launch: shape, tile configuration and epilogue options (tools/gemm_census.py)
+      fprintf(stderr, "[vg_gemm] cfg=%d M=%d N=%d K=%d a_tr=%d b_tr=%d splits=%d act=%d dact=%d bias=%d res=%d pre=%d aux_out=%d "
+                      "lens=%d f32=%d acc=%d colpart=%d colsum=%d alpha=%g\n",
+              tile_cfg, p.M, p.N, p.K, a_tr, b_tr, splits, p.act, p.dact, p.bias != nullptr, p.residual != nullptr,
+              p.pre_add != nullptr, p.aux_out != nullptr, p.lengths != nullptr, p.out_f32, p.accumulate,
+              p.colpart != nullptr, p.colsum_out != nullptr, (double)p.alpha);
     const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream, gemm_algorithmic_bytes(p, sizeof(T)));
     int rc = -1;
     if (tile_cfg >= 10) {     // phase-pipelined 256x256 tile (vg_gemm_ph.hip); shapes it does not take run on cfg 3
