@@ -155,6 +155,53 @@ def test_wgrad_with_fused_bias_gradient(F, dtype, frames):
         torch.testing.assert_close(gb.double(), ref_b + 2.0, **wt)
 
 
+LEAN_VARIANTS = {
+    "plain": dict(),
+    "bias + residual + colpart": dict(bias=True, residual=True, colpart=True),
+    "GELU + stored derivative": dict(bias=True, act=2 | 16, aux=True),
+    "times stored derivative + colpart": dict(dact=4, aux_in=True, colpart=True),
+}
+
+
+@pytest.mark.parametrize("variant", list(LEAN_VARIANTS))
+@pytest.mark.parametrize("mode", ["nt", "nn"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_lean_epilogues_are_bitwise_the_generic_one(F, variant, mode, masked):
+    """tile_cfg 13 ends in a compile-time epilogue (tile_epilogue_lean) when the options fit one of three shapes;
+    tile_cfg 3 always runs the all-options epilogue.  Same arithmetic in the same order: results must be bitwise
+    equal, on ragged tile edges and with a row mask whose sequences (T = 17) end inside 16-row bands."""
+    kw = LEAN_VARIANTS[variant]
+    M, N, K, T = (85 if masked else 1003), 520, 256, 17
+    A = rnd(M, K, dtype=torch.bfloat16)
+    B = rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=1)
+    if mode == "nn":
+        B = B.T.contiguous()
+    bias, res, der = rnd(N, seed=2), rnd(M, N, dtype=torch.bfloat16, seed=3), rnd(M, N, dtype=torch.bfloat16, seed=4)
+    lens = torch.tensor([17, 16, 1, 0, 16], dtype=torch.int32, device=dev())
+    outs = {}
+    for cfg in (3, 13):
+        args = dict(tile_cfg=cfg, b_tr=(mode == "nn"))
+        if kw.get("bias"): args["bias"] = bias
+        if kw.get("residual"): args["residual"] = res
+        if "act" in kw: args["act"] = kw["act"]
+        if "dact" in kw: args.update(dact=kw["dact"], aux_in=der)
+        aux = torch.zeros(M, N, device=dev(), dtype=torch.bfloat16) if kw.get("aux") else None
+        if aux is not None: args["aux_out"] = aux
+        part = [] if kw.get("colpart") else None
+        if part is not None: args["colpart"] = part
+        if masked: args.update(lengths=lens, T=T)
+        out = F.gemm(A, B, M, N, K, **args)
+        outs[cfg] = (out, aux, part[0] if part else None)
+    assert torch.equal(outs[3][0], outs[13][0])
+    if outs[3][1] is not None:
+        assert torch.equal(outs[3][1], outs[13][1])
+    if outs[3][2] is not None:      # per-row-tile partial sums: both tile shapes have 256 rows, the summation order inside differs
+        torch.testing.assert_close(outs[3][2].sum(0), outs[13][2].sum(0), atol=2e-2, rtol=1e-3)
+    ref = A.float() @ (B.float() if mode == "nn" else B.float().T)
+    if variant == "plain" and not masked:
+        torch.testing.assert_close(outs[13][0].float(), ref, atol=3e-2, rtol=3e-2)
+
+
 GROUPED_CASES = {
     # name: [((out features, in features), frames)]   -- frames = the reduction length of that product
     "layer (192 tiles: heads + tails in lockstep)": [((4096, 1024), 2048), ((1024, 4096), 2048), ((3072, 1024), 2048),
