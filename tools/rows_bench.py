@@ -36,8 +36,8 @@ def main():
     L = hipvg.lib()
     st = hipvg.stream()
     p = hipvg.ptr
-    M, T = 8000, 1000
-    lengths = torch.full((8,), T, dtype=torch.int32, device=dev)
+    M, T = int(os.environ.get("M", "8000")), 1000
+    lengths = torch.full((M // T,), T, dtype=torch.int32, device=dev)
     for C in (1024, 512):
         x = torch.randn(M, C, device=dev).bfloat16()
         dy = torch.randn(M, C, device=dev).bfloat16()
@@ -54,6 +54,19 @@ def main():
         report(f"rmsnorm_fwd C={C}", t, 2 * M * C * 2)
         t = timeit(lambda: L.vg_rmsnorm_bwd(p(dy), p(x), p(sc), p(rstd), p(add), p(dx), p(part), M, C, p(lengths), T, 1, st))
         report(f"rmsnorm_bwd C={C} (+dx_add)", t, 4 * M * C * 2)
+        # cold operands: rotate over R buffer sets (> the 256 MB Infinity Cache), as inside the training step
+        R = 8
+        xs, dys, adds, ys_, dxs = ([torch.randn(M, C, device=dev).bfloat16() for _ in range(R)] for _ in range(5))
+        k = [0]
+        def fwd_cold():
+            i = k[0] = (k[0] + 1) % R
+            L.vg_rmsnorm_fwd(p(xs[i]), p(sc), p(ys_[i]), p(rstd), M, C, 1e-6, p(lengths), T, 1, st)
+        def bwd_cold():
+            i = k[0] = (k[0] + 1) % R
+            L.vg_rmsnorm_bwd(p(dys[i]), p(xs[i]), p(sc), p(rstd), p(adds[i]), p(dxs[i]), p(part), M, C, p(lengths), T, 1, st)
+        report(f"rmsnorm_fwd C={C} cold", timeit(fwd_cold), 2 * M * C * 2)
+        report(f"rmsnorm_bwd C={C} cold", timeit(bwd_cold), 4 * M * C * 2)
+        del xs, dys, adds, ys_, dxs
         t = timeit(lambda: L.vg_colsum(p(part), nb, C, C, None, p(out), 0, 1, st))
         report(f"colsum partial [{nb}x{C}] f32", t, nb * C * 4)
         t = timeit(lambda: L.vg_colsum(p(dy), M, C, C, p(ws), p(out), 1, 1, st))

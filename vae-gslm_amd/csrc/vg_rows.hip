@@ -47,6 +47,9 @@ constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 template <typename T> struct Vec;
 template <> struct Vec<float> {
   static constexpr int N = 4;
+  typedef f32x4 raw_t;
+  static VG_DEVICE raw_t load_raw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static VG_DEVICE void unpack(raw_t v, float (&o)[8]) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
   static VG_DEVICE void load(const float* p, float (&o)[8]) {
     f32x4 v = *reinterpret_cast<const f32x4*>(p);
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
@@ -58,6 +61,12 @@ template <> struct Vec<float> {
 };
 template <> struct Vec<bf16_t> {
   static constexpr int N = 8;
+  typedef bf16x8 raw_t;
+  static VG_DEVICE raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static VG_DEVICE void unpack(raw_t v, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
   static VG_DEVICE void load(const bf16_t* p, float (&o)[8]) {
     bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -74,7 +83,7 @@ template <> struct Vec<bf16_t> {
 // ------------------------------------------------------------------ RMSNorm forward
 // one wave per frame, grid-stride over frames; the scale vector is read once per wave and the
 // next frame's loads are issued before the current frame's reduction (two frames in flight)
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                           T* __restrict__ y, float* __restrict__ rstd, int M, int C,
                                                           float eps, const int* __restrict__ lengths, int Tlen) {
@@ -84,9 +93,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
   const int stride = gridDim.x * 4;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  float sc[MAXV][8], v[MAXV][8], nx[MAXV][8];
+  float sc[NV][8], v[NV][8], nx[NV][8];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nvec) {
       Vec<T>::load(x + (long)row * C + c * N, v[i]);
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
     const int nrow = row + stride;
     if (nrow < M) {
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
+      for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nvec) Vec<T>::load(x + (long)nrow * C + c * N, nx[i]);
       }
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
     const bool valid = row_valid(lengths, Tlen, row);
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
 #pragma unroll
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
     const float r = rsqrtf(ss * inv_c + eps);
     if (lane == 0) rstd[row] = r;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
         float o[8];
@@ -135,35 +144,54 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------ RMSNorm backward
 // dx = dx_add + mask * rstd * (g - xhat * mean(g * xhat)),  g = dy * scale, xhat = x * rstd
 // dscale_partial[block][c] = sum over this block's valid rows of dy * xhat
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ rstd, const T* __restrict__ dx_add,
                                                           T* __restrict__ dx, float* __restrict__ dscale_partial,
                                                           int M, int C, const int* __restrict__ lengths, int Tlen) {
   constexpr int N = Vec<T>::N;
-  __shared__ float red[4][64 * MAXV * 8 / 4];   // sized for the f32 case below (see static_assert)
-  static_assert(sizeof(red) >= 4 * 64 * MAXV * 2 * sizeof(float), "reduction scratch");
+  __shared__ float red[4][64 * 8];             // [wave][lane * N + e], N <= 8
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C / N;
-  float ds[MAXV][8];
+  float ds[NV][8];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ds[i][e] = 0.f;
 
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  // two frames in flight per wave: the next frame's three row segments are requested (and kept packed) before
+  // this frame's reduction
+  typedef typename Vec<T>::raw_t raw_t;
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  raw_t ra[NV], rb[NV], ro[NV], na[NV], nb[NV], no[NV];
+  auto fetch = [&](int rw, raw_t (&fa)[NV], raw_t (&fb)[NV], raw_t (&fo)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        fa[i] = Vec<T>::load_raw(dy + (long)rw * C + c * N);
+        fb[i] = Vec<T>::load_raw(x + (long)rw * C + c * N);
+        if (dx_add) fo[i] = Vec<T>::load_raw(dx_add + (long)rw * C + c * N);
+      }
+    }
+  };
+  if (row < M) fetch(row, ra, rb, ro);
+  for (; row < M; row += stride) {
+    const int nrow = row + stride;
+    if (nrow < M) fetch(nrow, na, nb, no);
     const bool valid = row_valid(lengths, Tlen, row);
     const float r = rstd[row];
-    float g[MAXV][8], xh[MAXV][8];
+    float g[NV][8], xh[NV][8];
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
         float a[8], b[8];
-        Vec<T>::load(dy + (long)row * C + c * N, a);
-        Vec<T>::load(x + (long)row * C + c * N, b);
+        Vec<T>::unpack(ra[i], a);
+        Vec<T>::unpack(rb[i], b);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           xh[i][e] = b[e] * r;
@@ -175,27 +203,30 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
     }
     dot = wave_sum(dot) / (float)C;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
-        float o[8];
-        if (dx_add) Vec<T>::load(dx_add + (long)row * C + c * N, o);
+        float out[8];
+        if (dx_add) Vec<T>::unpack(ro[i], out);
         else {
 #pragma unroll
-          for (int e = 0; e < N; ++e) o[e] = 0.f;
+          for (int e = 0; e < N; ++e) out[e] = 0.f;
         }
         if (valid) {
 #pragma unroll
-          for (int e = 0; e < N; ++e) o[e] += r * (g[i][e] - xh[i][e] * dot);
+          for (int e = 0; e < N; ++e) out[e] += r * (g[i][e] - xh[i][e] * dot);
         }
-        Vec<T>::store(dx + (long)row * C + c * N, o);
+        Vec<T>::store(dx + (long)row * C + c * N, out);
+        ra[i] = na[i];
+        rb[i] = nb[i];
+        ro[i] = no[i];
       }
     }
   }
-  // cross-wave reduction of the scale-gradient partials, MAXV passes of [4][64*N]
+  // cross-wave reduction of the scale-gradient partials, NV passes of [4][64*N]
   float* scratch = &red[0][0];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < N; ++e) scratch[(wave * 64 + lane) * N + e] = ds[i][e];
@@ -522,15 +553,18 @@ template <typename T>
 void run_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, int M, int C, float eps,
                      const int32_t* lengths, int Tn, hipStream_t stream) {
   const int nb = (M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024;
-  rmsnorm_fwd_kernel<T><<<dim3(nb), dim3(256), 0, stream>>>((const T*)x, scale, (T*)y, rstd, M, C, eps,
-                                                                     lengths, Tn);
+  const int nv = (C / Vec<T>::N + 63) / 64;      // 16-byte vectors per lane and row
+  auto k = nv <= 1 ? rmsnorm_fwd_kernel<T, 1> : nv <= 2 ? rmsnorm_fwd_kernel<T, 2> : rmsnorm_fwd_kernel<T, MAXV>;
+  k<<<dim3(nb), dim3(256), 0, stream>>>((const T*)x, scale, (T*)y, rstd, M, C, eps, lengths, Tn);
 }
 template <typename T>
 void run_rmsnorm_bwd(int nb, const void* dy, const void* x, const float* scale, const float* rstd,
                      const void* dx_add, void* dx, float* dsp, int M, int C, const int32_t* lengths, int Tn,
                      hipStream_t stream) {
-  rmsnorm_bwd_kernel<T><<<dim3(nb), dim3(256), 0, stream>>>((const T*)dy, (const T*)x, scale, rstd,
-                                                            (const T*)dx_add, (T*)dx, dsp, M, C, lengths, Tn);
+  const int nv = (C / Vec<T>::N + 63) / 64;
+  auto k = nv <= 1 ? rmsnorm_bwd_kernel<T, 1> : nv <= 2 ? rmsnorm_bwd_kernel<T, 2> : rmsnorm_bwd_kernel<T, MAXV>;
+  k<<<dim3(nb), dim3(256), 0, stream>>>((const T*)dy, (const T*)x, scale, rstd, (const T*)dx_add, (T*)dx, dsp, M, C,
+                                        lengths, Tn);
 }
 template <typename T>
 void run_colsum(dim3 grid, const void* x, int M, int N, long ld, float* out, hipStream_t stream) {
