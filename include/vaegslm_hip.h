@@ -195,6 +195,11 @@ typedef struct vg_colsum_task {
   int accumulate;
 } vg_colsum_task;
 int vg_colsum_multi(const vg_colsum_task* tasks, int n, vg_stream_t stream);
+/* first stage of up to VG_COLSUM_MAX_TASKS LARGE column sums in one launch (the bias gradients of one Transformer
+ * layer: column sums of the incoming gradient, of the attention-output gradient and of dQKV): src is [rows][ld] of
+ * `dtype` (passed through the float* field), dst receives nb rows of cols fp32 partial sums (nb as vg_colsum_blocks),
+ * which vg_colsum_multi then folds together with the node's other partial arrays. */
+int vg_colsum_partials_multi(const vg_colsum_task* tasks, int n, int nb, int dtype, vg_stream_t stream);
 /* dx = dy * act'(aux): ReLU takes aux = activation output, GELU (erf) takes aux = pre-activation
  * (modules/activations.py:5-18 backward, for Linear+activation heads with several consumers). */
 int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, vg_stream_t stream);

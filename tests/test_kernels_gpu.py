@@ -814,6 +814,26 @@ def test_colsum_multi_folds_several_partial_arrays_in_one_launch(F):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum_partials_of_several_large_matrices_in_one_launch(F, dtype):
+    """vg_colsum_partials_multi (the three or four bias gradients of a Transformer layer's backward): partial sums of
+    matrices of different widths, strided rows included, folded by vec_grads into sunk gradients."""
+    g = torch.Generator().manual_seed(4)
+    M = 4001                                         # not a multiple of the row blocking
+    wide = torch.randn(M, 3072 + 64, generator=g).to(dev()).to(dtype)
+    mats = [torch.randn(M, 1024, generator=g).to(dev()).to(dtype), wide[:, :3072], torch.randn(M, 72 * 8, generator=g).to(dev()).to(dtype)]
+    parts = F.colsum_partials(mats)
+    assert parts is not None and all(q.shape[1] == x.shape[1] for q, x in zip(parts, mats))
+    ps = [torch.nn.Parameter(torch.zeros(x.shape[1], device=dev())) for x in mats]
+    ps[1].grad = torch.full_like(ps[1], -1.0)
+    outs = F.vec_grads(list(zip(ps, parts)))
+    assert all(o is None for o in outs)
+    tl = dict(rtol=1e-5, atol=2e-3) if dtype == torch.float32 else dict(rtol=1e-5, atol=2e-3)
+    for i, (p, x) in enumerate(zip(ps, mats)):
+        torch.testing.assert_close(p.grad, x.float().sum(0) + (-1.0 if i == 1 else 0.0), **tl)
+    assert F.colsum_partials([mats[0], mats[0][:100]]) is None       # different row counts: caller takes the single path
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,relu", [(128, True), (256, False), (72, True)])
 def test_narrow_channel_norm_matches_tensor_ops(F, dtype, C, relu):
     """vg_chnorm_fwd / _bwd (unbiased variance, optional fused ReLU) against the tensor expression the narrow

@@ -1015,6 +1015,84 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumTasks tk) {
 }
 }  // namespace
 
+namespace {
+// first stage of several LARGE column sums in one launch: blockIdx.x walks the 64-lane column blocks of all tasks,
+// blockIdx.y the row blocks; task k's partial sums go to dst[blockIdx.y][cols] (fp32)
+struct ColsumBigTasks {
+  vg_colsum_task t[VG_COLSUM_MAX_TASKS];
+  int first_block[VG_COLSUM_MAX_TASKS + 1];
+  int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partials_multi_kernel(ColsumBigTasks tk) {
+  constexpr int V = Vec<T>::N;
+  __shared__ float red[4][64][V];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < VG_COLSUM_MAX_TASKS; ++i)
+    if (i < tk.n && (int)blockIdx.x >= tk.first_block[i]) k = i;
+  const vg_colsum_task& t = tk.t[k];
+  const T* __restrict__ x = reinterpret_cast<const T*>(t.src);
+  const int M = t.rows, N = t.cols;
+  const long ld = t.ld;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c0 = (((int)blockIdx.x - tk.first_block[k]) * 64 + tx) * V;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    const int step = gridDim.y * 4;
+    int m = blockIdx.y * 4 + ty;
+    for (; m + step < M; m += 2 * step) {
+      float a[8], b[8];
+      Vec<T>::load(x + (long)m * ld + c0, a);
+      Vec<T>::load(x + (long)(m + step) * ld + c0, b);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += a[e] + b[e];
+    }
+    if (m < M) {
+      float a[8];
+      Vec<T>::load(x + (long)m * ld + c0, a);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += a[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[ty][tx][e] = s[e];
+  __syncthreads();
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      t.dst[(long)blockIdx.y * N + c0 + e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
+  }
+}
+}  // namespace
+
+extern "C" int vg_colsum_partials_multi(const vg_colsum_task* tasks, int n, int nb, int dtype, hipStream_t stream) {
+  VG_REQUIRE(tasks != nullptr && n >= 1 && n <= VG_COLSUM_MAX_TASKS, "vg_colsum_partials_multi: n=%d (1..%d)", n,
+             VG_COLSUM_MAX_TASKS);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_colsum_partials_multi: bad dtype %d", dtype);
+  VG_REQUIRE(nb >= 1 && nb <= 1024, "vg_colsum_partials_multi: nb=%d", nb);
+  const int vec = dtype == VG_BF16 ? 8 : 4;
+  ColsumBigTasks tk;
+  tk.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const vg_colsum_task& k = tasks[i];
+    VG_REQUIRE(k.src != nullptr && k.dst != nullptr && k.rows > 0 && k.cols > 0 && k.cols % vec == 0 && k.ld % vec == 0 &&
+                   ((uintptr_t)k.src % 16) == 0,
+               "vg_colsum_partials_multi: task %d: rows=%d cols=%d ld=%ld (16-byte aligned rows, cols %% %d == 0)", i,
+               k.rows, k.cols, (long)k.ld, vec);
+    tk.t[i] = k;
+    tk.first_block[i] = blocks;
+    blocks += (k.cols + 64 * vec - 1) / (64 * vec);
+  }
+  for (int i = n; i <= VG_COLSUM_MAX_TASKS; ++i) tk.first_block[i] = blocks;
+  dim3 grid(blocks, nb), block(64, 4);
+  if (dtype == VG_BF16) colsum_partials_multi_kernel<bf16_t><<<grid, block, 0, stream>>>(tk);
+  else colsum_partials_multi_kernel<float><<<grid, block, 0, stream>>>(tk);
+  return vg_host::check_launch("vg_colsum_partials_multi");
+}
+
 extern "C" int vg_colsum_multi(const vg_colsum_task* tasks, int n, hipStream_t stream) {
   VG_REQUIRE(tasks != nullptr && n >= 1 && n <= VG_COLSUM_MAX_TASKS, "vg_colsum_multi: n=%d (1..%d)", n,
              VG_COLSUM_MAX_TASKS);

@@ -34,12 +34,14 @@ def _flag(name: str, default: str) -> bool:
 _FUSE_BIAS_GRAD = _flag("VG_FUSE_BIAS_GRAD", "0")
 _STORED_DERIV = _flag("VG_STORED_DERIV", "1")   # forward stores act'(u): the backward epilogue is one multiply
 _COLSUM_MULTI = _flag("VG_COLSUM_MULTI", "1")   # the small column sums of a backward node in one launch
+_COLSUM_BIG = _flag("VG_COLSUM_BIG", "1")     # a layer's large bias column sums (first stage) in one launch
 _COLPART = _flag("VG_COLPART", "1")             # dgrad launches also reduce their result per row tile (bias gradients)
 # in-launch slab reduction of split-K weight gradients instead of fp32 atomics: measured SLOWER on these tiles
 # (64 KiB of slab per slice; write-through slabs + ticket: 80 vs 67 us per wgrad launch, 289k vs 305k tokens/s;
 # with an agent-scope release fence per block instead of write-through stores: 90 us)
 _SPLIT_SLABS = _flag("VG_SPLIT_SLABS", "0")
 _PH_WGRAD = _flag("VG_PH_WGRAD", "1")           # weight gradients on 256x256 ring tiles (split sized for one block per CU)
+_GROUP_MIN_TILES = int(os.environ.get("VG_GROUP_MIN_TILES", "24"))   # fewer 256x256 tiles than this: one launch per product
 _PH_GROUP = _flag("VG_PH_GROUP", "1")           # a layer's four weight gradients as one grouped launch
 _GRAD_SINK = _flag("VG_GRAD_SINK", "1")         # wgrad / column sums write straight into param.grad
 # sunk weight gradients of a layer on a second stream (parallel graph branch): measured slower, 55.4 vs 53.2 ms
@@ -169,39 +171,48 @@ def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -
     return max(1, min(s, k_red // 256))
 
 
-def sink_wgrad_group(items) -> None:
-    """``items``: (weight, dy[M, N], x[M, K]) triples of one backward node.  The weight gradients
-    ``weight.grad[N, K] += dy^T x`` of all of them in ONE launch (``vg_gemm_grouped``: 256x256 ring tiles, the big
-    products unsplit, so no memory-side atomics) when every product qualifies; one launch each otherwise."""
-    items = [it for it in items if it is not None]
+def sink_wgrad_group(items, fire: bool = True) -> None:
+    """``items``: (weight, dy[M, N], x[M, K]) or (weight, dy, x, col0) of one backward node.  The weight gradients
+    ``weight.grad[N, col0:col0 + K] += dy^T x`` of all of them in ONE launch (``vg_gemm_grouped``: persistent grid of
+    256x256 tiles with equal K ranges per CU) when every product qualifies and together they are at least
+    ``VG_GROUP_MIN_TILES`` tiles; one split-K launch each otherwise.  ``col0`` addresses a column slice of a weight
+    whose input is a concatenation (the conv block's [u | cond] Linear)."""
+    items = [it if len(it) == 4 else (*it, 0) for it in items if it is not None]
     if not items:
         return
+
+    def grad_view(w, x, col0):
+        N = w.shape[0]
+        return _grad_buffer(w).view(N, -1)[:, col0:col0 + x.shape[1]]
     ok = _PH_GROUP and len(items) <= 8
     total = 0
-    for w, dy, x in items:
-        N, K, M = w.shape[0], w.numel() // w.shape[0], x.shape[0]
+    for w, dy, x, col0 in items:
+        N, K, M = w.shape[0], x.shape[1], x.shape[0]
         ok = ok and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and M % 64 == 0 and M >= 1024
-        ok = ok and N % 8 == 0 and K % 8 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and w.is_contiguous()
+        ok = ok and N % 8 == 0 and K % 8 == 0 and col0 % 4 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and w.is_contiguous()
         ok = ok and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
         total += ((N + 255) // 256) * ((K + 255) // 256)
-    if not ok or total < 96:
-        for w, dy, x in items:
-            sink_wgrad(w, dy, x, None)
-        return
-    # blocks of equal length fill 256 CUs in whole rounds: 96..256 tiles run unsplit (one round), more tiles mean more
-    # rounds; fewer than 96 went the other way above
-    descs = (GemmDesc * len(items))()
-    for d, (w, dy, x) in zip(descs, items):
-        N, K, M = w.shape[0], w.numel() // w.shape[0], x.shape[0]
-        g = _grad_buffer(w).view(N, K)
-        d.A, d.B, d.C = ptr(dy), ptr(x), ptr(g)
-        d.M, d.N, d.K = N, K, M
-        d.lda, d.ldb, d.ldc = dy.stride(0), x.stride(0), g.stride(0)
-        d.a_tr, d.b_tr, d.dtype = 1, 1, dtype_id(torch.bfloat16)
-        d.out_f32, d.accumulate, d.split_k, d.alpha = 1, 1, 1, 1.0
-    check(lib().vg_gemm_grouped(descs, len(items), stream()), "vg_gemm_grouped")
-    for w, _, _ in items:
-        _fire(w)
+    if not ok or total < _GROUP_MIN_TILES:
+        for w, dy, x, col0 in items:
+            N, K, M = w.shape[0], x.shape[1], x.shape[0]
+            s = wgrad_splits(N, K, M, x.dtype)
+            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=grad_view(w, x, col0), split_k=s, accumulate=(s == 1))
+    else:
+        descs = (GemmDesc * len(items))()
+        for d, (w, dy, x, col0) in zip(descs, items):
+            g = grad_view(w, x, col0)
+            d.A, d.B, d.C = ptr(dy), ptr(x), ptr(g)
+            d.M, d.N, d.K = w.shape[0], x.shape[1], x.shape[0]
+            d.lda, d.ldb, d.ldc = dy.stride(0), x.stride(0), g.stride(0)
+            d.a_tr, d.b_tr, d.dtype = 1, 1, dtype_id(torch.bfloat16)
+            d.out_f32, d.accumulate, d.split_k, d.alpha = 1, 1, 1, 1.0
+        check(lib().vg_gemm_grouped(descs, len(items), stream()), "vg_gemm_grouped")
+    if fire:
+        seen = set()
+        for w, _, _, _ in items:
+            if id(w) not in seen:
+                seen.add(id(w))
+                _fire(w)
 
 
 def colsum(x: Tensor, into: Optional[Tensor] = None) -> Tensor:
@@ -255,6 +266,28 @@ def vec_grads(pairs):
         for p in fire:
             _fire(p)
     return out
+
+
+def colsum_partials(mats):
+    """First stage of the column sums of several large [M, N_i] matrices of one dtype in ONE launch
+    (``vg_colsum_partials_multi``): returns fp32 partial-sum arrays [nb, N_i] to be folded by ``vec_grads``; None
+    for the whole list when some matrix does not qualify."""
+    import hipvg
+    if not mats or len(mats) > hipvg.COLSUM_MAX_TASKS:
+        return None
+    dt = mats[0].dtype
+    vec = 8 if dt == torch.bfloat16 else 4
+    M = mats[0].shape[0]
+    nb = lib().vg_colsum_blocks(M)
+    for x in mats:
+        if (x.dtype != dt or dt not in (torch.bfloat16, torch.float32) or x.dim() != 2 or x.stride(1) != 1
+                or x.shape[0] != M or x.shape[1] % vec or x.stride(0) % vec or x.data_ptr() % 16 or nb <= 1):
+            return None
+    parts = [torch.empty((nb, x.shape[1]), dtype=torch.float32, device=x.device) for x in mats]
+    arr = (hipvg.ColsumTask * len(mats))(*[hipvg.ColsumTask(x.data_ptr(), M, x.shape[1], x.stride(0), q.data_ptr(), 0)
+                                           for x, q in zip(mats, parts)])
+    check(lib().vg_colsum_partials_multi(arr, len(mats), nb, dtype_id(dt), stream()), "vg_colsum_partials_multi")
+    return parts
 
 
 def sink_colsum(p: Tensor, x: Tensor) -> None:
@@ -860,10 +893,15 @@ class TransformerLayerFn(torch.autograd.Function):
         group = [] if (_PH_GROUP and not ws.enabled and dt == torch.bfloat16 and
                        all(_sinkable(w) and w.is_contiguous() for w in (w1, w2, wo, wqkv))) else None
 
+        big = []                                 # (bias, gradient rows): first-stage column sums in ONE launch below
+
         def wgrad(weight, bias, g_out, inp):
             if group is None:
                 return ws.wgrad(weight, bias, g_out, inp)
             group.append((weight, g_out, inp))
+            if bias is not None and _COLSUM_MULTI and _COLSUM_BIG:
+                big.append((bias, g_out))
+                return None, None
             return None, vec_grad(bias, g_out)
         g_w2, g_b2 = wgrad(w2, b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
@@ -887,10 +925,29 @@ class TransformerLayerFn(torch.autograd.Function):
         g_wq, g_bq = wgrad(wqkv, bqkv, dqkv, n1)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
         small.append((n1s, ds1))
+        if big:                                  # b2 <- dy, bo <- dx1, bqkv <- dqkv (and b1 <- du without colpart)
+            parts_big = colsum_partials([g for _, g in big])
+            if parts_big is None:
+                parts_big = [None] * len(big)
+            for (bp, g), q in zip(big, parts_big):
+                if q is None:
+                    folded_one = vec_grad(bp, g)
+                    if bp is b2: g_b2 = folded_one
+                    elif bp is bo: g_bo = folded_one
+                    elif bp is bqkv: g_bq = folded_one
+                    elif bp is b1: g_b1 = folded_one
+                else:
+                    small.append((bp, q))
         folded = dict(zip((id(p) for p, _ in small), vec_grads(small)))
         g_n1, g_n3 = folded[id(n1s)], folded[id(n3s)]
         if b1 is not None and id(b1) in folded:
             g_b1 = folded[id(b1)]
+        if b2 is not None and id(b2) in folded:
+            g_b2 = folded[id(b2)]
+        if bo is not None and id(bo) in folded:
+            g_bo = folded[id(bo)]
+        if bqkv is not None and id(bqkv) in folded:
+            g_bq = folded[id(bqkv)]
         if group is not None:
             sink_wgrad_group(group)
         ws.join()                                # before qkv / att / du ... can be released
@@ -1004,16 +1061,33 @@ class ConvBlockFn(torch.autograd.Function):
             return gemm(g_out, inp, rows, cols, M, a_tr=True, b_tr=True, out_f32=True,
                         split_k=wgrad_splits(rows, cols, M, dt))
 
-        g_c3 = wgrad_into(c3w, Cc, 0, Hd, dy, h, c3b)
+        # both (or, with a conditioning input, all three) weight gradients as ONE grouped launch when they can be sunk
+        grouped = (_PH_GROUP and not _FUSE_BIAS_GRAD and dt == torch.bfloat16 and _sinkable(c2w) and _sinkable(c3w)
+                   and c2w.is_contiguous() and c3w.is_contiguous())
+        group = []
+        if grouped:
+            g_c3 = None
+            group.append((c3w, dy, h, 0))
+        else:
+            g_c3 = wgrad_into(c3w, Cc, 0, Hd, dy, h, c3b)
         g_c3b = None if id(c3b) in fused_bias else vec_grad(c3b, dy)
         du = gemm(dpre, Wa, M, Cc, Hd, b_tr=True)
-        ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u, c2b)
+        if grouped:
+            ga = None
+            group.append((c2w, dpre, u, 0))
+        else:
+            ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u, c2b)
         dcond = gc = None
         if cond is not None:
             Wc = s2[:, Cc:]
             Kc = cond.shape[1]
             dcond = gemm(dpre, Wc, M, Kc, Hd, b_tr=True)
-            gc = wgrad_into(c2w, Hd, Cc, Kc, dpre, cond)
+            if grouped:
+                group.append((c2w, dpre, cond, Cc))
+            else:
+                gc = wgrad_into(c2w, Hd, Cc, Kc, dpre, cond)
+        if group:
+            sink_wgrad_group(group, fire=False)          # fired below, once per weight
         if _sinkable(c2w):
             _fire(c2w)
             g_c2 = None
