@@ -160,6 +160,10 @@ LEAN_VARIANTS = {
     "bias + residual + colpart": dict(bias=True, residual=True, colpart=True),
     "GELU + stored derivative": dict(bias=True, act=2 | 16, aux=True),
     "times stored derivative + colpart": dict(dact=4, aux_in=True, colpart=True),
+    "bias + ReLU": dict(bias=True, act=1),
+    "SiLU + stored derivative": dict(bias=True, act=3 | 16, aux=True),
+    "pre-add + SiLU + stored derivative": dict(bias=True, act=3 | 16, aux=True, pre_add=True),
+    "ReLU derivative from the stored output + colpart": dict(dact=1, aux_in=True, colpart=True),
 }
 
 
@@ -185,6 +189,7 @@ def test_lean_epilogues_are_bitwise_the_generic_one(F, variant, mode, masked):
         if kw.get("residual"): args["residual"] = res
         if "act" in kw: args["act"] = kw["act"]
         if "dact" in kw: args.update(dact=kw["dact"], aux_in=der)
+        if kw.get("pre_add"): args["pre_add"] = res
         aux = torch.zeros(M, N, device=dev(), dtype=torch.bfloat16) if kw.get("aux") else None
         if aux is not None: args["aux_out"] = aux
         part = [] if kw.get("colpart") else None

@@ -331,12 +331,13 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
 // operands (residual / stored derivative) are requested before its LDS transpose, and the row mask is worked out once
 // per band (a band's 16 rows span at most two sequences).  Same arithmetic in the same order: results are bitwise
 // those of tile_epilogue.
-//   EPI_PLAIN      C = mask(acc + bias + residual)                         (bias, residual, lengths optional)
+//   EPI_PLAIN      C = mask(relu?(acc + bias) + residual)                  (bias, ReLU, residual, lengths optional)
 //   EPI_GELU_SAVE  C = mask(GELU(acc + bias)), aux_out = GELU'(acc + bias) (act = GELU | SAVE_DERIV)
-//   EPI_DACT       C = mask((acc + bias) * aux_in)                         (dact = STORED)
+//   EPI_SILU_SAVE  the same with SiLU, and an optional pre_add operand     (act = SILU | SAVE_DERIV: the conv blocks)
+//   EPI_DACT       C = mask((acc + bias) * aux_in)                         (dact = STORED; dact = RELU: aux_in > 0 ? . : 0)
 // Host-side preconditions (gemm_ph_launch): bf16 C, alpha = 1, one K slice, no pre_add / accumulate / colsum_out,
 // N % 8 == 0, T >= 16 when lengths are given.  colpart is supported (the dgrad that also reduces the bias gradient).
-enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3 };
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3, EPI_SILU_SAVE = 4 };
 
 template <int BM, int BN, int WM, int WN, bool ILV, bool ILVC, int EPI>
 VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0) {
@@ -375,8 +376,8 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
   // the tile's global operands (residual / stored derivative: 16 x 16 bytes per lane) are all requested here, ahead
   // of the barrier and of the first LDS transpose: one exposed memory round trip per tile instead of one per band
   bf16x8 g[TM][2];
-  if constexpr (EPI == EPI_PLAIN || EPI == EPI_DACT) {
-    const bf16_t* __restrict__ src = EPI == EPI_PLAIN ? res : ain;
+  if constexpr (EPI == EPI_PLAIN || EPI == EPI_DACT || EPI == EPI_SILU_SAVE) {
+    const bf16_t* __restrict__ src = EPI == EPI_PLAIN ? res : EPI == EPI_DACT ? ain : reinterpret_cast<const bf16_t*>(p.pre_add);
     if (src != nullptr) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -433,10 +434,32 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
           v[e + 1] *= cdf[1];
         }
         *reinterpret_cast<bf16x8*>(aout + idx[ps]) = o;
-      } else if constexpr (EPI == EPI_DACT) {
+      } else if constexpr (EPI == EPI_SILU_SAVE) {
+        if (p.pre_add != nullptr) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= (float)g[i][ps][e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)g[i][ps][e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sg = __frcp_rn(1.0f + __expf(-v[e]));
+          o[e] = (bf16_t)(sg * (1.0f + v[e] * (1.0f - sg)));
+          v[e] *= sg;
+        }
+        *reinterpret_cast<bf16x8*>(aout + idx[ps]) = o;
+      } else if constexpr (EPI == EPI_DACT) {
+        if (p.dact == VG_ACT_STORED) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= (float)g[i][ps][e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((float)g[i][ps][e] > 0.f) ? v[e] : 0.f;
+        }
       } else {
+        if ((p.act & 15) == VG_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         if (res != nullptr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)g[i][ps][e];
