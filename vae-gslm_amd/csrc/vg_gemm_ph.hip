@@ -864,7 +864,7 @@ __global__ __launch_bounds__(512) void gemm_ring_group_kernel(GroupParams gp) {
     f32x4 acc[8][4];
     zero_acc(acc);
     px2_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-    tile_epilogue<256, 256, 2, 4, true, false>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg, count == gp.nkt[g] ? 1 : 2, 0);
+    tile_epilogue_wgrad<256, 256, 2, 4, true, false>(p, acc, smem, c.m0, c.n0, count != gp.nkt[g]);
     __syncthreads();               // the strips are read out before the next segment's images land in them
   }
 }

@@ -507,4 +507,61 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
 }
 
 
+// ---- lean epilogue of the weight-gradient products (fp32 C, alpha = 1, C += acc): plain 16-byte read-modify-write
+// when this block holds the tile's whole K range, fp32 atomics (two 128-byte row segments per wave-instruction) when
+// it holds a piece of it.  Same arithmetic as tile_epilogue's two fp32 branches without its other 15,000 instructions.
+template <int BM, int BN, int WM, int WN, bool ILV, bool ILVC>
+VG_DEVICE void tile_epilogue_wgrad(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0,
+                                   bool atomic) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int WCOLS = TN * 16;
+  constexpr int SW = WCOLS + 4;
+  constexpr int CPR = WCOLS / 8, RPP = 64 / CPR;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  auto band_row = [&](int i) {
+    if constexpr (ILV) return (i / (TM / 2)) * (BM / 2) + wm * (BM / WM / 2) + (i % (TM / 2)) * 16;
+    else return wm * (BM / WM) + i * 16;
+  };
+  auto strip_col = [&](int c) {
+    if constexpr (ILVC) return (c / (WCOLS / 2)) * (BN / 2) + wn * (WCOLS / 2) + c % (WCOLS / 2);
+    else return wn * (BN / WN) + c;
+  };
+  __syncthreads();                         // every wave is done reading the last stage
+  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
+  float* __restrict__ c = reinterpret_cast<float*>(p.C);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        strip[(4 * (lane >> 4) + rr) * SW + j * 16 + (lane & 15)] = acc[i][j][rr];
+    const int mband = m0 + band_row(i);
+    if (atomic) {
+      constexpr int SEGS = WCOLS / 32;     // 32-float segments per strip row
+      for (int it = lane >> 5; it < 16 * SEGS; it += 2) {
+        const int rloc = it / SEGS, seg = it % SEGS;
+        const int m = mband + rloc, n = n0 + strip_col(seg * 32) + (lane & 31);
+        if (m < p.M && n < p.N) atomicAdd(c + (long)m * p.ldc + n, strip[rloc * SW + seg * 32 + (lane & 31)]);
+      }
+    } else {
+      const int crow = lane / CPR, cch = lane % CPR;
+#pragma unroll
+      for (int ps = 0; ps < 16 / RPP; ++ps) {
+        const int rloc = ps * RPP + crow;
+        const int m = mband + rloc, n = n0 + strip_col(cch * 8);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
+        if (m >= p.M || n >= p.N) continue;
+        f32x4* dst = reinterpret_cast<f32x4*>(c + (long)m * p.ldc + n);
+        dst[0] += lo;
+        dst[1] += hi;
+      }
+    }
+  }
+}
+
+
 }  // namespace
