@@ -708,7 +708,7 @@ VG_DEVICE void duo_main_loop(DuoCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* sm
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
 }
 
-template <bool A_TR, bool B_TR>
+template <bool A_TR, bool B_TR, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -718,13 +718,16 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
   f32x4 acc[8][4];                 // [A half * 4 + i][j]
   zero_acc(acc);
   duo_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-  tile_epilogue<256, 128, 2, 2, true, false>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
+  if constexpr (EPI == EPI_GENERIC) tile_epilogue<256, 128, 2, 2, true, false>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
+  else tile_epilogue_lean<256, 128, 2, 2, true, false, EPI>(p, acc, smem, c.m0, c.n0);
 }
 
-template <bool A_TR, bool B_TR>
-int launch_duo(const GemmParams& p, int splits, hipStream_t stream) {
+int lean_epilogue_of(const GemmParams& p, int splits);
+
+template <bool A_TR, bool B_TR, int EPI>
+int launch_duo_epi(const GemmParams& p, int splits, hipStream_t stream) {
   constexpr size_t lds = 5 * HALF_BYTES;
-  auto k = gemm_duo_kernel<A_TR, B_TR>;
+  auto k = gemm_duo_kernel<A_TR, B_TR, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -733,6 +736,18 @@ int launch_duo(const GemmParams& p, int splits, hipStream_t stream) {
   const int ntn = (p.N + 127) / 128, ntm = (p.M + 255) / 256;
   hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(256), lds, stream, p);
   return 0;
+}
+template <bool A_TR, bool B_TR>
+int launch_duo(const GemmParams& p, int splits, hipStream_t stream) {
+  if constexpr (!A_TR) {
+    switch (lean_epilogue_of(p, splits)) {
+      case EPI_PLAIN: return launch_duo_epi<A_TR, B_TR, EPI_PLAIN>(p, splits, stream);
+      case EPI_GELU_SAVE: return launch_duo_epi<A_TR, B_TR, EPI_GELU_SAVE>(p, splits, stream);
+      case EPI_DACT: return launch_duo_epi<A_TR, B_TR, EPI_DACT>(p, splits, stream);
+      default: break;
+    }
+  }
+  return launch_duo_epi<A_TR, B_TR, EPI_GENERIC>(p, splits, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
