@@ -200,6 +200,11 @@ int vg_colsum_multi(const vg_colsum_task* tasks, int n, vg_stream_t stream);
  * `dtype` (passed through the float* field), dst receives nb rows of cols fp32 partial sums (nb as vg_colsum_blocks),
  * which vg_colsum_multi then folds together with the node's other partial arrays. */
 int vg_colsum_partials_multi(const vg_colsum_task* tasks, int n, int nb, int dtype, vg_stream_t stream);
+/* out[seg][cols] = sum over the `rows` rows of segment seg of x[nseg * rows][ld] (the time-embedding gradient of a
+ * conv block: the block's input gradient summed over the frames of each sequence; `.float().sum(1)` on a [B, T, C]
+ * view in the reference-shaped code).  part: nb * nseg * cols floats of scratch, nb <= 64 row blocks per segment. */
+int vg_colsum_segments(const void* x, int nseg, int rows, int cols, int64_t ld, float* part, int nb, float* out, int dtype,
+                       vg_stream_t stream);
 /* dx = dy * act'(aux): ReLU takes aux = activation output, GELU (erf) takes aux = pre-activation
  * (modules/activations.py:5-18 backward, for Linear+activation heads with several consumers). */
 int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, vg_stream_t stream);

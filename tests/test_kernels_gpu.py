@@ -819,6 +819,16 @@ def test_colsum_multi_folds_several_partial_arrays_in_one_launch(F):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nseg,T,C", [(16, 1000, 512), (3, 77, 1024), (5, 1, 512)])
+def test_segment_column_sums(F, dtype, nseg, T, C):
+    """vg_colsum_segments (time-embedding gradient of a conv block): per-sequence sums over time of [B * T, C] rows."""
+    x = rnd(nseg * T, C, dtype=dtype)
+    got = F.segment_colsum(x, nseg)
+    want = x.view(nseg, T, C).float().sum(1)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_colsum_partials_of_several_large_matrices_in_one_launch(F, dtype):
     """vg_colsum_partials_multi (the three or four bias gradients of a Transformer layer's backward): partial sums of
     matrices of different widths, strided rows included, folded by vec_grads into sunk gradients."""

@@ -1067,6 +1067,61 @@ __global__ __launch_bounds__(256) void colsum_partials_multi_kernel(ColsumBigTas
 }
 }  // namespace
 
+namespace {
+// per-SEGMENT column sums, first stage: x is [nseg * rows][ld]; part[blockIdx.y][seg][cols] = sum over this row
+// block's rows of segment seg.  A plain column sum over the nb rows of part (viewed [nb][nseg * cols]) finishes it.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_segments_kernel(const T* __restrict__ x, int rows, int N, long ld,
+                                                              float* __restrict__ part) {
+  constexpr int V = Vec<T>::N;
+  __shared__ float red[4][64][V];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int seg = blockIdx.z, nseg = gridDim.z;
+  const int c0 = (blockIdx.x * 64 + tx) * V;
+  const T* __restrict__ xs = x + (long)seg * rows * ld;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    const int step = gridDim.y * 4;
+    int m = blockIdx.y * 4 + ty;
+    for (; m + step < rows; m += 2 * step) {
+      float a[8], b[8];
+      Vec<T>::load(xs + (long)m * ld + c0, a);
+      Vec<T>::load(xs + (long)(m + step) * ld + c0, b);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += a[e] + b[e];
+    }
+    if (m < rows) {
+      float a[8];
+      Vec<T>::load(xs + (long)m * ld + c0, a);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += a[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[ty][tx][e] = s[e];
+  __syncthreads();
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      part[((long)blockIdx.y * nseg + seg) * N + c0 + e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
+  }
+}
+}  // namespace
+
+extern "C" int vg_colsum_segments(const void* x, int nseg, int rows, int cols, int64_t ld, float* part, int nb, float* out,
+                                  int dtype, hipStream_t stream) {
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_colsum_segments: bad dtype %d", dtype);
+  const int vec = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(x != nullptr && part != nullptr && out != nullptr && nseg >= 1 && nseg <= 65535 && rows >= 1 && nb >= 1 && nb <= 64 &&
+                 cols > 0 && cols % vec == 0 && ld % vec == 0 && ((uintptr_t)x % 16) == 0,
+             "vg_colsum_segments: nseg=%d rows=%d cols=%d ld=%ld nb=%d", nseg, rows, cols, (long)ld, nb);
+  dim3 grid((cols + 64 * vec - 1) / (64 * vec), nb, nseg), block(64, 4);
+  if (dtype == VG_BF16) colsum_segments_kernel<bf16_t><<<grid, block, 0, stream>>>((const bf16_t*)x, rows, cols, (long)ld, part);
+  else colsum_segments_kernel<float><<<grid, block, 0, stream>>>((const float*)x, rows, cols, (long)ld, part);
+  launch_colsum_small(part, nb, nseg * cols, (long)nseg * cols, out, 0, stream);
+  return vg_host::check_launch("vg_colsum_segments");
+}
+
 extern "C" int vg_colsum_partials_multi(const vg_colsum_task* tasks, int n, int nb, int dtype, hipStream_t stream) {
   VG_REQUIRE(tasks != nullptr && n >= 1 && n <= VG_COLSUM_MAX_TASKS, "vg_colsum_partials_multi: n=%d (1..%d)", n,
              VG_COLSUM_MAX_TASKS);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp],
     "vg_colsum_multi": [C.POINTER(ColsumTask), _i, _vp],
     "vg_colsum_partials_multi": [C.POINTER(ColsumTask), _i, _i, _i, _vp],
+    "vg_colsum_segments": [_vp, _i, _i, _i, _i64, _vp, _i, _vp, _i, _vp],
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "vg_mask_rows": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],

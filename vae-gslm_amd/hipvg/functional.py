@@ -290,6 +290,23 @@ def colsum_partials(mats):
     return parts
 
 
+def segment_colsum(x: Tensor, nseg: int) -> Tensor:
+    """``x.view(nseg, -1, C).float().sum(1)`` for [M, C] rows (M = nseg * T) in two small launches
+    (``vg_colsum_segments``): fp32 [nseg, C]."""
+    M, Cc = x.shape
+    rows = M // nseg
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if (x.dtype not in (torch.bfloat16, torch.float32) or M % nseg or Cc % vec or x.stride(1) != 1 or x.stride(0) % vec
+            or x.data_ptr() % 16 or nseg > 65535):
+        return x.view(nseg, rows, Cc).float().sum(1)
+    nb = max(1, min(64, rows // 64))
+    part = torch.empty((nb, nseg, Cc), dtype=torch.float32, device=x.device)
+    out = torch.empty((nseg, Cc), dtype=torch.float32, device=x.device)
+    check(lib().vg_colsum_segments(ptr(x), nseg, rows, Cc, x.stride(0), ptr(part), nb, ptr(out), dtype_id(x.dtype), stream()),
+          "vg_colsum_segments")
+    return out
+
+
 def sink_colsum(p: Tensor, x: Tensor) -> None:
     """p.grad (any shape with N elements) += column sums of x[M, N]."""
     colsum(x, into=_grad_buffer(p).view(-1))
@@ -1098,7 +1115,7 @@ class ConvBlockFn(torch.autograd.Function):
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
         dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
-        dte = dv.view(-1, T, Cc).float().sum(1)
+        dte = segment_colsum(dv, dv.shape[0] // T)
         # the five small reductions of this block (conv weight / bias, norm weight / bias, c2's bias) in one launch
         g_c2b, g_c1w, g_c1b, g_nw, g_nb = vec_grads([
             (None if id(c2b) in fused_bias else c2b, parts[0] if parts and parts[0] is not None else dpre),
