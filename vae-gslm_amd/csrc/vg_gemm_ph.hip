@@ -411,6 +411,11 @@ VG_DEVICE void ring_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* 
 //   slots they take (images 2 k - 2, 2 k - 1) were last read by Y in interval k - 1, behind the barrier -- and wait
 //   before the closing barrier for what interval k + 1 reads: images <= 2 k + 6 after a phase A (vmcnt(6)),
 //   <= 2 k + 5 after a phase B (vmcnt(8)).
+// Order inside a read segment (measured, same call): fragment reads first, LDS-DMA requests after them.  With the
+// requests in front of the reads (either group) the k-major modes lose 12-35 % (dgrad->model 104 -> 119-127 us, the
+// grouped weight gradients 350 -> 448-472 us; their fragments are two ds_read_b64_tr_b16 each and sit on the critical
+// path of the next MFMA run) while the row-image mode does not move; requests after Y's MFMAs: 3-17 % slower;
+// without s_setprio around the MFMAs: no difference.
 template <bool A_TR, bool B_TR>
 VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
   constexpr int NSLOT = 10;
