@@ -555,6 +555,9 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
 #ifdef VG_LAB_STAMPS
   long long st0 = wall_clock64();
 #endif
+#ifdef VG_LAB_XCDMASK                 // lab: only the blocks of some XCDs work (timing experiment: the others exit)
+  if (((VG_LAB_XCDMASK) >> (blockIdx.x & 7) & 1) == 0) return;
+#endif
   TileCtx<A_TR, B_TR> c;
   c.init(p, blockIdx.x, blockIdx.z, wave, lane);
   f32x4 acc[8][4];                 // [a * 4 + i][b * 2 + j]; SCHED 2: [a * 4 + i][j]
