@@ -12,7 +12,8 @@ hipvg.lib()
 g = torch.Generator().manual_seed(0)
 M, N = 16000, 1024
 ts = []
-for K in (1024, 4096):
+KS = tuple(int(v) for v in os.environ.get("KS", "1024,4096").split(","))
+for K in KS:
     A = torch.randn(M, K, generator=g).to(dev).bfloat16()
     B = torch.randn(N, K, generator=g).to(dev).bfloat16()
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
@@ -24,4 +25,4 @@ for K in (1024, 4096):
     for _ in range(20): fn()
     b.record(); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b) / 20 * 1e3)
-print(os.environ.get("VG_LIB", "all XCDs").split("/")[-1], f"K=1024 {ts[0]:.1f} us, K=4096 {ts[1]:.1f} us, slope {(ts[1] - ts[0]) / 48:.3f} us per K tile")
+print(os.environ.get("VG_LIB", "all XCDs").split("/")[-1], f"K={KS[0]} {ts[0]:.1f} us, K={KS[1]} {ts[1]:.1f} us, slope {(ts[1] - ts[0]) / ((KS[1] - KS[0]) / 64):.3f} us per K tile")
