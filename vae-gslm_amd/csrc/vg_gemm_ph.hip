@@ -142,6 +142,10 @@ struct TileCtx {
       mt = first + rem % gm;
       nt = rem / gm;
     }
+#ifdef VG_LAB_SAMETILE               // lab: every block reads (and writes) tile 0 -- a full chip with no L2 misses
+    mt = VG_LAB_SAMETILE == 2 ? mt & 7 : 0;
+    nt = 0;
+#endif
     m0 = mt * BM;
     n0 = nt * BN;
     nkt = ntiles;                      // whole K tiles only (the host checks)
