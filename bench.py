@@ -370,6 +370,10 @@ def main():
                          "peak_measured": peaks["mfma_bf16_dense_tflops"],
                          "frac_of_measured": achieved / peaks["mfma_bf16_dense_tflops"],
                          "hbm_copy_measured_tb_per_s": peaks["hbm_copy_tb_per_s"], "hbm_peak_tb_per_s": 8.0,
+                         # second ceiling of a 256x256x64 LDS-DMA tile: 64 KB out of L2 per
+                         # 8.4 MFLOP = 128 FLOP/B at the L2 -> LDS level, times the ~11.5 TB/s all eight XCDs deliver
+                         # together (measured with tools/lab/kslope_small.py, xcd_mask.py); a STATIC figure
+                         "l2_to_lds_bound_tflops": 1450.0, "frac_of_l2_to_lds_bound": achieved / 1450.0,
                          "hbm_kernels": hbm_kernels,
                          "measured_on": ("one eager optimizer step right after the timed hipGraph replays"
                                          if args.graph else "the timed region"),
