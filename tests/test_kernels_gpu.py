@@ -183,7 +183,7 @@ def test_lean_epilogues_are_bitwise_the_generic_one(F, variant, mode, masked):
     bias, res, der = rnd(N, seed=2), rnd(M, N, dtype=torch.bfloat16, seed=3), rnd(M, N, dtype=torch.bfloat16, seed=4)
     lens = torch.tensor([17, 16, 1, 0, 16], dtype=torch.int32, device=dev())
     outs = {}
-    for cfg in (3, 13):
+    for cfg in (3, 13, 1):
         args = dict(tile_cfg=cfg, b_tr=(mode == "nn"))
         if kw.get("bias"): args["bias"] = bias
         if kw.get("residual"): args["residual"] = res
@@ -197,9 +197,10 @@ def test_lean_epilogues_are_bitwise_the_generic_one(F, variant, mode, masked):
         if masked: args.update(lengths=lens, T=T)
         out = F.gemm(A, B, M, N, K, **args)
         outs[cfg] = (out, aux, part[0] if part else None)
-    assert torch.equal(outs[3][0], outs[13][0])
-    if outs[3][1] is not None:
-        assert torch.equal(outs[3][1], outs[13][1])
+    for cfg in (13, 1):              # 13: every variant lean; 1 (128x128 tiles): the plain / ReLU variants lean
+        assert torch.equal(outs[3][0], outs[cfg][0]), cfg
+        if outs[3][1] is not None:
+            assert torch.equal(outs[3][1], outs[cfg][1]), cfg
     if outs[3][2] is not None:      # per-row-tile partial sums: both tile shapes have 256 rows, the summation order inside differs
         torch.testing.assert_close(outs[3][2].sum(0), outs[13][2].sum(0), atol=2e-2, rtol=1e-3)
     ref = A.float() @ (B.float() if mode == "nn" else B.float().T)

@@ -14,7 +14,7 @@
 
 namespace {
 
-template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES, bool COLSUM = false>
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES, bool COLSUM = false, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int PIECES = ((BM + BN) / 8) / NW;            // LDS-DMA instructions per wave per K tile
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(GemmParams p) {
         }
     }
   }
-  tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, wg, nwg);
+  if constexpr (EPI == EPI_GENERIC) tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, wg, nwg);
+  else tile_epilogue_lean<BM, BN, WM, WN, false, false, EPI>(p, acc, smem, m0, n0);
 }
 
 // =====================================================================================
@@ -308,10 +309,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma32_kernel(GemmParams p) {
   tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, wg, nwg);
 }
 
-template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES = 2, bool COLSUM = false>
+template <bool A_TR, bool B_TR, int BM, int BN, int WM, int WN, int STAGES = 2, bool COLSUM = false, int EPI = EPI_GENERIC>
 int launch_cfg(const GemmParams& p, int splits, hipStream_t stream) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
-  auto k = gemm_dma_kernel<A_TR, B_TR, BM, BN, WM, WN, STAGES, COLSUM>;
+  auto k = gemm_dma_kernel<A_TR, B_TR, BM, BN, WM, WN, STAGES, COLSUM, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -342,7 +343,11 @@ int launch_mode(const GemmParams& p, int cfg, int splits, hipStream_t stream) {
     if (p.colsum_out) return launch_cfg<A_TR, B_TR, 128, 128, 2, 2, 2, true>(p, splits, stream);
   }
   switch (cfg) {
-    case 1: return launch_cfg<A_TR, B_TR, 128, 128, 2, 2>(p, splits, stream);
+    case 1:
+      if constexpr (!A_TR) {     // the N <= 512 products of the conv stacks: plain / bias / residual / ReLU epilogues
+        if (lean_epilogue_of(p, splits) == EPI_PLAIN) return launch_cfg<A_TR, B_TR, 128, 128, 2, 2, 2, false, EPI_PLAIN>(p, splits, stream);
+      }
+      return launch_cfg<A_TR, B_TR, 128, 128, 2, 2>(p, splits, stream);
     case 2: return launch_cfg<A_TR, B_TR, 256, 128, 4, 2>(p, splits, stream);
     case 3: return launch_cfg<A_TR, B_TR, 256, 256, 2, 4>(p, splits, stream);
     case 4: return launch_cfg<A_TR, B_TR, 128, 256, 2, 4>(p, splits, stream);

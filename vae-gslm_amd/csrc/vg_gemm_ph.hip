@@ -759,8 +759,6 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
   else tile_epilogue_lean<256, 128, 2, 2, true, false, EPI>(p, acc, smem, c.m0, c.n0);
 }
 
-int lean_epilogue_of(const GemmParams& p, int splits);
-
 template <bool A_TR, bool B_TR, int EPI>
 int launch_duo_epi(const GemmParams& p, int splits, hipStream_t stream) {
   constexpr size_t lds = 5 * HALF_BYTES;
@@ -938,23 +936,6 @@ int launch_ph(const GemmParams& p, int splits, hipStream_t stream) {
   const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
   hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(512), lds, stream, p);
   return 0;
-}
-
-// which lean epilogue (vg_gemm_tile.h) covers this problem; EPI_GENERIC when none does
-int lean_epilogue_of(const GemmParams& p, int splits) {
-  static const int off = [] { const char* e = getenv("VG_NO_LEAN_EPI"); return e ? atoi(e) : 0; }();
-  if (off) return EPI_GENERIC;
-  if (p.out_f32 || p.accumulate || splits != 1 || p.alpha != 1.0f || p.split_ws || p.colsum_out) return EPI_GENERIC;
-  if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.lengths != nullptr && p.T < 16)) return EPI_GENERIC;
-  const int act = p.act & 15;
-  const bool save = (p.act & VG_ACT_SAVE_DERIV) != 0;
-  if (p.pre_add && !(act == VG_ACT_SILU && save)) return EPI_GENERIC;
-  if ((act == VG_ACT_NONE || act == VG_ACT_RELU) && !save && !p.aux_out && p.dact == VG_ACT_NONE) return EPI_PLAIN;
-  if (act == VG_ACT_GELU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE) return EPI_GELU_SAVE;
-  if (act == VG_ACT_SILU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE) return EPI_SILU_SAVE;
-  if (act == VG_ACT_NONE && !save && !p.aux_out && (p.dact == VG_ACT_STORED || p.dact == VG_ACT_RELU) && p.aux_in && !p.residual)
-    return EPI_DACT;
-  return EPI_GENERIC;
 }
 
 template <bool A_TR, bool B_TR>

@@ -564,4 +564,22 @@ VG_DEVICE void tile_epilogue_wgrad(const GemmParams& p, f32x4 (&acc)[BM / WM / 1
 }
 
 
+// which lean epilogue (vg_gemm_tile.h) covers this problem; EPI_GENERIC when none does
+inline int lean_epilogue_of(const GemmParams& p, int splits) {
+  static const int off = [] { const char* e = getenv("VG_NO_LEAN_EPI"); return e ? atoi(e) : 0; }();
+  if (off) return EPI_GENERIC;
+  if (p.out_f32 || p.accumulate || splits != 1 || p.alpha != 1.0f || p.split_ws || p.colsum_out) return EPI_GENERIC;
+  if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.lengths != nullptr && p.T < 16)) return EPI_GENERIC;
+  const int act = p.act & 15;
+  const bool save = (p.act & VG_ACT_SAVE_DERIV) != 0;
+  if (p.pre_add && !(act == VG_ACT_SILU && save)) return EPI_GENERIC;
+  if ((act == VG_ACT_NONE || act == VG_ACT_RELU) && !save && !p.aux_out && p.dact == VG_ACT_NONE) return EPI_PLAIN;
+  if (act == VG_ACT_GELU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE) return EPI_GELU_SAVE;
+  if (act == VG_ACT_SILU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE) return EPI_SILU_SAVE;
+  if (act == VG_ACT_NONE && !save && !p.aux_out && (p.dact == VG_ACT_STORED || p.dact == VG_ACT_RELU) && p.aux_in && !p.residual)
+    return EPI_DACT;
+  return EPI_GENERIC;
+}
+
+
 }  // namespace
