@@ -94,13 +94,14 @@ typedef struct vg_gemm_desc {
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 /* rows per output tile the launch for `desc` will use (128 or 256), 0 if it takes the register-staged kernel */
 int vg_gemm_tile_rows(const vg_gemm_desc* desc);
-/* Several weight-gradient products in ONE launch: every desc must be bf16, a_tr = b_tr = 1, fp32 C, K and K / split_k
- * multiples of 64, no epilogue beyond alpha / accumulate (split_k == 1: C += result when accumulate, else C = result;
- * split_k > 1: fp32 atomics into a C that already holds its initial value).  Replaces the four dW = dY^T X launches
- * of one Transformer layer's backward (the nn.Linear weight gradients autograd computes for
- * modules/transformer/layers.py:52,79,82,151 of the reference): 176 unsplit 256x256 tiles + 16 tiles split 4 ways fill
- * 240 CUs without the memory-side atomics that four split-K launches pay.  Returns non-zero (nothing launched) if a
- * desc does not qualify -- launch them through vg_gemm then. */
+/* Several weight-gradient products in ONE launch.  Contract (anything else is refused with a message in
+ * vg_last_error and nothing is launched -- run those through vg_gemm): every desc bf16, a_tr = b_tr = 1, fp32 C
+ * (out_f32 = 1) in 16-byte aligned rows (N % 8 == 0, ldc % 4 == 0), K a multiple of 64, split_k = 1, accumulate = 1,
+ * alpha = 1 (C += A^T B: C must hold its initial value; the launch divides the reduction among its blocks itself
+ * and combines whole-K segments with plain adds, head / tail pieces with fp32 atomics), no epilogue fields.  Replaces
+ * the four dW = dY^T X launches of one Transformer layer's backward (the nn.Linear weight gradients autograd computes
+ * for modules/transformer/layers.py:52,79,82,151 of the reference) and the two or three of a conv bottleneck block
+ * (modules/conv/layers.py): one persistent grid of 256 blocks with equal (tile, K tile) unit counts. */
 enum { VG_GROUP_MAX = 8 };
 int vg_gemm_grouped(const vg_gemm_desc* descs, int n, vg_stream_t stream);
 

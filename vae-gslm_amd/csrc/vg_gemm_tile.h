@@ -570,6 +570,11 @@ inline int lean_epilogue_of(const GemmParams& p, int splits) {
   if (off) return EPI_GENERIC;
   if (p.out_f32 || p.accumulate || splits != 1 || p.alpha != 1.0f || p.split_ws || p.colsum_out) return EPI_GENERIC;
   if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.lengths != nullptr && p.T < 16)) return EPI_GENERIC;
+  // the lean epilogues move C / residual / aux / pre_add as bf16x8 and the bias as f32x4: an output view whose first
+  // column is not a multiple of 8 (or a bias slice off a 4-float boundary) takes the element-wise generic epilogue
+  const uintptr_t ptrs16 = (uintptr_t)p.C | (uintptr_t)p.residual | (uintptr_t)p.aux_in | (uintptr_t)p.aux_out |
+                           (uintptr_t)p.pre_add | (uintptr_t)p.bias;
+  if (ptrs16 & 15) return EPI_GENERIC;
   const int act = p.act & 15;
   const bool save = (p.act & VG_ACT_SAVE_DERIV) != 0;
   if (p.pre_add && !(act == VG_ACT_SILU && save)) return EPI_GENERIC;

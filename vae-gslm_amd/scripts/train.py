@@ -70,18 +70,20 @@ def main(argv=None):
 
     module_name, cls_name = hp.trainer.identifier.rsplit(".", 1)
     trainer = getattr(importlib.import_module(module_name), cls_name)(hp).to(device)
-    if args.resume:          # weights first, so that rank 0's broadcast below starts from them
-        ck = torch.load(args.resume, map_location=device)
-        trainer.model.load_state_dict(ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck)
-        del ck
+    resume_ck = None
+    if args.resume:          # weights first, so that rank 0's broadcast below starts from them; the file is read once
+        resume_ck = torch.load(args.resume, map_location=device)
+        trainer.model.load_state_dict(resume_ck["state_dict"] if isinstance(resume_ck, dict) and "state_dict" in resume_ck
+                                      else resume_ck)
     if world > 1:   # identical replicas: broadcast rank 0's initial weights
         for p in trainer.model.parameters():
             dist.broadcast(p.data, 0)
     trainer.configure_optimizers()
     trainer.attach_reducer()
-    if args.resume and trainer.load_checkpoint(args.resume, map_location=device):
+    if args.resume and trainer.load_checkpoint(args.resume, map_location=device, ckpt=resume_ck):
         # full checkpoint: optimizer moments / step, LR schedule and global_step (hence the KL warm-up) continue
         log.info("resumed %s at optimizer step %d", args.resume, trainer.global_step)
+    resume_ck = None
     torch.autograd.set_detect_anomaly(args.detect_anomaly)
 
     data_hp = hp.data.train
@@ -103,6 +105,16 @@ def main(argv=None):
     every = int(hp.trainer.get("save_every_n_epoch", 1)) * int(hp.trainer.get("steps_per_epoch", 1000))
     keep = int(hp.trainer.get("save_top_k", 5))
     saved = []
+    if args.resume and rank == 0 and os.path.isdir(outdir):
+        # a resumed run keeps pruning the earlier run's checkpoints (Lightning's ModelCheckpoint restores its
+        # top-k list from the checkpoint): seed the list from the files already there, oldest step first
+        import re
+        found = {}
+        for name in os.listdir(outdir):
+            m = re.fullmatch(r"(epoch=\d+-step=(\d+))(-cpt)?\.ckpt", name)
+            if m:
+                found[int(m.group(2))] = os.path.join(outdir, m.group(1))
+        saved = [found[k] for k in sorted(found)]
 
     def checkpoint():
         if rank != 0:

@@ -472,15 +472,25 @@ class LVTRTrainer(BaseTrainer):
         import torch.distributed as dist
         self.sampled = 0
         acc = getattr(self, "_val_acc", None)
-        if acc is None:
-            return {}
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        nvals = 3 if self.use_tokens else 2
         if world > 1:
-            # Lightning reduces each rank's epoch MEAN with equal weights (sync_dist=True)
-            mean = acc[:-1] / acc[-1]
-            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=group)
-            mean = mean / world
+            # Lightning reduces each rank's epoch MEAN with equal weights (sync_dist=True).  EVERY rank takes part in
+            # the collective: a rank whose shard was empty (uneven validation shards, limit_val_batches) contributes
+            # zeros and a zero "has data" flag, and the mean is taken over the ranks that saw data.
+            dev = acc.device if acc is not None else next(self.model.parameters()).device
+            msg = torch.zeros(nvals + 1, dtype=torch.float32, device=dev)
+            if acc is not None and float(acc[-1]) > 0:
+                msg[:-1] = acc[:-1] / acc[-1]
+                msg[-1] = 1.0
+            dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+            if float(msg[-1]) == 0:
+                self._val_acc = None
+                return {}
+            mean = msg[:-1] / msg[-1]
         else:
+            if acc is None:
+                return {}
             mean = acc[:-1] / acc[-1]
         names = ["val/kld", "val/rec_loss"] + (["val/token_kld"] if self.use_tokens else [])
         out = {k: float(v) for k, v in zip(names, mean.cpu())}
@@ -502,11 +512,12 @@ class LVTRTrainer(BaseTrainer):
                     "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None,
                     "global_step": int(self.global_step)}, filepath)
 
-    def load_checkpoint(self, filepath: str, map_location=None) -> bool:
+    def load_checkpoint(self, filepath: str, map_location=None, ckpt=None) -> bool:
         """Load a full or a compact checkpoint.  Call after ``configure_optimizers`` / ``attach_reducer`` so the
         optimizer state lands in the bound flat buffers.  Returns True when training state was restored too
         (``fit(ckpt_path=...)`` of the reference, scripts/train.py:104)."""
-        ckpt = torch.load(filepath, map_location=map_location)
+        if ckpt is None:                 # ``ckpt``: the already loaded file (scripts.train reads it once)
+            ckpt = torch.load(filepath, map_location=map_location)
         if not (isinstance(ckpt, dict) and "state_dict" in ckpt and "global_step" in ckpt):
             self.model.load_state_dict(ckpt)
             return False

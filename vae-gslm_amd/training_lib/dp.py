@@ -50,6 +50,7 @@ class GradReducer:
         self._expected = {}            # signature -> {id(param): reports per backward pass}
         self._calibrating, self._in_pass, self._surprise, self._sig = False, False, None, None
         self._counts, self._remaining = {}, {}
+        self._next = 0                 # buckets [0, _next) are on the wire: launches go out in bucket-index order
         # measurement hooks (bench.py): event pairs around every collective on the stream it runs on, and a switch
         # that skips the collectives (the same step without its exchange: what is left is the exposed part)
         self.time_collectives = False
@@ -117,6 +118,7 @@ class GradReducer:
             self._remaining = dict(exp)
             for b in self.buckets:
                 b["pending"] = sum(1 for p in b["params"] if exp.get(id(p), 0) > 0)
+                b["ready"] = self.sync_now and b["pending"] == 0 and not b.get("launched", False)
 
     def _end_pass(self) -> None:
         if getattr(self, "_in_pass", False):
@@ -138,8 +140,9 @@ class GradReducer:
                 b["pending"] -= 1
                 if b["pending"] == 0:
                     b["pending"] = b["need"]
-                    if self.sync_now and self.world > 1:
-                        self._launch(b)
+                    if self.sync_now:          # a non-final micro-batch completes the bucket again later
+                        b["ready"] = True
+                        self._drain()
                 return
             key = id(param)
             if self._calibrating:
@@ -154,9 +157,28 @@ class GradReducer:
             if rem == 1:
                 b = self.buckets[bi]
                 b["pending"] -= 1
-                if b["pending"] == 0 and self.sync_now and self.world > 1:
-                    self._launch(b)
+                if b["pending"] == 0 and self.sync_now:
+                    b["ready"] = True
+                    self._drain()
         return hook
+
+    def _drain(self) -> None:
+        """Launch every complete bucket up to the first incomplete one.  Collectives leave in bucket-INDEX order on
+        every rank whatever order backward completed them in and whether or not this rank is still counting reports
+        for the step's signature (a counting rank launches nothing before ``flush()``, which also walks the buckets
+        in index order) -- so ranks that disagree about the calibration state still issue the same sequence of
+        collectives."""
+        if not (self.sync_now and self.world > 1):
+            return
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b.get("launched", False):
+                self._next += 1
+            elif b.get("ready", False):
+                self._launch(b)
+                self._next += 1
+            else:
+                break
 
     def _timed_allreduce(self, flat):
         if self.stub_collectives:
@@ -262,8 +284,9 @@ class GradReducer:
                 h.wait()
         self._handles.clear()
         for b in self.buckets:
-            b["handle"], b["launched"] = None, False
+            b["handle"], b["launched"], b["ready"] = None, False, False
             b["pending"] = b["need"]
+        self._next = 0
         if self.comm_stream is not None and self.overlap and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
