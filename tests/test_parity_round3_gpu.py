@@ -104,11 +104,9 @@ def test_full_config_T1000_fp32_matches_oracle(full_cfg):
 
     hipvg.set_precision("fp32")
     model = LVTR(Hparams.from_dict(copy.deepcopy(cfg)), input_dim=80)
-    msd = model.state_dict()
-    assert sorted(msd.keys()) == sorted(filled.keys())
-    with torch.no_grad():
-        for k, arr in filled.items():
-            msd[k].copy_(torch.from_numpy(arr))
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()}, strict=False)
+    # the oracle fills every parameter; what is left are the diffusion schedule's registered buffers (decoder.betas ...)
+    assert not unexpected and all(k.startswith("decoder.") and k.count(".") == 1 for k in missing), (missing, unexpected)
     model = model.cuda()
     mask = (torch.arange(T)[None] < lengths[:, None]).to(dev())
     x = TensorMask(batch["tokens"].to(dev()), mask).expand().cat(TensorMask(batch["mel"].to(dev()), mask))

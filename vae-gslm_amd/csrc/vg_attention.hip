@@ -13,6 +13,7 @@
 // a K-contiguous RowTile (operand of the score products) and a TrTile read
 // with ds_read_b64_tr_b16 (operand of the products that sum over time).
 // Scores live in the log2 domain: s2 = (q.k / 8 - slope (i - j)) * log2(e).
+#include <type_traits>
 #include "vg_common.h"
 #include "../../include/vaegslm_hip.h"
 
@@ -20,6 +21,10 @@ using namespace vg;
 
 namespace {
 
+#ifndef VG_LAB_ATTN
+#define VG_LAB_ATTN 0      // lab builds (tools/lab/variant.sh ... -DVG_LAB_ATTN=bits), results wrong, timing only.  attn2_fwd:
+#endif                     // 1 no exp2, 2 no PV products, 4 no barrier, 8 no DMA requests, 16 no S products, 32 no maxima,
+                           // 64 empty tile body; backward kernels: 256 empty tile body, 512 no DMA requests
 constexpr int DH = 64;
 constexpr int QB = 128;      // time rows owned by a block (4 waves x 32)
 constexpr int TB = 64;       // time rows staged per LDS tile
@@ -33,6 +38,29 @@ constexpr float SCALE = 0.125f;   // 1 / sqrt(64)
 #ifndef VG_ATTN_OCC
 #define VG_ATTN_OCC 2
 #endif
+
+// Block index -> ((batch, head) pair, rank of the tile inside the pair: 0 = longest sweep).
+// sched 0 (default): launch-wide longest-first order (LPT): rank-major, all pairs' longest tiles first.
+// sched 1 (VG_ATTN_SCHED=1, measured and NOT kept): all tiles of a pair dispatched back to back onto one XCD (blocks i
+// and i + 8 share an XCD under the round-robin placement) and swept from the same end, so that co-resident blocks of a
+// pair request the same K/V (Q/dO) tile at about the same time and all but one hit the XCD's L2.  It was built because
+// with LPT the blocks resident together belong to different pairs (L2 hit rate of the forward: 25 %), but the stream
+// is not what bounds these kernels (every request pointed at one L2-resident tile: 58.1 vs 59.6 us) and the lost
+// balance costs more than the hits return: forward 88 vs 65 us, backward 226 vs 210 us at B = 16, T = 1000.
+VG_DEVICE void pair_and_rank(int bid, int ntiles, int npairs, int sched, int& hb, int& rank) {
+  sched &= 1;
+  if (sched == 1 && (npairs & 7) == 0) {
+    const int j = bid >> 3;
+    hb = (j / ntiles) * 8 + (bid & 7);
+    rank = j % ntiles;
+  } else if (sched == 1) {
+    hb = bid / ntiles;
+    rank = bid % ntiles;
+  } else {
+    hb = bid % npairs;
+    rank = bid / npairs;
+  }
+}
 
 template <typename T> struct NVec { static constexpr int v = TB * DH / Traits<T>::VEC / 256; };  // 2 bf16 / 4 f32
 
@@ -68,20 +96,40 @@ VG_DEVICE void slab_store(const uint4 (&r)[NVec<T>::v], char* row_img, char* tr_
 // 4 waves: each issues pieces wave, wave + 4 of the 8 pieces (8 rows x 128 B) of an image.
 VG_DEVICE __amdgpu_buffer_rsrc_t slab_rsrc(const bf16_t* base, long row_stride, int Tn) {
   const long bytes = (long)(Tn - 1) * row_stride * 2 + DH * 2;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, (int)bytes, 0x00020000);
+  // provably wave-uniform inputs: the descriptor must live in SGPRs (it is an "s" operand of the asm DMA)
+  const uintptr_t a = (uintptr_t)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(((uintptr_t)hi << 32) | lo), 0, nb, 0x00020000);
 }
+// One LDS-DMA piece (1 KiB per wave-instruction) issued from inline asm, so that it is NOT part of hipcc's s_waitcnt
+// bookkeeping: with the builtin form the compiler treats every later LDS read that may alias the destination as
+// dependent on the DMA and drains vmcnt in the middle of the tile (s_waitcnt vmcnt(0) in front of the transposed
+// reads of the PV / dV / dK products: the NEXT tile's transfer, requested one barrier earlier, was waited for before
+// the current tile's second half could start -- its latency was exposed once per tile).  The kernels order DMA
+// against the reads themselves: a counted s_waitcnt vmcnt + s_barrier before the first read of a stage.
+// `lds_addr` must be wave-uniform; M0 is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+VG_DEVICE void dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+VG_DEVICE unsigned lds_addr_of(const char* p) { return (unsigned)(uintptr_t)LDS_PTR(const char, p); }
+
 template <bool TR>
 VG_DEVICE void slab_dma(__amdgpu_buffer_rsrc_t rsrc, char* img, long row_stride, int t0, int wave, int lane) {
+  const unsigned img_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(img));
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int piece = wave + 4 * j;
+    const int piece = wv + 4 * j;
     const int row = piece * 8 + (lane >> 3);
     const int pos = lane & 7;               // 16-byte position inside the 128-byte LDS row
     int col;
     if constexpr (!TR) col = (pos ^ ((row >> 1) & 7)) * 8;
     else col = (((pos >> 2) ^ ((row >> 1) & 1)) * 32) + (pos & 3) * 8;
     const unsigned voff = (unsigned)(((long)(t0 + row) * row_stride + col) * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(void, img + piece * 1024), 16, voff, 0, 0, 0);
+    dma16(rsrc, img_lds + piece * 1024, voff);
   }
 }
 VG_DEVICE void dma_wait_and_publish() {
@@ -143,8 +191,23 @@ VG_DEVICE void store_rows_T(T* __restrict__ dst_row, const f32x16 (&o)[2], float
     }
 }
 
-VG_DEVICE float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
-VG_DEVICE float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// lanes l and l + 32 hold the same accumulator column: combine the two halves with one v_permlane32_swap (VALU)
+// instead of a ds_bpermute round trip through the LDS crossbar.  With both operands = v the instruction returns
+// {v[l & 31], v[(l & 31) + 32]} in every lane.
+VG_DEVICE float xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+VG_DEVICE float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// v_max3_f32 without the canonicalising v_max the compiler puts in front of fmaxf on MFMA results
+VG_DEVICE float max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 template <typename T> struct LdsPlan {
   static constexpr int ROW_BYTES = sizeof(T) == 2 ? TB * 128 : TB * (DH + 1) * 4;
@@ -158,11 +221,9 @@ template <typename T> VG_DEVICE float fexp2(float x) {
 }
 
 VG_DEVICE float max16(const f32x16& s) {
-  float a = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-  float b = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
-  float c = fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11]));
-  float d = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
-  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+  const float a = max3(s[0], s[1], s[2]), b = max3(s[3], s[4], s[5]), c = max3(s[6], s[7], s[8]);
+  const float d = max3(s[9], s[10], s[11]), e = max3(s[12], s[13], s[14]);
+  return max3(max3(a, b, c), max3(d, e, s[15]), s[15]);
 }
 
 // 16 per-row constants (rows of the accumulator map) from an LDS float array
@@ -190,15 +251,17 @@ VG_DEVICE f32x16 rows16(const float* arr, int row0, int lane) {
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const float* __restrict__ slopes,
-                                                       int Tn, int H, const int* __restrict__ lengths) {
+                                                       int Tn, int H, const int* __restrict__ lengths, int sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_row = smem;
   char* v_tr = smem + LdsPlan<T>::ROW_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, longest sweeps first over the whole launch (LPT order); the tiles of one (b, h)
   // are H*B apart, i.e. on the same XCD whenever H*B is a multiple of 8, and share K/V in its L2
-  const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt, hb = blockIdx.x % HB;
-  const int qt = nqt - 1 - (int)(blockIdx.x / HB), h = hb % H, b = hb / H;
+  const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt;
+  int hb, rank;
+  pair_and_rank(blockIdx.x, nqt, HB, sched, hb, rank);
+  const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int len = lengths ? min(lengths[b], Tn) : Tn;
@@ -311,6 +374,311 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
 }
 
 // =====================================================================================
+// forward, bf16, round 3 (`attn2_fwd_kernel`): 64 queries per wave.
+//
+// Same orientation and arithmetic as attn_fwd_kernel (key on the accumulator rows, query on the lane, ALiBi row term
+// as the initial accumulator, log2-domain online softmax), re-shaped around what bounded that kernel on MI355X:
+//   * a wave owns TWO 32-query column sets, so every K fragment (ds_read_b128) and every V^T fragment (two
+//     ds_read_b64_tr_b16) feeds two MFMAs, a block of 4 waves owns 256 queries and one K/V tile (16 KB) is staged
+//     once per 256 queries: half the LDS reads, LDS-DMA requests and barriers per MFMA;
+//   * the two query sets give the scheduler two independent chains per tile: the softmax VALU work of set 0 sits
+//     beside the S MFMAs of set 1, that of set 1 beside the PV MFMAs of set 0;
+//   * K/V tiles stream through a THREE-stage ring, requested two tiles ahead by inline-asm LDS-DMA and retired by
+//     a counted `s_waitcnt vmcnt(4)` + one barrier per tile (one tile always stays in flight across the barrier);
+//   * the row sum stays per lane half until the end (no cross-half exchange per tile), the cross-half maximum is one
+//     v_permlane32_swap, the 16-register maxima are v_max3 chains;
+//   * O leaves through LDS as whole 128-byte rows (16-byte stores) instead of 8-byte pieces at a row stride.
+// Two blocks (8 waves) per CU: <= 256 VGPRs.
+// =====================================================================================
+constexpr int QW2 = 64;             // queries per wave
+constexpr int QB2 = 4 * QW2;        // queries per block
+constexpr int STAGE2 = 2 * TB * 128;   // K row image + V transposed-read image of one 64-key tile
+constexpr int NSTAGE2 = 3;
+
+template <bool DESC>
+__global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           float* __restrict__ lse, const float* __restrict__ slopes,
+                                                           int Tn, int H, const int* __restrict__ lengths, float skip_thr,
+                                                           int sched) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // 1-D grid, longest sweeps first over the whole launch (LPT order); the tiles of one (b, h) are H*B apart
+  const int nqt = (Tn + QB2 - 1) / QB2, HB = gridDim.x / nqt;
+  int hb, rank;
+  pair_and_rank(blockIdx.x, nqt, HB, sched, hb, rank);
+  const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
+  const int D = H * DH;
+  const long rs = 3L * D;
+  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int q0 = qt * QB2;
+  const int qw0 = q0 + wave * QW2;
+  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
+  T* __restrict__ obase = out + (long)b * Tn * D + h * DH;
+
+  if (q0 >= len) {   // fully padded tile: zero rows (attention.py:80 re-mask)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = qw0 + it * 8 + (lane >> 3);
+      if (row < Tn) *reinterpret_cast<uint4*>(obase + (long)row * D + (lane & 7) * 8) = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
+  const int qend = min(q0 + QB2, len);
+  const int nkt = (qend + TB - 1) / TB;
+
+  // Q fragments, pre-scaled by log2(e) / sqrt(d): the S products come out in the log2 domain
+  RowRegs<T> qf[2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) qf[qs].load(base + (long)min(qw0 + qs * 32 + (lane & 31), Tn - 1) * rs, lane);
+  const float slope = slopes[h];
+  const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
+  f32x16 o[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+  // r: the reference the exponentials of a query are taken against (log2 domain).  It is NOT the running maximum: it
+  // is set to the first tile's maximum and afterwards only raised when a tile's maximum exceeds it by more than
+  // RESCALE_THR, so that most tiles skip the O / row-sum rescale and its exp2 (probabilities stay <= 2^THR; they
+  // are floating point, so their relative precision does not depend on the reference).
+  float r[2] = {0.f, 0.f}, lp[2] = {0.f, 0.f};     // lp: row sum of THIS lane half only
+  constexpr float RESCALE_THR = 8.0f;
+  // Everything that is added to q.k enters the S product itself as a FIFTH k-step, so the score needs no VALU
+  // instruction between the MFMA and the exp2 (it was one fma per element -- a quarter of the VALU time of a loop that
+  // is VALU-bound at head dimension 64) and the chain starts from a zero accumulator (no 16-register ALiBi vector):
+  //   k slots 0, 1: K side 1, 1; Q side the per-(query, tile) constant slope2 * (tile start - first query) - r, hi + lo
+  //   k slots 2, 3: K side the ALiBi row term slope2 * (key - first key of the 32-key block), hi + lo; Q side 1, 1
+  // (two bf16 per constant: 16 mantissa bits, < 1e-3 absolute in the log2 domain).  Lanes 32..63 (k slots 8..15) carry zeros on the Q side.
+  bf16x8 kext;
+  {
+    const float rt = slope2 * (float)(lane & 31);
+    const bf16_t rhi = (bf16_t)rt, rlo = (bf16_t)(rt - (float)rhi);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kext[j] = (bf16_t)0.0f;
+    kext[0] = (bf16_t)1.0f; kext[1] = (bf16_t)1.0f; kext[2] = rhi; kext[3] = rlo;
+  }
+  const bool lowhalf = lane < 32;
+
+  // ---- addressing, hoisted: inside the loop every LDS read is a loop-invariant per-lane base + an immediate (the
+  // stage of a tile is a compile-time constant: the loop body is instantiated once per ring stage) and every DMA
+  // request is a loop-invariant per-lane source offset + the tile's byte offset.  Left to the per-tile helpers this
+  // was ~70 address instructions per tile in a loop that is bound by VALU issue.
+  int kbase[4];             // K fragment (kb, k-step s): stage + kb * 4096 + kbase[s]               (RowTile::frag)
+#pragma unroll
+  for (int st = 0; st < 4; ++st) kbase[st] = (lane & 31) * 128 + ((((2 * st + (lane >> 5)) ^ (((lane & 31) >> 1) & 7))) << 4);
+  int vbase[2];             // V^T fragment (kb, st, db): stage + 8192 + (32 kb + 16 st) * 128 + vbase[db], + 1024 for its second half (TrTile::frag<true>)
+  {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      vbase[db] = (4 * (g >> 1) + q) * 128 + ((db ^ ((q >> 1) & 1)) << 6) + ((16 * (g & 1) + 4 * pp) << 1);
+  }
+  unsigned dsrc[2][2];      // DMA source offset of this wave's piece j of the K (0) / V (1) image, without the tile offset
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave + 4 * j) * 8 + (lane >> 3), pos = lane & 7;
+    dsrc[0][j] = (unsigned)(((long)row * rs + (pos ^ ((row >> 1) & 7)) * 8) * 2);
+    dsrc[1][j] = (unsigned)(((long)row * rs + (((pos >> 2) ^ ((row >> 1) & 1)) * 32) + (pos & 3) * 8) * 2);
+  }
+  const unsigned tile_bytes = (unsigned)(TB * rs * 2);
+  const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  const __amdgpu_buffer_rsrc_t rsk = slab_rsrc(base + D, rs, Tn), rsv = slab_rsrc(base + 2 * D, rs, Tn);
+  auto issue = [&](int kt, int stage) {
+    // (sched & 2: lab switch -- every request reads tile 0, an L2-resident stream; results are wrong)
+    const unsigned tb = (sched & 2) ? 0u : (unsigned)kt * tile_bytes, dst = smem0 + stage * STAGE2 + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      dma16(rsk, dst + j * 4096, dsrc[0][j] + tb);
+      dma16(rsv, dst + 8192 + j * 4096, dsrc[1][j] + tb);
+    }
+  };
+  // Key tiles are swept from the block's last tile DOWN to tile 0: under ALiBi the nearest keys carry the largest
+  // bias, so the first tile a wave computes (its diagonal tile) fixes the reference and later tiles almost never
+  // raise it, and a tile all of whose scores lie more than `skip_thr` below the reference of every query of the wave
+  // (every probability < 2^-skip_thr of a row sum that is >= 1) is dropped after its S products: no exp2, no PV.
+  // Tile kt sits in ring stage (nkt - 1 - kt) % 3.  DESC = false sweeps upward instead (tile kt in stage kt % 3, the
+  // reference is raised as the bias grows, nothing can be skipped): the blocks of a pair then start on the same tile.
+  issue(DESC ? nkt - 1 : 0, 0);
+  if (nkt > 1) issue(DESC ? nkt - 2 : 1, 1);
+  // The Q fragments are ordinary loads the compiler counts: left alone, it waits for them at their first use INSIDE
+  // the loop with vmcnt(8..1), which on every later iteration drains the (uncounted) DMA ring.  Retire them here.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0].f[0]), "+v"(qf[0].f[1]), "+v"(qf[0].f[2]), "+v"(qf[0].f[3]),
+               "+v"(qf[1].f[0]), "+v"(qf[1].f[1]), "+v"(qf[1].f[2]), "+v"(qf[1].f[3]) :: "memory");
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[qs].f[st][j] = (bf16_t)((float)qf[qs].f[st][j] * c2);
+
+  const int kt_diag = qw0 / TB;            // the wave's first computed tile (qw0 is a multiple of 64)
+  auto tile = [&](auto jc, const int kt) {
+    constexpr int J = decltype(jc)::value;
+    const int kv0 = kt * TB;
+    // tile kt has landed (this wave's four pieces; the barrier adds everyone else's) while the next one stays in flight
+    if (DESC ? kt > 0 : kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(VG_LAB_ATTN & 4)) __builtin_amdgcn_s_barrier();
+    // the tile after next, into the stage of the previous tile, which every wave has finished reading
+    if (!(VG_LAB_ATTN & 8) && (DESC ? kt >= 2 : kt + 2 < nkt)) issue(DESC ? kt - 2 : kt + 2, (J + 2) % NSTAGE2);
+    if (kv0 > qw0) return;                 // all of this wave's queries precede the tile (causal)
+    if (VG_LAB_ATTN & 64) return;
+    const bool first = DESC ? kt == kt_diag : kt == 0;
+    const char* k_row = smem + J * STAGE2;
+    const char* v_tr = k_row + TB * 128;
+
+    bf16x8 kf[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) kf[kb][st] = *reinterpret_cast<const bf16x8*>(k_row + kb * 4096 + kbase[st]);
+    f32x16 s[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const float cb = slope2 * (float)(kv0 - qw0 - qs * 32) - r[qs];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const float cst = cb + (float)(kb * 32) * slope2;
+        const bf16_t hi = (bf16_t)cst;
+        const bf16_t lo = (bf16_t)(cst - (float)hi);
+        bf16x8 qext;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qext[j] = (bf16_t)0.0f;
+        qext[0] = lowhalf ? hi : (bf16_t)0.0f;
+        qext[1] = lowhalf ? lo : (bf16_t)0.0f;
+        qext[2] = qext[3] = lowhalf ? (bf16_t)1.0f : (bf16_t)0.0f;
+        f32x16 a = Traits<T>::mfma(kext, qext, zero16());
+        if (!(VG_LAB_ATTN & 16)) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st) a = Traits<T>::mfma(kf[kb][st], qf[qs].f[st], a);
+        } else {
+#pragma unroll
+          for (int st = 0; st < 4; ++st) asm volatile("" :: "v"(kf[kb][st]), "v"(qf[qs].f[st]));
+        }
+        s[qs][kb] = a;
+      }
+    }
+    if (kv0 == qw0) {                      // diagonal tile: mask key > query (tile start == wave's first query)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int lim = qs * 32 + (lane & 31) - kb * 32;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[qs][kb][i] = acc_row(i, lane) <= lim ? s[qs][kb][i] : -INFINITY;
+        }
+    }
+    // tile maxima relative to the references
+    float mx[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+      mx[qs] = (VG_LAB_ATTN & 32) ? s[qs][0][0] : xhalf_max(fmaxf(max16(s[qs][0]), max16(s[qs][1])));
+    if (DESC && !first && !__any(fmaxf(mx[0], mx[1]) > -skip_thr)) return;      // negligible for all 64 queries
+    bf16x8 vf[2][2][2];      // [kb][k-step of 16 keys][d block]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* at = v_tr + (32 * kb + 16 * st) * 128 + vbase[db];
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, at));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, at + 1024));
+          vf[kb][st][db] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      // the first tile sets the reference, later ones raise it rarely
+      if (first || __any(mx[qs] > RESCALE_THR)) {
+        const float delta = (first || mx[qs] > RESCALE_THR) ? mx[qs] : 0.f;
+        // first tile: O and the row sum are still zero and the maximum may be far below zero (2^-delta overflows)
+        const float sc = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        r[qs] += delta;
+        lp[qs] *= sc;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[qs][db][i] *= sc;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[qs][kb][i] -= delta;
+      }
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p0 = (VG_LAB_ATTN & 1) ? s[qs][0][i] : __builtin_amdgcn_exp2f(s[qs][0][i]);
+        const float p1 = (VG_LAB_ATTN & 1) ? s[qs][1][i] : __builtin_amdgcn_exp2f(s[qs][1][i]);
+        s[qs][0][i] = p0;
+        s[qs][1][i] = p1;
+        ps0 += p0;
+        ps1 += p1;
+      }
+      lp[qs] += ps0 + ps1;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 pb = AccOperand<T>::get(s[qs][kb], st);
+          if (!(VG_LAB_ATTN & 2)) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o[qs][db] = Traits<T>::mfma(vf[kb][st][db], pb, o[qs][db]);
+          } else {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) asm volatile("" :: "v"(vf[kb][st][db]), "v"(pb));
+          }
+        }
+    }
+  };
+  if constexpr (DESC) {
+    for (int kt = nkt - 1;;) {
+      tile(std::integral_constant<int, 0>{}, kt);
+      if (--kt < 0) break;
+      tile(std::integral_constant<int, 1>{}, kt);
+      if (--kt < 0) break;
+      tile(std::integral_constant<int, 2>{}, kt);
+      if (--kt < 0) break;
+    }
+  } else {
+    for (int kt = 0;;) {
+      tile(std::integral_constant<int, 0>{}, kt);
+      if (++kt >= nkt) break;
+      tile(std::integral_constant<int, 1>{}, kt);
+      if (++kt >= nkt) break;
+      tile(std::integral_constant<int, 2>{}, kt);
+      if (++kt >= nkt) break;
+    }
+  }
+
+  // ---- epilogue: O^T -> rows through LDS.  The last tile (tile 0) sits in stage (nkt - 1) % 3; the other two stages
+  // hold no tile any wave still reads and nothing is in flight: 2 x 16 KB = 8 KB per wave.
+  char* ow = smem + ((nkt + (wave >> 1)) % NSTAGE2) * STAGE2 + (wave & 1) * 8192;
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const float l = xhalf_sum(lp[qs]);
+    const int query = qw0 + qs * 32 + (lane & 31);
+    const float mul = query < len ? 1.f / l : 0.f;
+    const int row = qs * 32 + (lane & 31);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * (lane >> 5);
+        const bf16x4 v = {(bf16_t)(o[qs][db][4 * g] * mul), (bf16_t)(o[qs][db][4 * g + 1] * mul),
+                          (bf16_t)(o[qs][db][4 * g + 2] * mul), (bf16_t)(o[qs][db][4 * g + 3] * mul)};
+        *reinterpret_cast<bf16x4*>(ow + row * 128 + ((((d0 >> 3) ^ (row & 7))) << 4) + (d0 & 7) * 2) = v;
+      }
+    if (query < len && lane < 32)
+      lse[((long)b * H + h) * Tn + query] = (r[qs] + log2f(l) - slope2 * (float)(lane & 31)) * LN2;
+  }
+  // the rows of a wave are written and read by that wave only: no block barrier (LDS accesses of one wave stay in order)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(ow + row * 128 + ((c16 ^ (row & 7)) << 4));
+    if (qw0 + row < Tn) *reinterpret_cast<uint4*>(obase + (long)(qw0 + row) * D + c16 * 8) = v;
+  }
+}
+
+// =====================================================================================
 // backward: delta = rowsum(dO * O) per (b, h, t)
 // =====================================================================================
 template <typename T>
@@ -346,7 +714,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
                                                           const float* __restrict__ slopes, T* __restrict__ dqkv,
-                                                          int Tn, int H, const int* __restrict__ lengths) {
+                                                          int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_row = smem;
   char* v_row = smem + LdsPlan<T>::ROW_BYTES;
@@ -354,8 +722,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, longest sweeps first over the whole launch (LPT order); the tiles of one (b, h)
   // are H*B apart, i.e. on the same XCD whenever H*B is a multiple of 8, and share K/V in its L2
-  const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt, hb = blockIdx.x % HB;
-  const int qt = nqt - 1 - (int)(blockIdx.x / HB), h = hb % H, b = hb / H;
+  const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt;
+  int hb, rank;
+  pair_and_rank(blockIdx.x, nqt, HB, sched, hb, rank);
+  const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int len = lengths ? min(lengths[b], Tn) : Tn;
@@ -408,7 +778,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     const int kv0 = kt * TB;
     if constexpr (DMA) {
       dma_wait_and_publish();
-      if (kt + 1 < nkt) issue(kv0 + TB, smem + ((kt + 1) & 1) * STAGE);
+      if (!(VG_LAB_ATTN & 512) && kt + 1 < nkt) issue(kv0 + TB, smem + ((kt + 1) & 1) * STAGE);
       k_row = smem + (kt & 1) * STAGE;
       v_row = k_row + LdsPlan<T>::ROW_BYTES;
       k_tr = k_row + 2 * LdsPlan<T>::ROW_BYTES;
@@ -423,17 +793,21 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       }
     }
     if (qw0 + 31 < kv0) continue;
+    if (VG_LAB_ATTN & 256) continue;
     const bool diag = kv0 + TB - 1 > qw0;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, kinit);
-      f32x16 dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, dinit);
       if (diag) {
         const int lim = query - kv0 - kb * 32;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = acc_row(i, lane) <= lim ? s[i] : -INFINITY;
       }
       const float off = slope2 * (float)(kv0 + kb * 32 - qw0) - Lq;
+      // every probability of this 32-key block below 2^-skip_thr (of a row that sums to 1) for all 32 queries of the
+      // wave: its dS is dropped -- no dP product, no exp2, no dQ product (ALiBi: the far keys of the steep heads)
+      if (!__any(fmaf(max16(s), c2, off) > -skip_thr)) continue;
+      f32x16 dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, dinit);
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(fmaf(s[i], c2, off)) * dp[i];
 #pragma unroll
@@ -454,7 +828,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ slopes, T* __restrict__ dqkv,
-                                                           int Tn, int H, const int* __restrict__ lengths) {
+                                                           int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_row = smem;
   char* do_row = smem + LdsPlan<T>::ROW_BYTES;
@@ -462,8 +836,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   char* do_tr = q_tr + LdsPlan<T>::TR_BYTES;
   float* st = reinterpret_cast<float*>(do_tr + LdsPlan<T>::TR_BYTES);   // [2][64]: S init, dP init
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int HB = gridDim.x / ((Tn + QB - 1) / QB), hb = blockIdx.x % HB;   // low key tiles sweep the most query tiles: first
-  const int ktile = blockIdx.x / HB, h = hb % H, b = hb / H;
+  const int nkb = (Tn + QB - 1) / QB, HB = gridDim.x / nkb;   // low key tiles sweep the most query tiles: first
+  int hb, ktile;
+  pair_and_rank(blockIdx.x, nkb, HB, sched, hb, ktile);
+  const int h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int len = lengths ? min(lengths[b], Tn) : Tn;
@@ -490,7 +866,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const float* __restrict__ lse_bh = lse + ((long)b * H + h) * Tn;
   const float* __restrict__ dl_bh = delta + ((long)b * H + h) * Tn;
 
+  // query tiles are swept from the sequence's LAST tile down to the block's diagonal: the key blocks of a (batch, head)
+  // pair then start on the same tile (see pair_and_rank)
   const int qt_beg = k0 / TB, qt_end = (len + TB - 1) / TB;
+  const int nq = qt_end - qt_beg, qt_first = qt_end - 1;
   constexpr bool DMA = sizeof(T) == 2;
   constexpr int IMG = 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES;
   constexpr int STAGE = IMG + 2 * 64 * (int)sizeof(float);     // + the per-query constants of the tile
@@ -509,36 +888,51 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     a = ok ? -(lse_bh[qq] * LOG2E + slope2 * (float)(qq - k0)) / c2 : -INFINITY;
     d = ok ? -dl_bh[qq] : 0.f;
   };
-  float st_a = 0.f, st_d = 0.f;    // wave 0: constants of the NEXT tile, fetched one iteration ahead
+  // bf16 / LDS-DMA path: wave 0 fetches the RAW lse / delta of a tile two iterations ahead and turns them into the
+  // constants only when it stores them (one iteration later, behind the loop's own vmcnt(0)).  Any arithmetic on the
+  // loaded value in the iteration that issued the load makes the compiler wait for it right there -- behind the
+  // eight LDS-DMA requests of the next tile, i.e. wave 0 sat out the whole transfer once per tile.
+  auto st_raw = [&](int qs, float& a, float& d) {
+    const int qq = min(qs + tid, Tn - 1);
+    a = lse_bh[qq];
+    d = dl_bh[qq];
+  };
+  auto st_store = [&](int qs, float a_raw, float d_raw, float* dst) {
+    const int qq = qs + tid;
+    const bool ok = qq < len;
+    dst[tid] = ok ? -(a_raw * LOG2E + slope2 * (float)(qq - k0)) / c2 : -INFINITY;
+    dst[64 + tid] = ok ? -d_raw : 0.f;
+  };
+  float st_a = 0.f, st_d = 0.f;    // wave 0: raw lse / delta of the NEXT tile, fetched one iteration ahead
   if constexpr (DMA) {
     rsq = slab_rsrc(reinterpret_cast<const bf16_t*>(base), rs, Tn);
     rsd = slab_rsrc(reinterpret_cast<const bf16_t*>(dobase), D, Tn);
     if (tid < 64) {
-      st_values(qt_beg * TB, st_a, st_d);
-      float* s0 = reinterpret_cast<float*>(smem + IMG);
-      s0[tid] = st_a;
-      s0[64 + tid] = st_d;
-      if (qt_beg + 1 < qt_end) st_values((qt_beg + 1) * TB, st_a, st_d);
+      st_raw(qt_first * TB, st_a, st_d);
+      st_store(qt_first * TB, st_a, st_d, reinterpret_cast<float*>(smem + IMG));
+      if (nq > 1) st_raw((qt_first - 1) * TB, st_a, st_d);
     }
-    issue(qt_beg * TB, smem);
+    issue(qt_first * TB, smem);
+    // retire the counted prologue loads (K / V fragments, the first constants) here: left to the compiler, their
+    // waits land at the first use inside the loop as vmcnt(7..0) and drain the uncounted DMA ring on every iteration
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf.f[0]), "+v"(kf.f[1]), "+v"(kf.f[2]), "+v"(kf.f[3]), "+v"(vf.f[0]),
+                 "+v"(vf.f[1]), "+v"(vf.f[2]), "+v"(vf.f[3]), "+v"(st_a), "+v"(st_d) :: "memory");
   } else {
-    slab_load<T>(rq, base, rs, qt_beg * TB, Tn, tid);
-    slab_load<T>(rd, dobase, D, qt_beg * TB, Tn, tid);
+    slab_load<T>(rq, base, rs, qt_first * TB, Tn, tid);
+    slab_load<T>(rd, dobase, D, qt_first * TB, Tn, tid);
   }
-  for (int qt = qt_beg; qt < qt_end; ++qt) {
+  for (int it = 0; it < nq; ++it) {
+    const int qt = qt_first - it;
     const int qs0 = qt * TB;
     if constexpr (DMA) {
       dma_wait_and_publish();
-      const int sl = (qt - qt_beg) & 1;
-      if (qt + 1 < qt_end) {
+      const int sl = it & 1;
+      if (it + 1 < nq) {
         char* nx = smem + (sl ^ 1) * STAGE;
-        if (tid < 64) {              // registers were filled one iteration ago: no wait behind the DMA below
-          float* sn = reinterpret_cast<float*>(nx + IMG);
-          sn[tid] = st_a;
-          sn[64 + tid] = st_d;
-        }
-        issue(qs0 + TB, nx);
-        if (tid < 64 && qt + 2 < qt_end) st_values(qs0 + 2 * TB, st_a, st_d);
+        if (tid < 64)                // registers were filled one iteration ago: no wait behind the DMA below
+          st_store(qs0 - TB, st_a, st_d, reinterpret_cast<float*>(nx + IMG));
+        if (!(VG_LAB_ATTN & 512)) issue(qs0 - TB, nx);
+        if (tid < 64 && it + 2 < nq) st_raw(qs0 - 2 * TB, st_a, st_d);
       }
       q_row = smem + sl * STAGE;
       do_row = q_row + LdsPlan<T>::ROW_BYTES;
@@ -551,22 +945,25 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       slab_store<T, true, true>(rd, do_row, do_tr, tid);
       if (tid < 64) st_values(qs0, st[tid], st[64 + tid]);
       __syncthreads();
-      if (qt + 1 < qt_end) {
-        slab_load<T>(rq, base, rs, qs0 + TB, Tn, tid);
-        slab_load<T>(rd, dobase, D, qs0 + TB, Tn, tid);
+      if (it + 1 < nq) {
+        slab_load<T>(rq, base, rs, qs0 - TB, Tn, tid);
+        slab_load<T>(rd, dobase, D, qs0 - TB, Tn, tid);
       }
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int qb0 = qs0 + qb * 32;
       if (qb0 + 31 < kw0) continue;   // all queries precede this wave's keys
+      if (VG_LAB_ATTN & 256) continue;
       f32x16 s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, rows16(st, qb * 32, lane));
-      f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, rows16(st + 64, qb * 32, lane));
       if (qb0 < kw0 + 31) {            // diagonal block: mask query < key
         const int lim = key - qb0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = acc_row(i, lane) >= lim ? s[i] : -INFINITY;
       }
+      // all 32 x 32 probabilities of this block below 2^-skip_thr: no dP product, no exp2, no dV / dK products
+      if (!__any(fmaf(max16(s), c2, kl) > -skip_thr)) continue;
+      f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, rows16(st + 64, qb * 32, lane));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s[i] = fexp2<T>(fmaf(s[i], c2, kl));
@@ -630,15 +1027,50 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const T* __restrict__ q
   out[(long)b * D + h * DH + lane] = from_f32<T>(o / lg);
 }
 
+// integer switches for A/B measurements, read on every launch (cheap: a getenv per launch is ~50 ns)
+static int attn_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+// VG_ATTN_V1=1 selects the round-1/2 forward kernel for bf16 as well (A/B measurements)
+static bool attn_v1() {
+  static const bool v = [] { const char* e = getenv("VG_ATTN_V1"); return e && atoi(e) != 0; }();
+  return v;
+}
+
+// Tiles whose every probability is below 2^-thr of its row's sum are dropped by the bf16 kernels (ALiBi makes the far
+// key tiles of the steep heads negligible).  VG_ATTN_SKIP=<thr> changes the threshold, VG_ATTN_SKIP=0 keeps every tile.
+static float attn_skip_thr() {
+  static const float v = [] {
+    const char* e = getenv("VG_ATTN_SKIP");
+    const float t = e ? (float)atof(e) : 20.0f;
+    return t > 0.f ? t : INFINITY;
+  }();
+  return v;
+}
+
 template <typename T>
 int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tn, int H,
                const int32_t* lengths, hipStream_t stream) {
-  const size_t lds = (sizeof(T) == 2 ? 2 : 1) * (LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
-  dim3 grid(((Tn + QB - 1) / QB) * H * B);
   // algorithmic work: causal-exact QK^T + PV, 2*2*64 FLOP per (query, key <= query) pair
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_FWD, 256.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
+  if constexpr (sizeof(T) == 2) {
+    if (!attn_v1()) {
+      dim3 grid2(((Tn + QB2 - 1) / QB2) * H * B);
+      if (attn_env("VG_ATTN_FWD_DESC", 1))
+        hipLaunchKernelGGL(attn2_fwd_kernel<true>, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
+                           lse, slopes, Tn, H, lengths, attn_skip_thr(), attn_env("VG_ATTN_SCHED", 0));
+      else
+        hipLaunchKernelGGL(attn2_fwd_kernel<false>, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
+                           lse, slopes, Tn, H, lengths, attn_skip_thr(), attn_env("VG_ATTN_SCHED", 0));
+      vg_host::prof_end(tok, stream);
+      return vg_host::check_launch("vg_attn_fwd");
+    }
+  }
+  const size_t lds = (sizeof(T) == 2 ? 2 : 1) * (LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
+  dim3 grid(((Tn + QB - 1) / QB) * H * B);
   hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
-                     lengths);
+                     lengths, attn_env("VG_ATTN_SCHED", 0));
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_fwd");
 }
@@ -653,8 +1085,9 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
                      (const T*)out, (const T*)dout, delta, B, Tn, H);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   const size_t lds_q = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
+  const float skip = sizeof(T) == 2 ? attn_skip_thr() : INFINITY;     // the fp32 parity path keeps every tile
   hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
-                     delta, slopes, (T*)dqkv, Tn, H, lengths);
+                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, attn_env("VG_ATTN_SCHED", 0));
   const size_t lds_k = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float));
   static bool attr[2] = {false, false};
   if (!attr[sizeof(T) == 2]) {
@@ -663,7 +1096,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     attr[sizeof(T) == 2] = true;
   }
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, dim3(256), lds_k, stream, (const T*)qkv, (const T*)dout, lse,
-                     delta, slopes, (T*)dqkv, Tn, H, lengths);
+                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, attn_env("VG_ATTN_SCHED", 0));
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_bwd");
 }
