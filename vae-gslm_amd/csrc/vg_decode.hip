@@ -69,32 +69,57 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
 #pragma unroll
   for (int m = 0; m < MM; ++m) sq[m] = 0.f;
   for (int k0 = wave * RCHUNK + lane * 8; k0 < K; k0 += nwaves * RCHUNK) {
-    float wv[RC][8];
+    // every load of the step is requested before the first FMA: the RC weight rows, the MM input rows (row index
+    // clamped to M - 1: no per-row branch -- with `if (m < M)` around each row's load the compiler waited for every
+    // row separately, eight dependent L2 round trips per launch) and the norm scale: ONE memory round trip
+    float wv[RC][8], gv[8];
 #pragma unroll
     for (int c = 0; c < RC; ++c) {
       const int n = min(n0 + c, N - 1);
       Ld8<T>::get(w + (long)n * ldw + k0, wv[c]);
     }
-    float gv[8];
     if (norm_scale) Ld8<float>::get(norm_scale + k0, gv);
+    if constexpr (MM <= 8) {
+      float xv[MM][8];
 #pragma unroll
-    for (int m = 0; m < MM; ++m) {
-      if (m < M) {
-        float xv[8];
-        Ld8<T>::get(x + (long)m * ldx + k0, xv);
+      for (int m = 0; m < MM; ++m) Ld8<T>::get(x + (long)min(m, M - 1) * ldx + k0, xv[m]);
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
         if (norm_scale) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            sq[m] = fmaf(xv[e], xv[e], sq[m]);
-            xv[e] *= gv[e];
+            sq[m] = fmaf(xv[m][e], xv[m][e], sq[m]);
+            xv[m][e] *= gv[e];
           }
         }
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
           float a = v[m * RC + c];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a = fmaf(xv[e], wv[c][e], a);
+          for (int e = 0; e < 8; ++e) a = fmaf(xv[m][e], wv[c][e], a);
           v[m * RC + c] = a;
+        }
+      }
+    } else {        // 16 rows: 128 accumulators leave no registers for more than one input row at a time
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        if (m < M) {
+          float xv[8];
+          Ld8<T>::get(x + (long)m * ldx + k0, xv);
+          if (norm_scale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              sq[m] = fmaf(xv[e], xv[e], sq[m]);
+              xv[e] *= gv[e];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < RC; ++c) {
+            float a = v[m * RC + c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(xv[e], wv[c][e], a);
+            v[m * RC + c] = a;
+          }
         }
       }
     }
@@ -150,97 +175,112 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
 // one block of 4 waves per (b, h): append this step's k/v rows to the cache at pos[b], then
 // softmax(q.k / 8 - slope (n - 1 - j)) v over the n = pos[b] + 1 cached frames.
 //  lanes = 8 cached frames x 8 chunks of 8 head channels: one wave-instruction reads 8 whole 128-byte cache rows
-//  (16 bytes per lane), a score is 8 FMAs per lane + 3 shuffles over the chunk lanes, and the weighted value sum
-//  keeps 8 channels per lane and folds the 8 frame lanes once at the end.  Two passes (scores to LDS, exact max
-//  and sum, then the value sum): the softmax is the plain one, not an online rescaling chain.
-//  dynamic LDS: Tmax scores + 4 x 64 partial outputs + 8 reduction words
+//  (16 bytes per lane).  Round 3: ONE pass with the loads of a whole chunk of frames in flight.  The round-2 kernel
+//  walked the cache twice in loops with a single dependent 16-byte load per lane and iteration (n / 32 memory round
+//  trips per pass, three block barriers, the new row written to the cache and read back): 24 us at 500 cached
+//  frames for 90 KB of cache.  Here every lane group (wave, frame slot) owns the frames j = 32 i + 8 wave + slot,
+//  requests CH of them at once (K and V rows together: 2 CH loads in flight per lane, the new frame's rows straight
+//  from the qkv row), keeps its own running maximum / sum / 8-channel value sum (online softmax per lane group, a
+//  rescale only when the chunk raises the maximum) and the 32 lane groups meet once at the end: three shuffle steps
+//  inside the wave, one LDS exchange across the four waves, ONE block barrier.
+//  static LDS: 4 x (64 + 2) floats
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
                                                                  T* __restrict__ vc, T* __restrict__ out,
                                                                  const float* __restrict__ slopes,
                                                                  const int* __restrict__ pos, int Tmax, int H) {
-  constexpr int DH = 64;
-  extern __shared__ __attribute__((aligned(16))) float dsm[];
-  float* sc = dsm;                       // [Tmax] scores, then probabilities
-  float* part = dsm + Tmax;              // [4][64] per-wave value sums
-  float* red = part + 4 * DH;            // [8] block reductions
+  constexpr int DH = 64, CH = 6;
+  __shared__ float part[4][DH + 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x, b = blockIdx.y;
   const int D = H * DH;
   const int p0 = min(pos[b], Tmax - 1);
   const T* __restrict__ row = qkv + (long)b * 3 * D + h * DH;
   const long cbase = ((long)b * Tmax) * D + h * DH;
-  if (wave == 0) {
+  if (wave == 0) {                                  // the cache rows of this frame, for the steps to come
     kc[cbase + (long)p0 * D + lane] = row[D + lane];
     vc[cbase + (long)p0 * D + lane] = row[2 * D + lane];
   }
-  __syncthreads();                                  // the new cache rows are visible to the whole block
   const int n = p0 + 1;
   const int sub = lane >> 3, ch = lane & 7;         // cached frame inside a group of 8, channel chunk
   float q8[8];
   Ld8<T>::get(row + ch * 8, q8);
+  const float slope = slopes[h] * 1.44269504088896340736f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) q8[e] *= 0.125f;
-  const float slope = slopes[h];
-  // ---- scores
-  float mloc = -INFINITY;
-  for (int j0 = wave * 8; j0 < n; j0 += 32) {
-    const int j = j0 + sub;
-    float s = 0.f;
-    if (j < n) {
-      float k8[8];
-      Ld8<T>::get(kc + cbase + (long)j * D + ch * 8, k8);
+  for (int e = 0; e < 8; ++e) q8[e] *= 0.125f * 1.44269504088896340736f;     // log2 domain
+  float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = wave * 8 + sub; j0 < n; j0 += 32 * CH) {
+    float k8[CH][8], v8[CH][8];
+    // all rows of the chunk are requested before the first one is used; frame p0 comes from the qkv row itself
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(q8[e], k8[e], s);
+    for (int c = 0; c < CH; ++c) {
+      const int j = j0 + 32 * c;
+      const int jc = min(j, n - 1);
+      const T* kp = jc == p0 ? row + D + ch * 8 : kc + cbase + (long)jc * D + ch * 8;
+      const T* vp = jc == p0 ? row + 2 * D + ch * 8 : vc + cbase + (long)jc * D + ch * 8;
+      Ld8<T>::get(kp, k8[c]);
+      Ld8<T>::get(vp, v8[c]);
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (j < n) {
-      s -= slope * (float)(n - 1 - j);
-      if (ch == 0) sc[j] = s;
-      mloc = fmaxf(mloc, s);
-    }
-  }
-  mloc = wave_max(mloc);
-  if (lane == 0) red[wave] = mloc;
-  __syncthreads();
-  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  // ---- probabilities and their sum
-  float lsum = 0.f;
-  for (int j = tid; j < n; j += 256) {
-    const float pj = expf(sc[j] - mx);
-    sc[j] = pj;
-    lsum += pj;
-  }
-  lsum = wave_sum(lsum);
-  if (lane == 0) red[4 + wave] = lsum;
-  __syncthreads();
-  const float den = red[4] + red[5] + red[6] + red[7];
-  // ---- weighted value sum
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int j0 = wave * 8; j0 < n; j0 += 32) {
-    const int j = j0 + sub;
-    if (j < n) {
-      const float pj = sc[j];
-      float v8[8];
-      Ld8<T>::get(vc + cbase + (long)j * D + ch * 8, v8);
+    float sc[CH], cmax = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, v8[e], acc[e]);
+    for (int c = 0; c < CH; ++c) {
+      float t = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t = fmaf(q8[e], k8[c][e], t);
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      const int j = j0 + 32 * c;
+      sc[c] = j < n ? t - slope * (float)(n - 1 - j) : -INFINITY;
+      cmax = fmaxf(cmax, sc[c]);
+    }
+    if (cmax > m) {                                  // (the first chunk always has a valid frame: j0 < n)
+      const float f = exp2f(m - cmax);
+      l *= f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= f;
+      m = cmax;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float pj = exp2f(sc[c] - m);
+      l += pj;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, v8[c][e], acc[e]);
     }
   }
+  // ---- the 8 frame slots of the wave (lanes 8 apart share a channel chunk)
+  float mw = m;
+  mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
+  mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+  mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+  const float f = m == -INFINITY ? 0.f : exp2f(m - mw);      // a slot that owned no frame contributes nothing
+  l *= f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    acc[e] += __shfl_xor(acc[e], 8, 64);
-    acc[e] += __shfl_xor(acc[e], 16, 64);
-    acc[e] += __shfl_xor(acc[e], 32, 64);
+  for (int e = 0; e < 8; ++e) acc[e] *= f;
+#pragma unroll
+  for (int o = 8; o <= 32; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
   if (sub == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[wave * DH + ch * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) part[wave][ch * 8 + e] = acc[e];
+    if (ch == 0) {
+      part[wave][DH] = mw;
+      part[wave][DH + 1] = l;
+    }
   }
   __syncthreads();
-  if (tid < DH)
-    out[(long)b * D + h * DH + tid] = from_f32<T>((part[tid] + part[DH + tid] + part[2 * DH + tid] + part[3 * DH + tid]) / den);
+  if (tid < DH) {
+    const float m0 = part[0][DH], m1 = part[1][DH], m2 = part[2][DH], m3 = part[3][DH];
+    const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float f0 = m0 == -INFINITY ? 0.f : exp2f(m0 - mx), f1 = m1 == -INFINITY ? 0.f : exp2f(m1 - mx);
+    const float f2 = m2 == -INFINITY ? 0.f : exp2f(m2 - mx), f3 = m3 == -INFINITY ? 0.f : exp2f(m3 - mx);
+    const float den = part[0][DH + 1] * f0 + part[1][DH + 1] * f1 + part[2][DH + 1] * f2 + part[3][DH + 1] * f3;
+    const float num = part[0][tid] * f0 + part[1][tid] * f1 + part[2][tid] * f2 + part[3][tid] * f3;
+    out[(long)b * D + h * DH + tid] = from_f32<T>(num / den);
+  }
 }
 
 // frame embedding of the step: out[b][c] = E[id_b][c] + relu(Wf[c][:] . z_b + bf[c])   (one wave per
@@ -344,20 +384,13 @@ extern "C" int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache
                                      const int32_t* pos, int B, int Tmax, int H, int dtype, hipStream_t stream) {
   VG_REQUIRE(B > 0 && Tmax > 0 && H > 0, "vg_attn_decode_append: empty problem");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_decode_append: bad dtype %d", dtype);
-  VG_REQUIRE(Tmax <= 32000, "vg_attn_decode_append: Tmax = %d frames exceed the score buffer (32000)", Tmax);
   dim3 grid(H, B);
-  const size_t lds = ((size_t)Tmax + 4 * 64 + 8) * sizeof(float);
-  if (dtype == VG_BF16) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_append_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    attn_decode_append_kernel<bf16_t><<<grid, dim3(256), lds, stream>>>((const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
-                                                                      (bf16_t*)out, slopes, pos, Tmax, H);
-  } else {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_append_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    attn_decode_append_kernel<float><<<grid, dim3(256), lds, stream>>>((const float*)qkv, (float*)kcache, (float*)vcache,
-                                                                     (float*)out, slopes, pos, Tmax, H);
-  }
+  if (dtype == VG_BF16)
+    attn_decode_append_kernel<bf16_t><<<grid, dim3(256), 0, stream>>>((const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+                                                                    (bf16_t*)out, slopes, pos, Tmax, H);
+  else
+    attn_decode_append_kernel<float><<<grid, dim3(256), 0, stream>>>((const float*)qkv, (float*)kcache, (float*)vcache,
+                                                                   (float*)out, slopes, pos, Tmax, H);
   return vg_host::check_launch("vg_attn_decode_append");
 }
 
