@@ -169,6 +169,12 @@ def main():
     ap.add_argument("--comm", default="torch", choices=("torch", "abi"),
                     help="gradient all-reduce through torch.distributed (nccl = RCCL) or through vg_allreduce_bucket")
     ap.add_argument("--graph", type=int, default=1, help="replay each micro-step as a hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--graph-bucket-mb", type=float, default=None,
+                    help="N > 1, hipGraph mode: size of the gradient messages (hip.graph_bucket_mb of the yaml, 256)")
+    ap.add_argument("--graph-cut-layers", default=None,
+                    help="N > 1, hipGraph mode: comma-separated Transformer layers below which the micro-step is cut into "
+                         "separately replayed graphs (hip.graph_cut_layer, default 12,8,4); 'none' = one graph")
+    ap.add_argument("--bucket-mb", type=float, default=None, help="N > 1, eager mode: gradient bucket size (hip.bucket_mb, 50)")
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN, help="frames per sequence (BASELINE config 5: 2000)")
     ap.add_argument("--coalesce", type=int, default=1,
                     help="1 (default, = hip.coalesce_accumulation of the yaml): the micro-batches of an accumulation "
@@ -217,6 +223,13 @@ def main():
     hp.hip.graph = bool(args.graph)
     hp.hip.coalesce_accumulation = bool(args.coalesce)
     hp.hip.comm = args.comm
+    if args.graph_bucket_mb is not None:
+        hp.hip.graph_bucket_mb = args.graph_bucket_mb
+    if args.bucket_mb is not None:
+        hp.hip.bucket_mb = args.bucket_mb
+    if args.graph_cut_layers is not None:
+        hp.hip.graph_cut_layer = [] if args.graph_cut_layers.lower() == "none" else \
+            [int(v) for v in args.graph_cut_layers.split(",") if v]
     torch.manual_seed(1234)
     trainer = LVTRTrainer(hp).to(device)
     if world > 1:
@@ -329,14 +342,20 @@ def main():
                 hbm_kernels[k] = {"launches": n, "avg_us": 1e3 * ms / n, "gb_per_s": nbytes / (ms * 1e-3) / 1e9}
         hipvg.prof_enable(False)
         achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
+        a_ms = a_work = 0.0
+        for k in ("attn_fwd", "attn_bwd"):
+            if k in kinds:
+                a_ms += kinds[k]["launches"] * kinds[k]["avg_us"] * 1e-3
+                a_work += kinds[k]["tflops"] * 1e12 * kinds[k]["launches"] * kinds[k]["avg_us"] * 1e-6
+        path_tflops = (tot_work + a_work) / ((tot_ms + a_ms) * 1e-3) / 1e12 if tot_ms + a_ms else 0.0
         peaks = hipvg.probe_peaks(device)          # this box, this run: register-fed MFMA chains and a 1 GiB copy
         # HBM-side bytes per launch of the same kernel family: bench.py cannot collect PMC counters itself, so
         # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
         # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v9.json), valid for the default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
         if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v9.json")
+            pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
         if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16" and args.coalesce and not args.ragged:
             with open(pmc) as f:
                 traffic = json.load(f)["bf16_gemm_family"]["traffic_bytes_per_launch"]
@@ -370,10 +389,8 @@ def main():
                          "peak_measured": peaks["mfma_bf16_dense_tflops"],
                          "frac_of_measured": achieved / peaks["mfma_bf16_dense_tflops"],
                          "hbm_copy_measured_tb_per_s": peaks["hbm_copy_tb_per_s"], "hbm_peak_tb_per_s": 8.0,
-                         # second ceiling of a 256x256x64 LDS-DMA tile: 64 KB out of L2 per
-                         # 8.4 MFLOP = 128 FLOP/B at the L2 -> LDS level, times the ~11.5 TB/s all eight XCDs deliver
-                         # together (measured with tools/lab/kslope_small.py, xcd_mask.py); a STATIC figure
-                         "l2_to_lds_bound_tflops": 1450.0, "frac_of_l2_to_lds_bound": achieved / 1450.0,
+                         # the north_star's gate: bf16 GEMMs and attention kernels together (causal-exact FLOP)
+                         "attn_gemm_path_tflops": path_tflops, "attn_gemm_path_frac": path_tflops / (PEAK_BF16 / 1e12),
                          "hbm_kernels": hbm_kernels,
                          "measured_on": ("one eager optimizer step right after the timed hipGraph replays"
                                          if args.graph else "the timed region"),
@@ -390,8 +407,15 @@ def main():
                             "allreduce_bytes_per_step": comm["allreduce_bytes"] / args.steps,
                             "collectives_per_step": comm["collectives"] / args.steps,
                             "comm_exposed_ms": comm_exposed_ms,
+                            "graph_mode": bool(args.graph),
+                            "graph_bucket_mb": hp.hip.get("graph_bucket_mb", None),
+                            "graph_cut_layers": list(getattr(trainer, "graph_cuts", [])) if args.graph else None,
+                            "eager_bucket_mb": hp.hip.get("bucket_mb", None),
+                            "predicted_exposed_ms_at_8_gpus": 1.9,
                             "note": "allreduce_ms: events on the communication stream (rank 0); comm_exposed_ms: "
-                                    "ms_per_step minus the same steps with the collectives skipped"}
+                                    "ms_per_step minus the same steps with the collectives skipped; "
+                                    "predicted_exposed_ms_at_8_gpus: DESIGN.md section 5 (the last 24 % of 908 MB at "
+                                    "~7 x 45 GB/s effective + the pipelined AdamW tail), to be falsified by the first 8-GPU run"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

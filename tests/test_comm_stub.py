@@ -1,0 +1,122 @@
+"""The library's RCCL binding (csrc/vg_comm.hip, hipvg/comm.py) against a test double of librccl (tests/stubs/
+fake_rccl.c, selected through VG_RCCL_LIB): order and arguments of the RCCL calls, error propagation, teardown and
+re-initialisation, and the two-rank id hand-off of ``hipvg.comm.init`` over a gloo group -- everything about
+``hip.comm=abi`` that can be checked without two GPUs.  CPU only."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "vae-gslm_amd")
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", out, os.path.join(ROOT, "tests", "stubs", "fake_rccl.c")], check=True)
+    from hipvg.build import build
+    build()
+    return out
+
+
+def run(code, env_extra, nproc=1, tmp=None):
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT, **env_extra)
+    if nproc == 1:
+        return subprocess.run([sys.executable, "-c", textwrap.dedent(code)], env=env, capture_output=True, text=True, timeout=180)
+    script = os.path.join(tmp, "two_rank.py")
+    with open(script, "w") as f:
+        f.write(textwrap.dedent(code))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                           "--master-addr", "127.0.0.1", "--master-port", "29731", script],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+SINGLE = """
+import ctypes, hipvg
+L = hipvg.lib()
+fake = ctypes.CDLL(__import__('os').environ['VG_RCCL_LIB'])
+fake.fake_rccl_log.restype = ctypes.c_char_p
+log = lambda: fake.fake_rccl_log().decode()
+buf = (ctypes.c_uint8 * 128)()
+assert L.vg_allreduce_bucket(ctypes.c_void_p(4096), 16, 0, 1, None) != 0 and 'vg_comm_init' in hipvg.last_error()
+assert log() == '', log()                                  # nothing reached RCCL before a communicator exists
+assert L.vg_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p), 128) == 0
+assert bytes(buf)[:4] == bytes([3, 10, 17, 24])
+assert L.vg_comm_init(1, 2, ctypes.cast(buf, ctypes.c_void_p), 128) == 0 and L.vg_comm_world() == 2
+assert L.vg_comm_init(1, 2, ctypes.cast(buf, ctypes.c_void_p), 128) != 0 and 'already initialised' in hipvg.last_error()
+x = (ctypes.c_float * 16)()
+assert L.vg_allreduce_bucket(ctypes.cast(x, ctypes.c_void_p), 16, 0, 1, None) == 0      # fp32, mean, in place, live comm
+assert L.vg_allreduce_bucket(ctypes.cast(x, ctypes.c_void_p), 16, 1, 0, None) == 0      # bf16, sum
+assert L.vg_allreduce_bucket(ctypes.cast(x, ctypes.c_void_p), 16, 5, 0, None) != 0      # bad dtype: refused before RCCL
+assert L.vg_comm_destroy() == 0 and L.vg_comm_world() == 0
+assert L.vg_comm_destroy() == 0                                                           # idempotent
+assert L.vg_allreduce_bucket(ctypes.cast(x, ctypes.c_void_p), 16, 0, 1, None) != 0      # after teardown: refused again
+assert L.vg_comm_init(0, 1, ctypes.cast(buf, ctypes.c_void_p), 128) == 0 and L.vg_comm_world() == 1   # re-initialisation
+assert L.vg_comm_destroy() == 0
+assert log() == 'GetUniqueId;CommInitRank:1/2;AllReduce:7,4,I,L;AllReduce:9,0,I,L;CommDestroy;CommInitRank:0/1;CommDestroy;', log()
+print('ok')
+"""
+
+
+def test_rccl_call_sequence_and_teardown(fake_rccl):
+    r = run(SINGLE, {"VG_RCCL_LIB": fake_rccl})
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+FAIL = """
+import ctypes, hipvg
+L = hipvg.lib()
+buf = (ctypes.c_uint8 * 128)()
+assert L.vg_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p), 128) == 0
+assert L.vg_comm_init(0, 2, ctypes.cast(buf, ctypes.c_void_p), 128) == 0
+x = (ctypes.c_float * 16)()
+assert L.vg_allreduce_bucket(ctypes.cast(x, ctypes.c_void_p), 16, 0, 1, None) != 0
+assert 'ncclAllReduce' in hipvg.last_error() and 'all-reduce refused' in hipvg.last_error(), hipvg.last_error()
+assert L.vg_comm_world() == 2                 # a failed collective does not tear the communicator down
+assert L.vg_comm_destroy() == 0
+print('ok')
+"""
+
+
+def test_rccl_errors_carry_the_library_message(fake_rccl):
+    r = run(FAIL, {"VG_RCCL_LIB": fake_rccl, "FAKE_RCCL_FAIL": "allreduce"})
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    r = run("import ctypes, hipvg\nL = hipvg.lib()\nb = (ctypes.c_uint8 * 128)()\n"
+            "assert L.vg_comm_init(0, 2, ctypes.cast(b, ctypes.c_void_p), 128) != 0\n"
+            "assert 'ncclCommInitRank' in hipvg.last_error() and L.vg_comm_world() == 0\nprint('ok')\n",
+            {"VG_RCCL_LIB": fake_rccl, "FAKE_RCCL_FAIL": "init"})
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+TWO_RANK = """
+import ctypes, os
+import torch.distributed as dist
+import hipvg
+from hipvg import comm
+dist.init_process_group('gloo')
+rank = dist.get_rank()
+fake = ctypes.CDLL(os.environ['VG_RCCL_LIB'])
+fake.fake_rccl_log.restype = ctypes.c_char_p
+fake.fake_rccl_last_id.restype = ctypes.POINTER(ctypes.c_uint8)
+comm.init(rank, 2)                      # rank 0 draws the id, the gloo group carries it, both ranks create their communicator
+assert comm.world() == 2
+log = fake.fake_rccl_log().decode()
+assert log == ('GetUniqueId;' if rank == 0 else '') + f'CommInitRank:{rank}/2;', log
+ident = bytes(fake.fake_rccl_last_id()[:128])
+assert ident[:4] == bytes([3, 10, 17, 24]) and ident[127] == (127 * 7 + 3) % 256      # rank 1 received rank 0's id
+comm.init(rank, 2)                      # same world: no second communicator
+assert fake.fake_rccl_log().decode() == log
+comm.destroy()
+assert comm.world() == 0
+dist.barrier()
+dist.destroy_process_group()
+print('ok', rank)
+"""
+
+
+def test_two_rank_id_handoff_over_gloo(fake_rccl, tmp_path):
+    r = run(TWO_RANK, {"VG_RCCL_LIB": fake_rccl, "MASTER_ADDR": "127.0.0.1"}, nproc=2, tmp=str(tmp_path))
+    assert r.returncode == 0 and "ok 0" in r.stdout and "ok 1" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

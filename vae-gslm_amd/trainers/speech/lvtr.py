@@ -108,6 +108,7 @@ class LVTRTrainer(BaseTrainer):
         cuts = [c for c in cuts if 0 < c < nl]
         seg_env = os.environ.get("VG_GRAPH_SEGMENTS", "2")       # "1": one graph; "force": segmented on one rank too
         self._segmented = bool(self.use_graph and (world > 1 or seg_env == "force") and cuts and seg_env != "1")
+        self.graph_cuts = list(cuts) if self._segmented else []      # reported by bench.py's comm block
         boundaries = ()
         if self._segmented:     # a bucket ends at every cut
             boundaries = tuple(list(stack.layers[c - 1].parameters())[-1] for c in cuts)
