@@ -162,6 +162,16 @@ VG_DEVICE f32x16 mma_row_regs(const char* row_img, int row, const RowRegs<T>& b,
   return acc;
 }
 
+// the same product with the transposed fragments read out of a ROW image (bf16 backward kernels: K, Q and dO are
+// staged once instead of twice -- a third less LDS-DMA traffic for dQ, half for dK / dV)
+VG_DEVICE f32x16 mma_tr_acc_rowimg(const char* row_img, int k0, int db, const f32x16& x, int lane, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < AccOperand<bf16_t>::STEPS; ++s)
+    acc = Traits<bf16_t>::mfma(RowTile<bf16_t, DH>::template tr_frag<true>(row_img, k0, db * 32, s, lane),
+                               AccOperand<bf16_t>::get(x, s), acc);
+  return acc;
+}
+
 // acc[d-block db] += (tr image)^T[d][time k0..k0+31] . X[time][lane]
 template <typename T>
 VG_DEVICE f32x16 mma_tr_acc(const char* tr_img, int k0, int db, const f32x16& x, int lane, f32x16 acc) {
@@ -763,8 +773,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   __amdgpu_buffer_rsrc_t rsk, rsv;
   auto issue = [&](int t0, char* st) {
     slab_dma<false>(rsk, st, rs, t0, wave, lane);
-    slab_dma<false>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);
-    slab_dma<true>(rsk, st + 2 * LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);
+    slab_dma<false>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);      // (K^T fragments come out of the K row image)
   };
   if constexpr (DMA) {
     rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tn);
@@ -811,7 +820,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(fmaf(s[i], c2, off)) * dp[i];
 #pragma unroll
-      for (int db = 0; db < 2; ++db) dq[db] = mma_tr_acc<T>(k_tr, kb * 32, db, s, lane, dq[db]);
+      for (int db = 0; db < 2; ++db) {
+        if constexpr (DMA) dq[db] = mma_tr_acc_rowimg(k_row, kb * 32, db, s, lane, dq[db]);
+        else dq[db] = mma_tr_acc<T>(k_tr, kb * 32, db, s, lane, dq[db]);
+      }
     }
   }
   if (query < Tn) store_rows_T<T>(dqbase + (long)query * rs, dq, SCALE, lane);
@@ -877,9 +889,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   __amdgpu_buffer_rsrc_t rsq, rsd;
   auto issue = [&](int t0, char* sg) {
     slab_dma<false>(rsq, sg, rs, t0, wave, lane);
-    slab_dma<false>(rsd, sg + LdsPlan<T>::ROW_BYTES, D, t0, wave, lane);
-    slab_dma<true>(rsq, sg + 2 * LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);
-    slab_dma<true>(rsd, sg + 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES, D, t0, wave, lane);
+    slab_dma<false>(rsd, sg + LdsPlan<T>::ROW_BYTES, D, t0, wave, lane);       // (Q^T / dO^T fragments come out of the row images)
   };
   // per-query constants of a tile: S init = -(lse2 + slope2 (q - k0)) / c2 (-inf for padded queries), dP init = -delta
   auto st_values = [&](int qs, float& a, float& d) {
@@ -971,8 +981,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       }
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        dv[db] = mma_tr_acc<T>(do_tr, qb * 32, db, s, lane, dv[db]);
-        dk[db] = mma_tr_acc<T>(q_tr, qb * 32, db, dp, lane, dk[db]);
+        if constexpr (DMA) {
+          dv[db] = mma_tr_acc_rowimg(do_row, qb * 32, db, s, lane, dv[db]);
+          dk[db] = mma_tr_acc_rowimg(q_row, qb * 32, db, dp, lane, dk[db]);
+        } else {
+          dv[db] = mma_tr_acc<T>(do_tr, qb * 32, db, s, lane, dv[db]);
+          dk[db] = mma_tr_acc<T>(q_tr, qb * 32, db, dp, lane, dk[db]);
+        }
       }
     }
   }

@@ -93,6 +93,25 @@ template <int KD> struct RowTile<bf16_t, KD> {
   static VG_DEVICE bf16x8 frag16(const char* base, int row0, int s, int lane) {
     return *reinterpret_cast<const bf16x8*>(base + chunk_off(row0 + (lane & 15), 4 * s + (lane >> 4)));
   }
+  // TRANSPOSED fragment out of the same image (the tile's ROW is the reduction index: what TrTile<bf16, 64>::frag
+  // reads from its own image, same element order): ds_read_b64_tr_b16 only needs each lane's four elements to be
+  // contiguous, which any 16-byte-chunk swizzle keeps.  Rows q and q + 2 of a 16-lane group fall on the same banks
+  // (2-way conflict, twice the LDS cycles of TrTile) -- the price of not staging a second copy of the tile.
+  template <bool PERM>
+  static VG_DEVICE bf16x8 tr_frag(const char* base, int k0, int col0, int s, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+    const int col = col0 + 16 * (g & 1) + 4 * p;
+    const int ka = k0 + 16 * s + (PERM ? 4 * h : 8 * h) + q;
+    const int kb = ka + (PERM ? 8 : 4);
+    const int oa = ka * 128 + ((((col >> 3) ^ ((ka >> 1) & 7))) << 4) + ((col & 7) << 1);
+    const int ob = kb * 128 + ((((col >> 3) ^ ((kb >> 1) & 7))) << 4) + ((col & 7) << 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + oa));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + ob));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
 };
 
 template <int KD> struct RowTile<float, KD> {
