@@ -278,15 +278,32 @@ VG_DEVICE float silu_grad(float x) {
   return sg * (1.0f + x * (1.0f - sg));
 }
 
+// Wave-wide reductions on the DPP path: quad swaps, half-row / row mirrors and the two row broadcasts of the gfx9
+// family fold into the VALU instruction itself (v_add_f32_dpp ...), six dependent steps of a few cycles each, and the
+// total leaves lane 63 through v_readlane (uniform result).  The __shfl_xor butterfly these replace is six dependent
+// ds_bpermute round trips through the LDS crossbar (~100 cycles each): the row kernels (RMSNorm, channel norms, CE,
+// flow) run one wave per frame with one or two such reductions on each frame's critical path.
+template <int CTRL, int ROW_MASK>
+VG_DEVICE float dpp_move(float v, float ident) {     // lanes the row mask disables receive `ident`
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 VG_DEVICE float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1, 0xF>(v, 0.f);      // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xF>(v, 0.f);      // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xF>(v, 0.f);     // row_half_mirror: 8 lanes
+  v += dpp_move<0x140, 0xF>(v, 0.f);     // row_mirror: 16 lanes
+  v += dpp_move<0x142, 0xA>(v, 0.f);     // row_bcast:15 into rows 1, 3
+  v += dpp_move<0x143, 0xC>(v, 0.f);     // row_bcast:31 into rows 2, 3: row 3 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 VG_DEVICE float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1, 0xF>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x4E, 0xF>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x141, 0xF>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x140, 0xF>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x142, 0xA>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x143, 0xC>(v, -INFINITY));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // row predicate: frame (b = m / T, t = m % T) is valid iff t < lengths[b]

@@ -281,6 +281,357 @@ __global__ __launch_bounds__(512) void dwnorm_fwd_kernel(const T* __restrict__ x
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: run-based forward for the shape the model runs (bf16, one 16-byte channel vector per lane, 7 taps).
+// A wave owns a RUN of 8 consecutive frames of one sequence instead of one frame at a time:
+//   * the 8 + 6 input rows of the run are requested together (one memory round trip per run; the frame-at-a-time
+//     kernel fetched 7 rows per frame, 6 of them again through L1 / L2, behind one dependent round trip per frame);
+//   * every input row is expanded to fp32 once and added into the up to 7 frames it feeds (64 accumulators);
+//   * the 2 x 8 wave reductions of a run are independent DPP chains that interleave, instead of two exposed
+//     reductions per frame;
+//   * the lane's frame-invariant parameters (56 tap weights, bias, affine) come straight from global memory with
+//     16-byte loads: no LDS staging, no block barrier.
+// Same arithmetic as dwnorm_fwd_kernel (fp32 statistics, two-pass unbiased variance).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RUNF = 8;
+
+VG_DEVICE void load8(const float* p, float (&o)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+
+template <int TAPS>
+struct RunParams {
+  float w[8][TAPS];            // [channel of the lane][tap]
+  VG_DEVICE void load(const float* __restrict__ wg, int lane) {
+    // weights are [C][taps]: the lane's 8 channels x TAPS taps are 8 * TAPS consecutive floats
+    float flat[8 * TAPS];
+    const float* p = wg + (long)lane * 8 * TAPS;
+#pragma unroll
+    for (int i = 0; i < 2 * TAPS; ++i) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(p + 4 * i);
+      flat[4 * i] = q[0]; flat[4 * i + 1] = q[1]; flat[4 * i + 2] = q[2]; flat[4 * i + 3] = q[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) w[e][k] = flat[e * TAPS + k];
+  }
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ cbias,
+                                                             const float* __restrict__ temb,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             DwArgs a) {
+  constexpr int NR = RUNF + TAPS - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rps = (a.Tn + RUNF - 1) / RUNF, nruns = (a.M / a.Tn) * rps;
+  RunParams<TAPS> P;
+  P.load(w, lane);
+  float cb[8], gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cb[e] = 0.f; gm[e] = 1.f; bt[e] = 0.f; }
+  if (cbias) load8(cbias + lane * 8, cb);
+  if (gamma) load8(gamma + lane * 8, gm);
+  if (beta) load8(beta + lane * 8, bt);
+  const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
+  for (int run = blockIdx.x * (blockDim.x >> 6) + wave; run < nruns; run += gridDim.x * (blockDim.x >> 6)) {
+    const int b = run / rps, t0 = (run - b * rps) * RUNF;
+    const bf16_t* xb = x + (long)b * a.Tn * a.C + lane * 8;
+    uint4 raw[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int tc = min(max(t0 - a.shift + j, 0), a.Tn - 1);
+      raw[j] = *reinterpret_cast<const uint4*>(xb + (long)tc * a.C);
+    }
+    float v[RUNF][8];
+    {
+      float te[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (temb) load8(temb + (long)b * a.C + lane * 8, te);
+#pragma unroll
+      for (int f = 0; f < RUNF; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[f][e] = cb[e] + te[e];
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int ti = t0 - a.shift + j;
+      const float on = (ti >= 0 && ti < a.Tn) ? 1.f : 0.f;       // per-sequence zero padding
+      float xv[8];
+      V8<bf16_t>::expand(raw[j], xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] *= on;
+#pragma unroll
+      for (int f = 0; f < RUNF; ++f) {
+        const int k = j - f;                                        // tap of frame f that reads window row j
+        if (k >= 0 && k < TAPS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[f][e] = fmaf(P.w[e][k], xv[e], v[f][e]);
+        }
+      }
+    }
+    float mean[RUNF], rstd[RUNF];
+#pragma unroll
+    for (int f = 0; f < RUNF; ++f) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[f][e];
+      mean[f] = wave_sum(s) * inv_c;
+    }
+#pragma unroll
+    for (int f = 0; f < RUNF; ++f) {
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[f][e] - mean[f]; q = fmaf(d, d, q); }
+      rstd[f] = rsqrtf(wave_sum(q) * inv_c1 + a.eps);
+    }
+    const long row0 = (long)b * a.Tn + t0;
+#pragma unroll
+    for (int f = 0; f < RUNF; ++f) {
+      if (t0 + f < a.Tn) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(gm[e], (v[f][e] - mean[f]) * rstd[f], bt[e]);
+        V8<bf16_t>::store(y + (row0 + f) * a.C + lane * 8, o);
+        if (lane == 0) { mean_out[row0 + f] = mean[f]; rstd_out[row0 + f] = rstd[f]; }
+      }
+    }
+  }
+}
+
+// run-based backward through the norm (same shapes as dwnorm_fwd_run_kernel; RF frames per run -- 4: the extra dy rows and
+// partial sums leave no registers for 8 at two waves per SIMD): recomputes v for the frames of a run from one
+// (RF + 6)-row window, the two reductions of the frames interleave; the per-lane gamma / beta partial sums of
+// the block's four waves meet in LDS once.  part[block][0][c] = sum_rows dy * xhat ; part[block][1][c] = sum_rows dy
+template <int TAPS, int RF>
+__global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ cbias,
+                                                                  const float* __restrict__ temb,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean_in,
+                                                                  const float* __restrict__ rstd_in, bf16_t* __restrict__ du,
+                                                                  float* __restrict__ part, DwArgs a) {
+  constexpr int NR = RF + TAPS - 1;
+  __shared__ float red[4][2][64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rps = (a.Tn + RF - 1) / RF, nruns = (a.M / a.Tn) * rps;
+  RunParams<TAPS> P;
+  P.load(w, lane);
+  float cb[8], gm[8], sg[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cb[e] = 0.f; gm[e] = 1.f; sg[e] = 0.f; sb[e] = 0.f; }
+  if (cbias) load8(cbias + lane * 8, cb);
+  if (gamma) load8(gamma + lane * 8, gm);
+  const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
+  for (int run = blockIdx.x * 4 + wave; run < nruns; run += gridDim.x * 4) {
+    const int b = run / rps, t0 = (run - b * rps) * RF;
+    const long row0 = (long)b * a.Tn + t0;
+    const bf16_t* xb = x + (long)b * a.Tn * a.C + lane * 8;
+    uint4 raw[NR], rdy[RF];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int tc = min(max(t0 - a.shift + j, 0), a.Tn - 1);
+      raw[j] = *reinterpret_cast<const uint4*>(xb + (long)tc * a.C);
+    }
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+      rdy[f] = *reinterpret_cast<const uint4*>(dy + ((long)b * a.Tn + min(t0 + f, a.Tn - 1)) * a.C + lane * 8);
+    float v[RF][8];
+    {
+      float te[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (temb) load8(temb + (long)b * a.C + lane * 8, te);
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[f][e] = cb[e] + te[e];
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int ti = t0 - a.shift + j;
+      const float on = (ti >= 0 && ti < a.Tn) ? 1.f : 0.f;
+      float xv[8];
+      V8<bf16_t>::expand(raw[j], xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] *= on;
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        const int k = j - f;
+        if (k >= 0 && k < TAPS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[f][e] = fmaf(P.w[e][k], xv[e], v[f][e]);
+        }
+      }
+    }
+    float s1[RF], s2[RF], rr[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      const int tf = min(t0 + f, a.Tn - 1);
+      const float mean = mean_in[(long)b * a.Tn + tf], r = rstd_in[(long)b * a.Tn + tf];
+      const float on = t0 + f < a.Tn ? 1.f : 0.f;               // frames past the end of the sequence contribute nothing
+      rr[f] = r;
+      float dyv[8];
+      V8<bf16_t>::expand(rdy[f], dyv);
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[f][e] - mean;
+        const float dd = dyv[e] * on;
+        const float g = dd * gm[e];
+        v[f][e] = d;
+        a1 += g;
+        a2 = fmaf(g, d, a2);
+        sg[e] = fmaf(dd * d, r, sg[e]);
+        sb[e] += dd;
+      }
+      s1[f] = a1;
+      s2[f] = a2;
+    }
+#pragma unroll
+    for (int f = 0; f < RF; ++f) s1[f] = wave_sum(s1[f]) * inv_c;
+#pragma unroll
+    for (int f = 0; f < RF; ++f) s2[f] = wave_sum(s2[f]) * rr[f] * rr[f] * rr[f] * inv_c1;
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      if (t0 + f < a.Tn) {
+        float dyv[8], o[8];
+        V8<bf16_t>::expand(rdy[f], dyv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rr[f] * (dyv[e] * gm[e] - s1[f]) - s2[f] * v[f][e];
+        V8<bf16_t>::store(du + (row0 + f) * a.C + lane * 8, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[wave][0][lane * 8 + e] = sg[e];
+    red[wave][1][lane * 8 + e] = sb[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 512; i += 256) {
+    const int which = i >> 9, c = i & 511;
+    part[((long)blockIdx.x * 2 + which) * a.C + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+// run-based backward through the depthwise convolution: dx[t] = dx_add[t] + sum_k w[c][k] du[t - (k - shift)] from one
+// 14-row window of du, then the tap gradients wpart[block][c][k] = sum_rows du[t] x[t + k - shift] from one 14-row
+// window of x and the run's own 8 du rows.
+template <int TAPS, int RF>
+__global__ __launch_bounds__(256) void dwnorm_bwd_conv_run_kernel(const bf16_t* __restrict__ du, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ w,
+                                                                  const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ dx,
+                                                                  float* __restrict__ wpart, DwArgs a) {
+  constexpr int NR = RF + TAPS - 1;
+  __shared__ float red[4][8 * TAPS * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rps = (a.Tn + RF - 1) / RF, nruns = (a.M / a.Tn) * rps;
+  float gw[8][TAPS];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) gw[e][k] = 0.f;
+  for (int run = blockIdx.x * 4 + wave; run < nruns; run += gridDim.x * 4) {
+    const int b = run / rps, t0 = (run - b * rps) * RF;
+    const long row0 = (long)b * a.Tn + t0;
+    const bf16_t* dub = du + (long)b * a.Tn * a.C + lane * 8;
+    const bf16_t* xb = x + (long)b * a.Tn * a.C + lane * 8;
+    {   // ---- dx: window row j holds du frame t0 + shift - (TAPS - 1) + j; frame f, tap k reads row f + TAPS - 1 - k
+      RunParams<TAPS> P;
+      P.load(w, lane);
+      uint4 raw[NR], radd[RF];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int tc = min(max(t0 + a.shift - (TAPS - 1) + j, 0), a.Tn - 1);
+        raw[j] = *reinterpret_cast<const uint4*>(dub + (long)tc * a.C);
+      }
+      if (dx_add) {
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+          radd[f] = *reinterpret_cast<const uint4*>(dx_add + ((long)b * a.Tn + min(t0 + f, a.Tn - 1)) * a.C + lane * 8);
+      }
+      float o[RF][8];
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        if (dx_add) V8<bf16_t>::expand(radd[f], o[f]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[f][e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int td = t0 + a.shift - (TAPS - 1) + j;
+        const float on = (td >= 0 && td < a.Tn) ? 1.f : 0.f;
+        float dv[8];
+        V8<bf16_t>::expand(raw[j], dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dv[e] *= on;
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+          const int k = f + TAPS - 1 - j;
+          if (k >= 0 && k < TAPS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[f][e] = fmaf(P.w[e][k], dv[e], o[f][e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+        if (t0 + f < a.Tn) V8<bf16_t>::store(dx + (row0 + f) * a.C + lane * 8, o[f]);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the second phase's loads behind the first phase (registers: two waves per SIMD)
+    {   // ---- tap gradients: window row j holds x frame t0 - shift + j; frame f, tap k reads row f + k
+      uint4 raw[NR], rdu[RF];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int tc = min(max(t0 - a.shift + j, 0), a.Tn - 1);
+        raw[j] = *reinterpret_cast<const uint4*>(xb + (long)tc * a.C);
+      }
+#pragma unroll
+      for (int f = 0; f < RF; ++f) rdu[f] = *reinterpret_cast<const uint4*>(dub + (long)min(t0 + f, a.Tn - 1) * a.C);
+      float duv[RF][8];
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        V8<bf16_t>::expand(rdu[f], duv[f]);
+        const float on = t0 + f < a.Tn ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) duv[f][e] *= on;
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int ts = t0 - a.shift + j;
+        const float on = (ts >= 0 && ts < a.Tn) ? 1.f : 0.f;
+        float xv[8];
+        V8<bf16_t>::expand(raw[j], xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] *= on;
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+          const int k = j - f;
+          if (k >= 0 && k < TAPS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gw[e][k] = fmaf(duv[f][e], xv[e], gw[e][k]);
+          }
+        }
+      }
+    }
+  }
+  // wpart[block][c][k]: the lane's 8 channels x TAPS taps are consecutive floats
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) red[wave][(lane * 8 + e) * TAPS + k] = gw[e][k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512 * TAPS; i += 256)
+    wpart[(long)blockIdx.x * a.C * a.taps + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
 // du = r * (g - mean(g)) - r^3 / (C - 1) * d * sum(g * d),  g = dy * gamma, d = v - mean
 // part[block][0][c] = sum_rows dy * xhat ; part[block][1][c] = sum_rows dy
 template <typename T, int NV>
@@ -488,7 +839,12 @@ extern "C" int vg_dwnorm_fwd(const void* x, const float* w, const float* cbias, 
   const int nv = C / (64 * (dtype == VG_BF16 ? 8 : 4));
   // algorithmic bytes: every frame read once and written once (the taps re-read neighbours from cache), + statistics
   const int tok = vg_host::prof_begin(VG_PROF_DWNORM_FWD, (double)M * (2.0 * C * (dtype == VG_BF16 ? 2 : 4) + 8.0), stream);
-  if (dtype == VG_BF16) {
+  static const int runs_off = [] { const char* e = getenv("VG_DW_RUNS"); return e && atoi(e) == 0; }();
+  if (dtype == VG_BF16 && nv == 1 && taps == 7 && !runs_off) {
+    const int nruns = (M / T) * ((T + RUNF - 1) / RUNF);
+    dwnorm_fwd_run_kernel<7><<<dim3(min((nruns + 3) / 4, 1024)), dim3(256), 0, stream>>>(
+        (const bf16_t*)x, w, cbias, temb, gamma, beta, (bf16_t*)y, mean, rstd, a);
+  } else if (dtype == VG_BF16) {
     if (nv == 1) launch_fwd<bf16_t, 1>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
     else launch_fwd<bf16_t, 2>(x, w, cbias, temb, gamma, beta, y, mean, rstd, a, nb, stream);
   } else {
@@ -510,7 +866,14 @@ extern "C" int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, cons
   // algorithmic bytes: dy, x read; du, dx written (+ the residual-path gradient when given)
   const int tok = vg_host::prof_begin(VG_PROF_DWNORM_BWD, (double)M * ((dx_add ? 5.0 : 4.0) * C * (dtype == VG_BF16 ? 2 : 4) + 8.0),
                                       stream);
-  if (dtype == VG_BF16) {
+  static const int runs_off = [] { const char* e = getenv("VG_DW_RUNS"); return e && atoi(e) == 0; }();
+  if (dtype == VG_BF16 && nv == 1 && taps == 7 && C == 512 && !runs_off) {
+    // (the grid stays vg_dwnorm_blocks(M): the caller sized the partial-sum arrays for it)
+    dwnorm_bwd_norm_run_kernel<7, 4><<<dim3(nb), dim3(256), 0, stream>>>((const bf16_t*)dy, (const bf16_t*)x, w, cbias, temb, gamma,
+                                                                     mean, rstd, (bf16_t*)du, norm_part, a);
+    dwnorm_bwd_conv_run_kernel<7, 4><<<dim3(nb), dim3(256), 0, stream>>>((const bf16_t*)du, (const bf16_t*)x, w,
+                                                                     (const bf16_t*)dx_add, (bf16_t*)dx, w_part, a);
+  } else if (dtype == VG_BF16) {
     if (nv == 1) launch_bwd<bf16_t, 1>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
     else launch_bwd<bf16_t, 2>(dy, x, w, cbias, temb, gamma, mean, rstd, dx_add, du, dx, norm_part, w_part, a, nb, stream);
   } else {
