@@ -80,7 +80,9 @@ typedef struct vg_gemm_desc {
   const void* pre_add;  /* [M][ldc] added before the activation (conditioning term of the conv blocks) or NULL */
   int tile_cfg;         /* 0 = auto; -1 = register-staged 128x128; 1..5 = LDS-DMA 128x128 / 256x128 / 256x256 / 128x256 / 256x128 with a 3-stage ring;
                            11 / 12 / 13 = phase-pipelined 256x256 (ring / complementary / complementary with long phases and
-                           compile-time epilogues: what auto picks for whole 64-deep K tiles), 14 = two 256x128 blocks per CU (vg_gemm_ph.hip) */
+                           compile-time epilogues: what auto picks for whole 64-deep K tiles), 14 = two 256x128 blocks per CU,
+                           15 = the long-phase schedule on 192x256 tiles (auto: where 256-row tiles leave a round of CUs
+                           badly filled, e.g. M = 10240 or 8000 with N = 1024) (vg_gemm_ph.hip) */
   float* colsum_out;    /* a_tr = b_tr = 1 only (weight gradient dY^T X): colsum_out[m] += sum_k A(m,k), i.e. the bias
                            gradient of the same Linear (modules/linear/layers.py:192) from the tiles already in LDS; NULL = off */
   float* colpart;       /* [ceil(M / vg_gemm_tile_rows(desc))][N] fp32 or NULL: per-row-tile column sums of the stored result

@@ -183,7 +183,7 @@ def test_lean_epilogues_are_bitwise_the_generic_one(F, variant, mode, masked):
     bias, res, der = rnd(N, seed=2), rnd(M, N, dtype=torch.bfloat16, seed=3), rnd(M, N, dtype=torch.bfloat16, seed=4)
     lens = torch.tensor([17, 16, 1, 0, 16], dtype=torch.int32, device=dev())
     outs = {}
-    for cfg in (3, 13, 1):
+    for cfg in (3, 13, 15, 1):
         args = dict(tile_cfg=cfg, b_tr=(mode == "nn"))
         if kw.get("bias"): args["bias"] = bias
         if kw.get("residual"): args["residual"] = res
@@ -197,7 +197,7 @@ def test_lean_epilogues_are_bitwise_the_generic_one(F, variant, mode, masked):
         if masked: args.update(lengths=lens, T=T)
         out = F.gemm(A, B, M, N, K, **args)
         outs[cfg] = (out, aux, part[0] if part else None)
-    for cfg in (13, 1):              # 13: every variant lean; 1 (128x128 tiles): the plain / ReLU variants lean
+    for cfg in (13, 15, 1):          # 13 / 15 (192-row tiles): every variant lean; 1 (128x128 tiles): the plain / ReLU variants lean
         assert torch.equal(outs[3][0], outs[cfg][0]), cfg
         if outs[3][1] is not None:
             assert torch.equal(outs[3][1], outs[cfg][1]), cfg

@@ -137,3 +137,36 @@ def test_full_config_T1000_fp32_matches_oracle(full_cfg):
         if rn > 1e-6 * top:
             worst = max(worst, abs(float(grads[k].grad.double().norm()) - rn) / rn)
     assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("cfg", [13, 15])
+@pytest.mark.parametrize("mode", ["nt", "nn"])
+@pytest.mark.parametrize("shape", [(520, 392, 320), (10240, 1024, 1024), (200, 136, 64), (8000, 1024, 4096)])
+def test_long_phase_tiles_exact(F, cfg, mode, shape):
+    """The long-phase 256x256 (tile_cfg 13) and 192x256 (15) tiles on small integers: ragged M / N edges (a last row tile
+    of 8 / 64 / 136 rows, rows past M and the unused quarter of the 192-row tile's A images are zero fills), one to 64
+    K tiles, and the two shapes the 192-row tile is chosen for (M = 10240 and 8000, N = 1024)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    ref = A @ B.T
+    Ad, Bd = A.to(dev()).bfloat16(), B.to(dev()).bfloat16()
+    if mode == "nt":
+        out = F.gemm(Ad, Bd, M, N, K, tile_cfg=cfg, out_f32=True)
+    else:
+        out = F.gemm(Ad, Bd.T.contiguous(), M, N, K, b_tr=True, tile_cfg=cfg, out_f32=True)
+    assert torch.equal(out.float().cpu(), ref)
+    # bf16 output through the lean epilogue with bias and residual (what the layer's products use)
+    bias = torch.randint(-2, 3, (N,), generator=g).float().to(dev())
+    res = torch.randint(-2, 3, (M, N), generator=g).float().to(dev()).bfloat16()
+    small = ref.abs().max() < 200                       # exactly representable in bf16
+    if mode == "nt":
+        out = F.gemm(Ad, Bd, M, N, K, tile_cfg=cfg, bias=bias, residual=res)
+    else:
+        out = F.gemm(Ad, Bd.T.contiguous(), M, N, K, b_tr=True, tile_cfg=cfg, bias=bias, residual=res)
+    want = (ref.to(dev()) + bias + res.float()).bfloat16()
+    if small:
+        assert torch.equal(out, want)
+    else:
+        torch.testing.assert_close(out.float(), want.float(), rtol=1e-2, atol=1.0)

@@ -343,6 +343,11 @@ int pick_cfg(const vg_gemm_desc* d) {
                       (long)(d->a_tr ? d->K : d->M) * d->lda * 2 < 0x7ffffff0L &&
                       (long)(d->b_tr ? d->K : d->N) * d->ldb * 2 < 0x7ffffff0L;
   if (!dma_ok) return -1;
+  if (cfg == 15) {                 // the 192-row long-phase tile takes row-image A operands and whole 64-deep K tiles only
+    const int sp = d->split_k > 0 ? d->split_k : 1;
+    const int kp = (((d->K + sp - 1) / sp + 63) / 64) * 64;
+    if (d->a_tr || d->K % 64 != 0 || kp % 64 != 0) cfg = 3;
+  }
   if (cfg != 0) return cfg;
   // Forward / dgrad products: the tile shape with the least estimated time.  A launch runs in rounds of
   // 256 x blocks-per-CU tiles; a round costs its tile area times a measured per-shape factor, a partly filled last
@@ -370,6 +375,12 @@ int pick_cfg(const vg_gemm_desc* d) {
       // N = 1024: 80 tiles, 128x128 is 15 % faster).  A partly filled round of one-block-per-CU tiles costs a whole one.
       const double c1 = cost(128, 128, 2, 1.08 + longk_pen, 0.85), c13 = cost(256, 256, 1, 0.62, 0.93);
       cfg = c13 <= c1 ? 13 : 1;
+      // round 3: the same schedule on 192 x 256 tiles (tile_cfg 15) where its rounds are cheaper -- 216 tiles instead
+      // of 160 at M = 10240 (the yaml's 2 x 8 x 640 frames), 168 instead of 128 at M = 8000: three quarters of a round's
+      // time for the N = 1024 products.  It has to win clearly (the narrower tile streams a third more B per FLOP).
+      static const int no15 = [] { const char* e = getenv("VG_NO_CFG15"); return e ? atoi(e) : 0; }();
+      const double c15 = cost(192, 256, 1, 0.70, 0.93);     // per-area factor from tools/tile_cold_sweep.py CFGS=1,13,15 at M = 8000 / 10240
+      if (!no15 && c15 < 0.93 * fmin(c1, c13)) cfg = 15;
     } else {
       const double c1 = cost(128, 128, 2, 1.08 + longk_pen, 0.85), c3 = cost(256, 256, 1, 1.0, 0.85),
                    c9 = cost(192, 256, 1, 0.97, 0.85);
@@ -388,7 +399,7 @@ int pick_cfg(const vg_gemm_desc* d) {
   if (no_ph && cfg >= 10) cfg = d->a_tr ? 1 : 3;     // A/B switch: the round-1 kernels
   return cfg;
 }
-int cfg_tile_rows(int cfg) { return cfg == 9 ? 192 : (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6 || cfg >= 10) ? 256 : 128; }
+int cfg_tile_rows(int cfg) { return (cfg == 9 || cfg == 15) ? 192 : (cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6 || cfg >= 10) ? 256 : 128; }
 }  // namespace
 
 extern "C" int vg_gemm_tile_rows(const vg_gemm_desc* d) {

@@ -36,7 +36,12 @@ constexpr int HALF_BYTES = 16384;            // one half-tile image
 constexpr int BUF_BYTES = 4 * HALF_BYTES;    // B0 A0 B1 A1 of one K tile
 
 // per-lane source offsets of this wave's two 1-KiB pieces of a half-tile image (same images as dma_tile<..., 128, 8>)
-template <bool TR>
+// HR = rows (row image) / columns (k-major image) of the operand half an image holds: 128, or 96 for the A operand of
+// the 192-row tile (tile_cfg 15).  The image keeps its 128-wide layout; the part past HR is never read, and its
+// requests get an offset outside every buffer window (the range check turns them into zero fills without a fetch), so
+// every wave still issues two pieces per image and the counted waits do not change.
+constexpr unsigned OOB_OFFSET = 0xfffffff0u;
+template <bool TR, int HR = 128>
 VG_DEVICE void piece_offsets(unsigned (&voff)[2][2], long ld_bytes, int rc0, int wave, int lane) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
@@ -46,14 +51,16 @@ VG_DEVICE void piece_offsets(unsigned (&voff)[2][2], long ld_bytes, int rc0, int
       if constexpr (!TR) {
         const int row = piece * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        voff[half][j] = (unsigned)((long)(rc0 + half * 128 + row) * ld_bytes + chunk * 16);
+        voff[half][j] = (unsigned)((long)(rc0 + half * HR + row) * ld_bytes + chunk * 16);
+        if (HR < 128 && row >= HR) voff[half][j] = OOB_OFFSET;
       } else {
         const int krow = piece * 4 + (lane >> 4);
         const int p16 = lane & 15;
         const int gran = (p16 >> 2) ^ (krow & 3);
         const int hf = ((p16 >> 1) & 1) ^ ((krow >> 3) & 1);
         const int col = gran * 32 + hf * 16 + (p16 & 1) * 8;
-        voff[half][j] = (unsigned)((long)krow * ld_bytes + (long)(rc0 + half * 128 + col) * 2);
+        voff[half][j] = (unsigned)((long)krow * ld_bytes + (long)(rc0 + half * HR + col) * 2);
+        if (HR < 128 && col >= HR) voff[half][j] = OOB_OFFSET;
       }
     }
 }
@@ -107,7 +114,7 @@ struct BlockReader {
 // once per K tile): a request is then a descriptor of four ready words plus the M0 write -- recomputing the window
 // from the tile index cost ~16 scalar instructions per request, eight requests per wave and K tile, inside segments
 // whose length is what bounds the loop.
-template <bool A_TR, bool B_TR>
+template <bool A_TR, bool B_TR, int BM_ = 256>
 struct TileCtx {
   int m0, n0, wg, nwg, nkt;
   int a_step, b_step;          // bytes from one K tile to the next
@@ -125,7 +132,7 @@ struct TileCtx {
   // launch, 0: tile = mt * ntn + nt, 2: the same line walked along the shorter of the two tile dimensions
   VG_DEVICE void init_range(const GemmParams& p, int tile, int kbeg, int ntiles, int order, int wave, int lane) {
     const bool remap = order == 1;
-    constexpr int BM = 256, BN = 256;
+    constexpr int BM = BM_, BN = 256;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     nwg = ntn * ntm;
     // blocks that share an XCD get a contiguous run of tiles (bijective remap) ...
@@ -162,7 +169,7 @@ struct TileCtx {
     b_cur = reinterpret_cast<const char*>(p.B) + b_first;
     a_left = (int)(a_bytes - a_first);
     b_left = (int)(b_bytes - b_first);
-    piece_offsets<A_TR>(va, lda_b, m0, wave, lane);
+    piece_offsets<A_TR, BM_ / 2>(va, lda_b, m0, wave, lane);
     piece_offsets<B_TR>(vb, ldb_b, n0, wave, lane);
   }
   // move the windows by `n` K tiles
@@ -420,19 +427,21 @@ VG_DEVICE void ring_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* 
 // grouped weight gradients 350 -> 448-472 us; their fragments are two ds_read_b64_tr_b16 each and sit on the critical
 // path of the next MFMA run) while the row-image mode does not move; requests after Y's MFMAs: 3-17 % slower;
 // without s_setprio around the MFMAs: no difference.
-template <bool A_TR, bool B_TR>
-VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* smem, int wave, int lane) {
+// NTA = 16-row A tiles a wave owns in each row half: 4 (256-row tile) or 3 (192-row tile, tile_cfg 15: 24 MFMAs per
+// phase instead of 32 against the same B fragments and the same barrier / request structure).
+template <bool A_TR, bool B_TR, int NTA = 4>
+VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR, 64 * NTA>& c, f32x4 (&acc)[2 * NTA][4], char* smem, int wave, int lane) {
   constexpr int NSLOT = 10;
   constexpr bool UNROLL5 = !A_TR && !B_TR;
   const int wr = wave >> 2, wc = wave & 3;
   // this schedule gives a wave 64 CONTIGUOUS columns (all of them inside one B half image): its rows of C are whole
   // 128-byte lines for the epilogue's stores and for the residual / stored-derivative reads
   const int bh = (wc >> 1) << 1;   // slot offset of this wave's B half inside a K tile's four images (0 or 2)
-  BlockReader<A_TR, 4> rda;
+  BlockReader<A_TR, NTA> rda;
   BlockReader<B_TR, 4> rdb;
-  rda.init(wr * 64, lane);
+  rda.init(wr * 16 * NTA, lane);
   rdb.init((wc & 1) * 64, lane);
-  bf16x8 fa[4][2], fb[4][2];
+  bf16x8 fa[NTA][2], fb[4][2];
   const int nkt = c.nkt;
   auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
   // requests always address the K tile the windows of `c` stand at (t + 2 inside the loop)
@@ -444,23 +453,23 @@ VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* s
 #pragma unroll
       for (int s = 0; s < 2; ++s) fb[j][s] = rdb.get(smem + wrap(s0 + bh) * HALF_BYTES, j, s);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NTA; ++i)
 #pragma unroll
       for (int s = 0; s < 2; ++s) fa[i][s] = rda.get(smem + wrap(s0 + 1) * HALF_BYTES, i, s);
   };
   auto reads_b = [&](int s0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NTA; ++i)
 #pragma unroll
       for (int s = 0; s < 2; ++s) fa[i][s] = rda.get(smem + wrap(s0 + 3) * HALF_BYTES, i, s);
   };
   auto mfmas = [&](auto halfc) {
-    constexpr int A0 = decltype(halfc)::value * 4;
+    constexpr int A0 = decltype(halfc)::value * NTA;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NTA; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[A0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], fb[j][s], acc[A0 + i][j], 0, 0, 0);
@@ -539,9 +548,10 @@ VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* s
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero fills past the end must not land in the strips
 }
 
-VG_DEVICE void zero_acc(f32x4 (&acc)[8][4]) {
+template <int TM>
+VG_DEVICE void zero_acc(f32x4 (&acc)[TM][4]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
@@ -551,8 +561,9 @@ VG_DEVICE void zero_acc(f32x4 (&acc)[8][4]) {
 __device__ long long* g_lab_stamps = nullptr;     // diagnostic build only (tools/lab/variant.sh ... -DVG_LAB_STAMPS)
 #endif
 
-template <bool A_TR, bool B_TR, int SCHED, int EPI = EPI_GENERIC>
+template <bool A_TR, bool B_TR, int SCHED, int EPI = EPI_GENERIC, int BM = 256>
 __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
+  static_assert(BM == 256 || (BM == 192 && SCHED == 2), "the 192-row tile exists on the long-phase schedule only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -562,19 +573,19 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
 #ifdef VG_LAB_XCDMASK                 // lab: only the blocks of some XCDs work (timing experiment: the others exit)
   if (((VG_LAB_XCDMASK) >> (blockIdx.x & 7) & 1) == 0) return;
 #endif
-  TileCtx<A_TR, B_TR> c;
+  TileCtx<A_TR, B_TR, BM> c;
   c.init(p, blockIdx.x, blockIdx.z, wave, lane);
-  f32x4 acc[8][4];                 // [a * 4 + i][b * 2 + j]; SCHED 2: [a * 4 + i][j]
+  f32x4 acc[BM / 32][4];           // [a * 4 + i][b * 2 + j]; SCHED 2: [a * (BM / 64) + i][j]
   zero_acc(acc);
   if constexpr (SCHED == 1) ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-  else if constexpr (SCHED == 2) px2_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
+  else if constexpr (SCHED == 2) px2_main_loop<A_TR, B_TR, BM / 64>(c, acc, smem, wave, lane);
   else px_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
 #ifdef VG_LAB_STAMPS
   long long st1 = wall_clock64();
 #endif
   constexpr bool ILVC = SCHED != 2;
-  if constexpr (EPI == EPI_GENERIC) tile_epilogue<256, 256, 2, 4, true, ILVC>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
-  else tile_epilogue_lean<256, 256, 2, 4, true, ILVC, EPI>(p, acc, smem, c.m0, c.n0);
+  if constexpr (EPI == EPI_GENERIC) tile_epilogue<BM, 256, 2, 4, true, ILVC>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
+  else tile_epilogue_lean<BM, 256, 2, 4, true, ILVC, EPI>(p, acc, smem, c.m0, c.n0);
 #ifdef VG_LAB_STAMPS
   if (g_lab_stamps && tid == 0 && blockIdx.x < 4096) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -924,32 +935,32 @@ void set_lds(K k, size_t lds) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <bool A_TR, bool B_TR, int SCHED, int EPI = EPI_GENERIC>
+template <bool A_TR, bool B_TR, int SCHED, int EPI = EPI_GENERIC, int BM = 256>
 int launch_ph(const GemmParams& p, int splits, hipStream_t stream) {
   constexpr size_t lds = SCHED != 0 ? 10 * HALF_BYTES : 2 * BUF_BYTES;
-  auto k = gemm_ph_kernel<A_TR, B_TR, SCHED, EPI>;
+  auto k = gemm_ph_kernel<A_TR, B_TR, SCHED, EPI, BM>;
   static bool attr_done = false;
   if (!attr_done) {
     set_lds(k, lds);
     attr_done = true;
   }
-  const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
+  const int ntn = (p.N + 255) / 256, ntm = (p.M + BM - 1) / BM;
   hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(512), lds, stream, p);
   return 0;
 }
 
-template <bool A_TR, bool B_TR>
+template <bool A_TR, bool B_TR, int BM = 256>
 int launch_px2(const GemmParams& p, int splits, hipStream_t stream) {
   if constexpr (!A_TR) {           // forward / dgrad products end in bf16 rows; the TN products are fp32 gradients
     switch (lean_epilogue_of(p, splits)) {
-      case EPI_PLAIN: return launch_ph<A_TR, B_TR, 2, EPI_PLAIN>(p, splits, stream);
-      case EPI_GELU_SAVE: return launch_ph<A_TR, B_TR, 2, EPI_GELU_SAVE>(p, splits, stream);
-      case EPI_DACT: return launch_ph<A_TR, B_TR, 2, EPI_DACT>(p, splits, stream);
-      case EPI_SILU_SAVE: return launch_ph<A_TR, B_TR, 2, EPI_SILU_SAVE>(p, splits, stream);
+      case EPI_PLAIN: return launch_ph<A_TR, B_TR, 2, EPI_PLAIN, BM>(p, splits, stream);
+      case EPI_GELU_SAVE: return launch_ph<A_TR, B_TR, 2, EPI_GELU_SAVE, BM>(p, splits, stream);
+      case EPI_DACT: return launch_ph<A_TR, B_TR, 2, EPI_DACT, BM>(p, splits, stream);
+      case EPI_SILU_SAVE: return launch_ph<A_TR, B_TR, 2, EPI_SILU_SAVE, BM>(p, splits, stream);
       default: break;
     }
   }
-  return launch_ph<A_TR, B_TR, 2>(p, splits, stream);
+  return launch_ph<A_TR, B_TR, 2, EPI_GENERIC, BM>(p, splits, stream);
 }
 
 }  // namespace
@@ -968,6 +979,11 @@ int gemm_ph_launch(const GemmParams& p, int a_tr, int b_tr, int cfg, int splits,
     if (!a_tr && !b_tr) return launch_duo<false, false>(p, splits, stream);
     if (!a_tr && b_tr) return launch_duo<false, true>(p, splits, stream);
     return launch_duo<true, true>(p, splits, stream);
+  }
+  if (cfg == 15) {                 // 192 x 256 tiles on the long-phase schedule (forward / dgrad products: A is a row image)
+    if (a_tr) return -1;
+    if (!b_tr) return launch_px2<false, false, 192>(p, splits, stream);
+    return launch_px2<false, true, 192>(p, splits, stream);
   }
   if (cfg == 13) {
     if (!a_tr && !b_tr) return launch_px2<false, false>(p, splits, stream);
