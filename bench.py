@@ -183,6 +183,10 @@ def main():
     ap.add_argument("--host-batches", action="store_true",
                     help="hand the step HOST batches: pinned memory -> asynchronous copies two steps ahead "
                          "(training_lib.prefetch); the PCIe-inclusive rate quoted in DESIGN.md")
+    ap.add_argument("--packed-rows", type=int, default=None,
+                    help="hip.packed_rows of the yaml (1): the Transformer stack runs on the valid frames only "
+                         "(row gather + varlen attention); 0 keeps the padded rows")
+    ap.add_argument("--packed-granule", type=int, default=None, help="hip.packed_rows_granule (rows per bucket)")
     ap.add_argument("--ragged", action="store_true",
                     help="sequence lengths ~ U{T/2..T} (right-padded batches, SURVEY 8d): shows the cost of masking; "
                          "tokens/s then counts valid frames only")
@@ -221,6 +225,10 @@ def main():
     hp = Hparams.from_yamlfile(CONFIG)
     hp.hip.precision = args.precision
     hp.hip.graph = bool(args.graph)
+    if args.packed_rows is not None:
+        hp.hip.packed_rows = bool(args.packed_rows)
+    if args.packed_granule is not None:
+        hp.hip.packed_rows_granule = args.packed_granule
     hp.hip.coalesce_accumulation = bool(args.coalesce)
     hp.hip.comm = args.comm
     if args.graph_bucket_mb is not None:
@@ -279,6 +287,13 @@ def main():
     for _ in range(args.warmup * accum):
         trainer.training_step(fetch(it), it)
         it += 1
+    if args.ragged and args.graph and not args.host_batches:
+        # ragged batches fall into several row buckets of hip.packed_rows: every (padded length, bucket) shape of the
+        # timed batches is captured here, untimed, so that the timed region measures replays and not captures
+        # (a training run meets each shape once in its first minutes)
+        lo = it
+        for j in range(args.steps * accum):
+            trainer.training_step(batches[lo + j], lo + j)
     sync()
     if not args.graph:
         hipvg.prof_enable(True)

@@ -128,14 +128,29 @@ int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const floa
  * qkv: [B*T][3*H*64] = in_proj output (q | k | v, head h = columns 64h..64h+63,
  * attention.py:12-18,52); out: [B*T][H*64] (heads merged, :78); rows
  * t >= lengths[b] of `out` are written as zeros.  head_dim must be 64.
- * slopes: fp32 [H] (positive; bias = -slope * (i - j)).  lse: fp32 [B][H][T].
+ * slopes: fp32 [H] (positive; bias = -slope * (i - j)).  lse: fp32 [H][B*T] (head-major over the rows of qkv;
+ * only passed on to vg_attn_bwd).
  */
 int vg_attn_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int T, int H,
                 const int32_t* lengths, int dtype, vg_stream_t stream);
-/* dqkv: [B*T][3*H*64]; delta: fp32 workspace [B][H][T]. */
+/* dqkv: [B*T][3*H*64]; delta: fp32 workspace [H][B*T]. */
 int vg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
                 void* dqkv, float* delta, int B, int T, int H, const int32_t* lengths, int dtype,
                 vg_stream_t stream);
+/* The same two calls on PACKED rows (the valid frames of a right-padded batch stored back to back, as
+ * utils/tensormask.py:63-67's apply_mask makes the padded ones irrelevant): sequence b owns rows
+ * cu_rows[b] .. cu_rows[b + 1] - 1 of qkv / out / dout / dqkv (`rows` rows in all; lengths[b] of them are attended,
+ * normally all), Tmax >= every length sizes the grid.  A sequence with lengths[b] = 0 has its rows zero-filled: the
+ * caller appends such pseudo sequences (each <= Tmax rows) to cover rows it padded the packed tensors with.
+ * lse / delta: fp32 [H][rows]. */
+int vg_attn_fwd_varlen(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tmax, int H,
+                       const int32_t* lengths, const int32_t* cu_rows, int rows, int dtype, vg_stream_t stream);
+int vg_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
+                       void* dqkv, float* delta, int B, int Tmax, int H, const int32_t* lengths,
+                       const int32_t* cu_rows, int rows, int dtype, vg_stream_t stream);
+/* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for rows of row_bytes (a multiple of 16) bytes: packing the valid frames of a
+ * padded batch, un-packing them, and each other's backward. */
+int vg_gather_rows(const void* src, const int32_t* map, void* dst, int n_dst, int row_bytes, vg_stream_t stream);
 /* Single-query decode step against a pre-allocated KV cache (attention.py:56-73
  * with past_kv).  q: [B][H*64]; kcache/vcache: [B][Tmax][H*64]; pos[b] = number
  * of valid cache rows INCLUDING the current one; out: [B][H*64]. */

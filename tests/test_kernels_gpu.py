@@ -926,7 +926,7 @@ def test_kernels_without_atomics_are_bitwise_repeatable(F):
         out["nn"] = F.gemm(qkv, w, M, D, 3 * D, b_tr=True, lengths=lens, T=T)
         slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
         att = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
-        lse = torch.empty(B, H, T, dtype=torch.float32, device=dev())
+        lse = torch.empty(H, B, T, dtype=torch.float32, device=dev())      # [H][B * T] (include/vaegslm_hip.h)
         hipvg.check(L.vg_attn_fwd(p(qkv), p(att), p(lse), p(slopes), B, T, H, p(lens), 1, st), "attn_fwd")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
@@ -941,7 +941,7 @@ def test_kernels_without_atomics_are_bitwise_repeatable(F):
 
     a, b = once(), once()
     torch.cuda.synchronize()
-    valid = (torch.arange(T, device=dev())[None] < lens[:, None])[:, None, :].expand(B, H, T)
+    valid = (torch.arange(T, device=dev())[None] < lens[:, None])[None].expand(H, B, T)
     for k in a:
         if k == "lse":          # the log-sum-exp of padded query rows is never written (nor read)
             assert torch.equal(a[k][valid], b[k][valid]), k

@@ -41,7 +41,7 @@ def main():
         dout = torch.randn(B * T, D, generator=g).to(dev).bfloat16()
         slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev)
         out = torch.empty(B * T, D, dtype=torch.bfloat16, device=dev)
-        lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+        lse = torch.empty(H, B, T, dtype=torch.float32, device=dev)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
         L = hipvg.lib()

@@ -261,7 +261,8 @@ VG_DEVICE f32x16 rows16(const float* arr, int row0, int lane) {
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const float* __restrict__ slopes,
-                                                       int Tn, int H, const int* __restrict__ lengths, int sched) {
+                                                       int Tn, int H, const int* __restrict__ lengths, int sched,
+                                                       const int* __restrict__ cu, int Mtot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_row = smem;
   char* v_tr = smem + LdsPlan<T>::ROW_BYTES;
@@ -274,23 +275,25 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
   const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
-  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
+  const int Tr = cu ? cu[b + 1] - soff : Tn;            // rows the sequence owns (packed layout: its own length)
+  const int len = lengths ? min(lengths[b], Tr) : Tr;
   const int q0 = qt * QB;
   const int qw0 = q0 + wave * 32;
   const int query = qw0 + (lane & 31);
-  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
-  T* __restrict__ obase = out + (long)b * Tn * D + h * DH;
+  const T* __restrict__ base = qkv + (long)soff * rs + h * DH;
+  T* __restrict__ obase = out + (long)soff * D + h * DH;
 
   if (q0 >= len) {   // fully padded tile: zero rows (attention.py:80 re-mask)
     f32x16 z[2] = {zero16(), zero16()};
-    if (query < Tn) store_rows_T<T>(obase + (long)query * D, z, 0.f, lane);
+    if (query < Tr) store_rows_T<T>(obase + (long)query * D, z, 0.f, lane);
     return;
   }
   const int qend = min(q0 + QB, len);
   const int nkt = (qend + TB - 1) / TB;
 
   RowRegs<T> qf;
-  qf.load(base + (long)min(query, Tn - 1) * rs, lane);
+  qf.load(base + (long)min(query, Tr - 1) * rs, lane);
   const float slope = slopes[h];
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   f32x16 kinit;
@@ -307,13 +310,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
   uint4 rk[DMA ? 1 : NVec<T>::v], rv[DMA ? 1 : NVec<T>::v];
   __amdgpu_buffer_rsrc_t rsk, rsv;
   if constexpr (DMA) {
-    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tn);
-    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tn);
+    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tr);
+    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tr);
     slab_dma<false>(rsk, smem, rs, 0, wave, lane);
     slab_dma<true>(rsv, smem + LdsPlan<T>::ROW_BYTES, rs, 0, wave, lane);
   } else {
-    slab_load<T>(rk, base + D, rs, 0, Tn, tid);
-    slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+    slab_load<T>(rk, base + D, rs, 0, Tr, tid);
+    slab_load<T>(rv, base + 2 * D, rs, 0, Tr, tid);
   }
   for (int kt = 0; kt < nkt; ++kt) {
     const int kv0 = kt * TB;
@@ -332,8 +335,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
       slab_store<T, false, true>(rv, nullptr, v_tr, tid);
       __syncthreads();
       if (kt + 1 < nkt) {
-        slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
-        slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+        slab_load<T>(rk, base + D, rs, kv0 + TB, Tr, tid);
+        slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tr, tid);
       }
     }
     if (qw0 + 31 < kv0) continue;   // this wave's queries all precede the tile (causal)
@@ -375,11 +378,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) o[db] = mma_tr_acc<T>(v_tr, kb * 32, db, s[kb], lane, o[db]);
   }
-  if (query < Tn) {
+  if (query < Tr) {
     const bool valid = query < len;
     store_rows_T<T>(obase + (long)query * D, o, valid ? 1.f / l : 0.f, lane);
     if (valid && lane < 32)
-      lse[((long)b * H + h) * Tn + query] = (m + log2f(l) - slope2 * (float)(query - qw0)) * LN2;
+      lse[(long)h * Mtot + soff + query] = (m + log2f(l) - slope2 * (float)(query - qw0)) * LN2;
   }
 }
 
@@ -409,7 +412,7 @@ template <bool DESC>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, const float* __restrict__ slopes,
                                                            int Tn, int H, const int* __restrict__ lengths, float skip_thr,
-                                                           int sched) {
+                                                           int sched, const int* __restrict__ cu, int Mtot) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,17 +423,19 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
-  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
+  const int Tr = cu ? cu[b + 1] - soff : Tn;            // rows the sequence owns (packed layout: its own length)
+  const int len = lengths ? min(lengths[b], Tr) : Tr;
   const int q0 = qt * QB2;
   const int qw0 = q0 + wave * QW2;
-  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
-  T* __restrict__ obase = out + (long)b * Tn * D + h * DH;
+  const T* __restrict__ base = qkv + (long)soff * rs + h * DH;
+  T* __restrict__ obase = out + (long)soff * D + h * DH;
 
   if (q0 >= len) {   // fully padded tile: zero rows (attention.py:80 re-mask)
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = qw0 + it * 8 + (lane >> 3);
-      if (row < Tn) *reinterpret_cast<uint4*>(obase + (long)row * D + (lane & 7) * 8) = make_uint4(0, 0, 0, 0);
+      if (row < Tr) *reinterpret_cast<uint4*>(obase + (long)row * D + (lane & 7) * 8) = make_uint4(0, 0, 0, 0);
     }
     return;
   }
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   // Q fragments, pre-scaled by log2(e) / sqrt(d): the S products come out in the log2 domain
   RowRegs<T> qf[2];
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs) qf[qs].load(base + (long)min(qw0 + qs * 32 + (lane & 31), Tn - 1) * rs, lane);
+  for (int qs = 0; qs < 2; ++qs) qf[qs].load(base + (long)min(qw0 + qs * 32 + (lane & 31), Tr - 1) * rs, lane);
   const float slope = slopes[h];
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   f32x16 o[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   }
   const unsigned tile_bytes = (unsigned)(TB * rs * 2);
   const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  const __amdgpu_buffer_rsrc_t rsk = slab_rsrc(base + D, rs, Tn), rsv = slab_rsrc(base + 2 * D, rs, Tn);
+  const __amdgpu_buffer_rsrc_t rsk = slab_rsrc(base + D, rs, Tr), rsv = slab_rsrc(base + 2 * D, rs, Tr);
   auto issue = [&](int kt, int stage) {
     // (sched & 2: lab switch -- every request reads tile 0, an L2-resident stream; results are wrong)
     const unsigned tb = (sched & 2) ? 0u : (unsigned)kt * tile_bytes, dst = smem0 + stage * STAGE2 + wave * 1024;
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
         *reinterpret_cast<bf16x4*>(ow + row * 128 + ((((d0 >> 3) ^ (row & 7))) << 4) + (d0 & 7) * 2) = v;
       }
     if (query < len && lane < 32)
-      lse[((long)b * H + h) * Tn + query] = (r[qs] + log2f(l) - slope2 * (float)(lane & 31)) * LN2;
+      lse[(long)h * Mtot + soff + query] = (r[qs] + log2f(l) - slope2 * (float)(lane & 31)) * LN2;
   }
   // the rows of a wave are written and read by that wave only: no block barrier (LDS accesses of one wave stay in order)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   for (int it = 0; it < 8; ++it) {
     const int row = it * 8 + (lane >> 3), c16 = lane & 7;
     const uint4 v = *reinterpret_cast<const uint4*>(ow + row * 128 + ((c16 ^ (row & 7)) << 4));
-    if (qw0 + row < Tn) *reinterpret_cast<uint4*>(obase + (long)(qw0 + row) * D + c16 * 8) = v;
+    if (qw0 + row < Tr) *reinterpret_cast<uint4*>(obase + (long)(qw0 + row) * D + c16 * 8) = v;
   }
 }
 
@@ -693,14 +698,14 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
 // =====================================================================================
 template <typename T>
 __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta,
-                                  int B, int Tn, int H) {
+                                  int Mtot, int H) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = gid & 7;
   const long mh = gid >> 3;
   const int h = mh % H;
   const long m = mh / H;
   float acc = 0.f;
-  if (m < (long)B * Tn) {
+  if (m < (long)Mtot) {
     const long off = m * (long)H * DH + h * DH + c * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc += to_f32<T>(o[off + e]) * to_f32<T>(dout[off + e]);
@@ -708,10 +713,7 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
   acc += __shfl_xor(acc, 4, 64);
-  if (c == 0 && m < (long)B * Tn) {
-    const int b = m / Tn, t = m % Tn;
-    delta[((long)b * H + h) * Tn + t] = acc;
-  }
+  if (c == 0 && m < (long)Mtot) delta[(long)h * Mtot + m] = acc;       // [head][row], like the LSE
 }
 
 // =====================================================================================
@@ -724,7 +726,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
                                                           const float* __restrict__ slopes, T* __restrict__ dqkv,
-                                                          int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched) {
+                                                          int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched,
+                                                          const int* __restrict__ cu, int Mtot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_row = smem;
   char* v_row = smem + LdsPlan<T>::ROW_BYTES;
@@ -738,27 +741,29 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
-  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
+  const int Tr = cu ? cu[b + 1] - soff : Tn;            // rows the sequence owns (packed layout: its own length)
+  const int len = lengths ? min(lengths[b], Tr) : Tr;
   const int q0 = qt * QB, qw0 = q0 + wave * 32, query = qw0 + (lane & 31);
-  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
-  T* __restrict__ dqbase = dqkv + (long)b * Tn * rs + h * DH;
+  const T* __restrict__ base = qkv + (long)soff * rs + h * DH;
+  T* __restrict__ dqbase = dqkv + (long)soff * rs + h * DH;
   if (q0 >= len) {
     f32x16 z[2] = {zero16(), zero16()};
-    if (query < Tn) store_rows_T<T>(dqbase + (long)query * rs, z, 0.f, lane);
+    if (query < Tr) store_rows_T<T>(dqbase + (long)query * rs, z, 0.f, lane);
     return;
   }
   const int qend = min(q0 + QB, len);
   const int nkt = (qend + TB - 1) / TB;
   const bool qvalid = query < len;
-  const int qc = min(query, Tn - 1);
+  const int qc = min(query, Tr - 1);
   RowRegs<T> qf, dof;
   qf.load(base + (long)qc * rs, lane);
-  dof.load(dout + ((long)b * Tn + qc) * D + h * DH, lane);
+  dof.load(dout + ((long)soff + qc) * D + h * DH, lane);
   const float slope = slopes[h];
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   // +inf for padded queries -> p = exp2(-inf) = 0 without a compare
-  const float Lq = qvalid ? lse[((long)b * H + h) * Tn + query] * LOG2E + slope2 * (float)(query - qw0) : INFINITY;
-  const float dl = qvalid ? delta[((long)b * H + h) * Tn + query] : 0.f;
+  const float Lq = qvalid ? lse[(long)h * Mtot + soff + query] * LOG2E + slope2 * (float)(query - qw0) : INFINITY;
+  const float dl = qvalid ? delta[(long)h * Mtot + soff + query] : 0.f;
   f32x16 kinit, dinit;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -776,12 +781,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     slab_dma<false>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);      // (K^T fragments come out of the K row image)
   };
   if constexpr (DMA) {
-    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tn);
-    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tn);
+    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tr);
+    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tr);
     issue(0, smem);
   } else {
-    slab_load<T>(rk, base + D, rs, 0, Tn, tid);
-    slab_load<T>(rv, base + 2 * D, rs, 0, Tn, tid);
+    slab_load<T>(rk, base + D, rs, 0, Tr, tid);
+    slab_load<T>(rv, base + 2 * D, rs, 0, Tr, tid);
   }
   for (int kt = 0; kt < nkt; ++kt) {
     const int kv0 = kt * TB;
@@ -797,8 +802,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       slab_store<T, true, false>(rv, v_row, nullptr, tid);
       __syncthreads();
       if (kt + 1 < nkt) {
-        slab_load<T>(rk, base + D, rs, kv0 + TB, Tn, tid);
-        slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tn, tid);
+        slab_load<T>(rk, base + D, rs, kv0 + TB, Tr, tid);
+        slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tr, tid);
       }
     }
     if (qw0 + 31 < kv0) continue;
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       }
     }
   }
-  if (query < Tn) store_rows_T<T>(dqbase + (long)query * rs, dq, SCALE, lane);
+  if (query < Tr) store_rows_T<T>(dqbase + (long)query * rs, dq, SCALE, lane);
 }
 
 // =====================================================================================
@@ -840,7 +845,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ slopes, T* __restrict__ dqkv,
-                                                           int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched) {
+                                                           int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched,
+                                                           const int* __restrict__ cu, int Mtot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_row = smem;
   char* do_row = smem + LdsPlan<T>::ROW_BYTES;
@@ -854,29 +860,31 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const int h = hb % H, b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
-  const int len = lengths ? min(lengths[b], Tn) : Tn;
+  const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
+  const int Tr = cu ? cu[b + 1] - soff : Tn;            // rows the sequence owns (packed layout: its own length)
+  const int len = lengths ? min(lengths[b], Tr) : Tr;
   const int k0 = ktile * QB, kw0 = k0 + wave * 32, key = kw0 + (lane & 31);
-  const T* __restrict__ base = qkv + (long)b * Tn * rs + h * DH;
-  const T* __restrict__ dobase = dout + (long)b * Tn * D + h * DH;
-  T* __restrict__ dkbase = dqkv + (long)b * Tn * rs + D + h * DH;
-  T* __restrict__ dvbase = dqkv + (long)b * Tn * rs + 2 * D + h * DH;
+  const T* __restrict__ base = qkv + (long)soff * rs + h * DH;
+  const T* __restrict__ dobase = dout + (long)soff * D + h * DH;
+  T* __restrict__ dkbase = dqkv + (long)soff * rs + D + h * DH;
+  T* __restrict__ dvbase = dqkv + (long)soff * rs + 2 * D + h * DH;
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
   if (k0 >= len) {
-    if (key < Tn) {
+    if (key < Tr) {
       store_rows_T<T>(dkbase + (long)key * rs, dk, 0.f, lane);
       store_rows_T<T>(dvbase + (long)key * rs, dv, 0.f, lane);
     }
     return;
   }
-  const int kc = min(key, Tn - 1);
+  const int kc = min(key, Tr - 1);
   RowRegs<T> kf, vf;
   kf.load(base + D + (long)kc * rs, lane);
   vf.load(base + 2 * D + (long)kc * rs, lane);
   const float slope = slopes[h];
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   const float kl = slope2 * (float)(key - k0);
-  const float* __restrict__ lse_bh = lse + ((long)b * H + h) * Tn;
-  const float* __restrict__ dl_bh = delta + ((long)b * H + h) * Tn;
+  const float* __restrict__ lse_bh = lse + (long)h * Mtot + soff;
+  const float* __restrict__ dl_bh = delta + (long)h * Mtot + soff;
 
   // query tiles are swept from the sequence's LAST tile down to the block's diagonal: the key blocks of a (batch, head)
   // pair then start on the same tile (see pair_and_rank)
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   // loaded value in the iteration that issued the load makes the compiler wait for it right there -- behind the
   // eight LDS-DMA requests of the next tile, i.e. wave 0 sat out the whole transfer once per tile.
   auto st_raw = [&](int qs, float& a, float& d) {
-    const int qq = min(qs + tid, Tn - 1);
+    const int qq = min(qs + tid, Tr - 1);
     a = lse_bh[qq];
     d = dl_bh[qq];
   };
@@ -915,8 +923,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   };
   float st_a = 0.f, st_d = 0.f;    // wave 0: raw lse / delta of the NEXT tile, fetched one iteration ahead
   if constexpr (DMA) {
-    rsq = slab_rsrc(reinterpret_cast<const bf16_t*>(base), rs, Tn);
-    rsd = slab_rsrc(reinterpret_cast<const bf16_t*>(dobase), D, Tn);
+    rsq = slab_rsrc(reinterpret_cast<const bf16_t*>(base), rs, Tr);
+    rsd = slab_rsrc(reinterpret_cast<const bf16_t*>(dobase), D, Tr);
     if (tid < 64) {
       st_raw(qt_first * TB, st_a, st_d);
       st_store(qt_first * TB, st_a, st_d, reinterpret_cast<float*>(smem + IMG));
@@ -928,8 +936,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf.f[0]), "+v"(kf.f[1]), "+v"(kf.f[2]), "+v"(kf.f[3]), "+v"(vf.f[0]),
                  "+v"(vf.f[1]), "+v"(vf.f[2]), "+v"(vf.f[3]), "+v"(st_a), "+v"(st_d) :: "memory");
   } else {
-    slab_load<T>(rq, base, rs, qt_first * TB, Tn, tid);
-    slab_load<T>(rd, dobase, D, qt_first * TB, Tn, tid);
+    slab_load<T>(rq, base, rs, qt_first * TB, Tr, tid);
+    slab_load<T>(rd, dobase, D, qt_first * TB, Tr, tid);
   }
   for (int it = 0; it < nq; ++it) {
     const int qt = qt_first - it;
@@ -956,8 +964,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       if (tid < 64) st_values(qs0, st[tid], st[64 + tid]);
       __syncthreads();
       if (it + 1 < nq) {
-        slab_load<T>(rq, base, rs, qs0 - TB, Tn, tid);
-        slab_load<T>(rd, dobase, D, qs0 - TB, Tn, tid);
+        slab_load<T>(rq, base, rs, qs0 - TB, Tr, tid);
+        slab_load<T>(rd, dobase, D, qs0 - TB, Tr, tid);
       }
     }
 #pragma unroll
@@ -991,7 +999,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       }
     }
   }
-  if (key < Tn) {
+  if (key < Tr) {
     store_rows_T<T>(dkbase + (long)key * rs, dk, SCALE, lane);
     store_rows_T<T>(dvbase + (long)key * rs, dv, 1.f, lane);
   }
@@ -1064,20 +1072,23 @@ static float attn_skip_thr() {
   return v;
 }
 
+// `cu` (packed rows, vg_attn_*_varlen): cu[b] = first row of sequence b in the [rows][...] tensors, cu[B] = their total;
+// Mtot = rows of those tensors (= B * Tn in the padded layout); lse / delta are [H][Mtot].
 template <typename T>
 int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tn, int H,
-               const int32_t* lengths, hipStream_t stream) {
+               const int32_t* lengths, const int32_t* cu, int Mtot, hipStream_t stream) {
   // algorithmic work: causal-exact QK^T + PV, 2*2*64 FLOP per (query, key <= query) pair
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_FWD, 256.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
+  const int sched = attn_env("VG_ATTN_SCHED", 0);
   if constexpr (sizeof(T) == 2) {
     if (!attn_v1()) {
       dim3 grid2(((Tn + QB2 - 1) / QB2) * H * B);
       if (attn_env("VG_ATTN_FWD_DESC", 1))
         hipLaunchKernelGGL(attn2_fwd_kernel<true>, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
-                           lse, slopes, Tn, H, lengths, attn_skip_thr(), attn_env("VG_ATTN_SCHED", 0));
+                           lse, slopes, Tn, H, lengths, attn_skip_thr(), sched, cu, Mtot);
       else
         hipLaunchKernelGGL(attn2_fwd_kernel<false>, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
-                           lse, slopes, Tn, H, lengths, attn_skip_thr(), attn_env("VG_ATTN_SCHED", 0));
+                           lse, slopes, Tn, H, lengths, attn_skip_thr(), sched, cu, Mtot);
       vg_host::prof_end(tok, stream);
       return vg_host::check_launch("vg_attn_fwd");
     }
@@ -1085,24 +1096,26 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
   const size_t lds = (sizeof(T) == 2 ? 2 : 1) * (LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
-                     lengths, attn_env("VG_ATTN_SCHED", 0));
+                     lengths, sched, cu, Mtot);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_fwd");
 }
 
 template <typename T>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
-               void* dqkv, float* delta, int B, int Tn, int H, const int32_t* lengths, hipStream_t stream) {
-  const long nthreads = (long)B * Tn * H * 8;
+               void* dqkv, float* delta, int B, int Tn, int H, const int32_t* lengths, const int32_t* cu, int Mtot,
+               hipStream_t stream) {
+  const long nthreads = (long)Mtot * H * 8;
   // algorithmic work of the backward: 5 products (S, dP, dV, dK, dQ) = 2.5 x forward
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_BWD, 640.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
-                     (const T*)out, (const T*)dout, delta, B, Tn, H);
+                     (const T*)out, (const T*)dout, delta, Mtot, H);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
+  const int sched = attn_env("VG_ATTN_SCHED", 0);
   const size_t lds_q = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   const float skip = sizeof(T) == 2 ? attn_skip_thr() : INFINITY;     // the fp32 parity path keeps every tile
   hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
-                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, attn_env("VG_ATTN_SCHED", 0));
+                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot);
   const size_t lds_k = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float));
   static bool attr[2] = {false, false};
   if (!attr[sizeof(T) == 2]) {
@@ -1111,7 +1124,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     attr[sizeof(T) == 2] = true;
   }
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, dim3(256), lds_k, stream, (const T*)qkv, (const T*)dout, lse,
-                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, attn_env("VG_ATTN_SCHED", 0));
+                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_bwd");
 }
@@ -1123,8 +1136,9 @@ extern "C" int vg_attn_fwd(const void* qkv, void* out, float* lse, const float* 
   VG_REQUIRE(B > 0 && T > 0 && H > 0, "vg_attn_fwd: empty problem");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_fwd: bad dtype %d", dtype);
   VG_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "vg_attn_fwd: unaligned");
-  if (dtype == VG_BF16) return launch_fwd<bf16_t>(qkv, out, lse, slopes, B, T, H, lengths, stream);
-  return launch_fwd<float>(qkv, out, lse, slopes, B, T, H, lengths, stream);
+  VG_REQUIRE((long)B * T < 0x7fffffffL / 4, "vg_attn_fwd: too many rows");
+  if (dtype == VG_BF16) return launch_fwd<bf16_t>(qkv, out, lse, slopes, B, T, H, lengths, nullptr, B * T, stream);
+  return launch_fwd<float>(qkv, out, lse, slopes, B, T, H, lengths, nullptr, B * T, stream);
 }
 
 extern "C" int vg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
@@ -1133,8 +1147,29 @@ extern "C" int vg_attn_bwd(const void* qkv, const void* out, const void* dout, c
   VG_REQUIRE(B > 0 && T > 0 && H > 0, "vg_attn_bwd: empty problem");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_bwd: bad dtype %d", dtype);
   if (dtype == VG_BF16)
-    return launch_bwd<bf16_t>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, stream);
-  return launch_bwd<float>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, stream);
+    return launch_bwd<bf16_t>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, nullptr, B * T, stream);
+  return launch_bwd<float>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, nullptr, B * T, stream);
+}
+
+extern "C" int vg_attn_fwd_varlen(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tmax, int H,
+                                  const int32_t* lengths, const int32_t* cu_rows, int rows, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && Tmax > 0 && H > 0 && rows > 0, "vg_attn_fwd_varlen: empty problem");
+  VG_REQUIRE(lengths != nullptr && cu_rows != nullptr, "vg_attn_fwd_varlen: lengths[B] and cu_rows[B + 1] are required");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_fwd_varlen: bad dtype %d", dtype);
+  VG_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "vg_attn_fwd_varlen: unaligned");
+  if (dtype == VG_BF16) return launch_fwd<bf16_t>(qkv, out, lse, slopes, B, Tmax, H, lengths, cu_rows, rows, stream);
+  return launch_fwd<float>(qkv, out, lse, slopes, B, Tmax, H, lengths, cu_rows, rows, stream);
+}
+
+extern "C" int vg_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse,
+                                  const float* slopes, void* dqkv, float* delta, int B, int Tmax, int H,
+                                  const int32_t* lengths, const int32_t* cu_rows, int rows, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && Tmax > 0 && H > 0 && rows > 0, "vg_attn_bwd_varlen: empty problem");
+  VG_REQUIRE(lengths != nullptr && cu_rows != nullptr, "vg_attn_bwd_varlen: lengths[B] and cu_rows[B + 1] are required");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_bwd_varlen: bad dtype %d", dtype);
+  if (dtype == VG_BF16)
+    return launch_bwd<bf16_t>(qkv, out, dout, lse, slopes, dqkv, delta, B, Tmax, H, lengths, cu_rows, rows, stream);
+  return launch_bwd<float>(qkv, out, dout, lse, slopes, dqkv, delta, B, Tmax, H, lengths, cu_rows, rows, stream);
 }
 
 extern "C" int vg_attn_decode(const void* q, const void* kcache, const void* vcache, void* out,

@@ -407,6 +407,20 @@ __global__ void mask_rows_kernel(const T* __restrict__ x, T* __restrict__ y, lon
     y[i] = row_valid(lengths, Tlen, (int)(i / C)) ? x[i] : from_f32<T>(0.f);
 }
 
+// ------------------------------------------------------------------ row gather (packed <-> padded rows)
+// dst[i][:] = map[i] >= 0 ? src[map[i]][:] : 0, 16 bytes per lane.  Packing the valid frames of a right-padded batch
+// (map = the frame of packed row i) and un-packing them (map = the packed row of frame i, -1 on padded frames) are
+// both this gather, and each is the other's backward: no scatter, no atomics, nothing to pre-zero.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int* __restrict__ map,
+                                                          uint4* __restrict__ dst, int n_dst, int vec_per_row) {
+  const long total = (long)n_dst * vec_per_row, stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int row = (int)(i / vec_per_row), v = (int)(i - (long)row * vec_per_row);
+    const int m = map[row];
+    dst[i] = m >= 0 ? src[(long)m * vec_per_row + v] : make_uint4(0, 0, 0, 0);
+  }
+}
+
 // ------------------------------------------------------------------ token cross-entropy
 template <typename T>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const long* __restrict__ targets,
@@ -710,6 +724,17 @@ extern "C" int vg_mask_rows(const void* x, void* y, int M, int C, const int32_t*
     mask_rows_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)x, (float*)y, n, C,
                                                                               lengths, T > 0 ? T : 1);
   return vg_host::check_launch("vg_mask_rows");
+}
+
+extern "C" int vg_gather_rows(const void* src, const int32_t* map, void* dst, int n_dst, int row_bytes, hipStream_t stream) {
+  VG_REQUIRE(n_dst > 0 && row_bytes > 0 && row_bytes % 16 == 0, "vg_gather_rows: %d rows of %d bytes (rows must be whole 16-byte vectors)",
+             n_dst, row_bytes);
+  VG_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "vg_gather_rows: unaligned");
+  const int vpr = row_bytes / 16;
+  long blocks = ((long)n_dst * vpr + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  gather_rows_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const uint4*)src, map, (uint4*)dst, n_dst, vpr);
+  return vg_host::check_launch("vg_gather_rows");
 }
 
 extern "C" int vg_ce_fwd(const void* logits, const int64_t* targets, float* loss_rows, float* lse, int32_t* argmax,

@@ -491,7 +491,7 @@ class AttentionFn(torch.autograd.Function):
         D = H * 64
         assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
         out = torch.empty((B * T, D), dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((H, B * T), dtype=torch.float32, device=qkv.device)
         check(lib().vg_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(slopes), B, T, H, ptr(lengths),
                                 dtype_id(qkv.dtype), stream()), "vg_attn_fwd")
         ctx.save_for_backward(qkv, out, lse, slopes, lengths)
@@ -504,7 +504,7 @@ class AttentionFn(torch.autograd.Function):
         B, T, H = ctx.dims
         dout = _as(dout, qkv.dtype)
         dqkv = torch.empty_like(qkv)
-        delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+        delta = torch.empty((H, B * T), dtype=torch.float32, device=qkv.device)
         check(lib().vg_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
                                 B, T, H, ptr(lengths), dtype_id(qkv.dtype), stream()), "vg_attn_bwd")
         return dqkv, None, None, None, None, None
@@ -512,6 +512,90 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(qkv, slopes, B, T, H, lengths=None):
     return AttentionFn.apply(qkv, slopes, B, T, H, lengths)
+
+
+# ---------------------------------------------------------------- packed rows (valid frames of a right-padded batch)
+class PackPlan:
+    """Row maps of one right-padded batch (``utils/tensormask.py:45-54``: prefix masks) for running the Transformer
+    stack on its VALID frames only: ``rows`` packed rows (the sum of the lengths rounded up to ``granule``, so that a
+    hipGraph is captured per bucket and not per batch), every tensor of static shape and computed on the device from
+    ``lengths`` -- the plan can be (re)filled inside a captured graph.
+
+    ``idx[i]``  frame (b * T + t) of packed row i, -1 for the rows the rounding added;
+    ``inv[m]``  packed row of frame m, -1 for padded frames;
+    ``cu`` / ``lengths``  row ranges of the B real sequences followed by zero-length pseudo sequences (each at most T
+    rows) that cover the added rows: the attention kernels zero-fill those, every other kernel of the stack is
+    row-local and sees them as all-zero frames (their gradients are exactly zero)."""
+
+    def __init__(self, B: int, T: int, rows: int, device, granule: Optional[int] = None):
+        self.B, self.T, self.M, self.rows = B, T, B * T, rows
+        # the rows the rounding adds (at most one granule: rows = max(granule, total rounded up); all of them when the
+        # granule is not given) are covered by zero-length pseudo sequences of at most T rows each
+        self.npseudo = -(-min(rows, granule or rows) // T)
+        self.nseq = B + self.npseudo
+        self.idx = torch.empty(rows, dtype=torch.int32, device=device)
+        self.inv = torch.empty(B * T, dtype=torch.int32, device=device)
+        self.cu = torch.empty(self.nseq + 1, dtype=torch.int32, device=device)
+        self.lengths = torch.empty(self.nseq, dtype=torch.int32, device=device)
+        self._t = torch.arange(T, device=device, dtype=torch.int32)[None]
+        self._m = torch.arange(B * T, device=device, dtype=torch.int32)
+        self._j = torch.arange(self.npseudo + 1, device=device, dtype=torch.int32)
+
+    def fill(self, lengths32: Tensor) -> "PackPlan":
+        """Device-only (no host synchronisation): safe to record into a hipGraph whose ``lengths32`` is a static input."""
+        B, T, rows = self.B, self.T, self.rows
+        lens = lengths32.to(torch.int32).clamp(0, T)
+        ends = torch.cumsum(lens, 0, dtype=torch.int32)
+        starts = ends - lens
+        valid = self._t < lens[:, None]
+        inv = torch.where(valid, starts[:, None] + self._t, torch.full_like(self._t, -1)).reshape(-1)
+        self.inv.copy_(inv)
+        buf = torch.full((rows + 1,), -1, dtype=torch.int32, device=lens.device)
+        buf.scatter_(0, torch.where(inv >= 0, inv, torch.full_like(inv, rows)).long(), self._m)
+        self.idx.copy_(buf[:rows])
+        total = ends[-1:]
+        tail = torch.minimum(total + self._j * T, torch.full_like(self._j, rows))       # pseudo-sequence boundaries
+        self.cu.copy_(torch.cat([torch.zeros(1, dtype=torch.int32, device=lens.device), ends[:-1], tail]))
+        self.lengths.copy_(torch.cat([lens, torch.zeros(self.npseudo, dtype=torch.int32, device=lens.device)]))
+        return self
+
+
+def pack_rows_bucket(total: int, granule: int = 256) -> int:
+    return max(granule, -(-total // granule) * granule)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """dst[i] = src[map[i]] (0 where map[i] < 0); the backward is the gather with the inverse map."""
+
+    @staticmethod
+    def forward(ctx, src, fwd_map, bwd_map):
+        assert src.dim() == 2 and src.is_contiguous() and (src.shape[1] * src.element_size()) % 16 == 0
+        n = fwd_map.numel()
+        dst = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
+        check(lib().vg_gather_rows(ptr(src), ptr(fwd_map), ptr(dst), n, src.shape[1] * src.element_size(), stream()),
+              "vg_gather_rows")
+        ctx.save_for_backward(bwd_map)
+        return dst
+
+    @staticmethod
+    def backward(ctx, ddst):
+        (bwd_map,) = ctx.saved_tensors
+        ddst = ddst.contiguous()
+        n = bwd_map.numel()
+        dsrc = torch.empty((n, ddst.shape[1]), dtype=ddst.dtype, device=ddst.device)
+        check(lib().vg_gather_rows(ptr(ddst), ptr(bwd_map), ptr(dsrc), n, ddst.shape[1] * ddst.element_size(), stream()),
+              "vg_gather_rows")
+        return dsrc, None, None
+
+
+def pack_rows(x2: Tensor, plan: PackPlan) -> Tensor:
+    """[B * T, C] padded rows -> [plan.rows, C] packed rows."""
+    return GatherRowsFn.apply(x2, plan.idx, plan.inv)
+
+
+def unpack_rows(xp: Tensor, plan: PackPlan) -> Tensor:
+    """[plan.rows, C] packed rows -> [B * T, C] padded rows (zeros on padded frames)."""
+    return GatherRowsFn.apply(xp, plan.inv, plan.idx)
 
 
 def attention_decode(q, kcache, vcache, slopes, pos, H):
@@ -854,19 +938,26 @@ class TransformerLayerFn(torch.autograd.Function):
     bias-grad reductions match the reference's masked ones."""
 
     @staticmethod
-    def forward(ctx, x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps):
+    def forward(ctx, x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps, pack=None):
         M, D = x.shape
         F_ = w1.shape[0]
         dt = x.dtype
+        if pack is not None:         # packed rows: every row is a valid frame (or an all-zero row): no row masks
+            assert M == pack.rows and pack.T == T
+            lengths = None
         sq, so, s1, s2 = shadow(wqkv, dt), shadow(wo, dt), shadow(w1, dt), shadow(w2, dt)
         sc1, sc3 = n1s.detach().float().contiguous(), n3s.detach().float().contiguous()
         f32 = lambda b: None if b is None else b.detach().float()
         n1, rstd1 = rmsnorm_fwd_raw(x, sc1, eps, lengths, T)
         qkv = gemm(n1, sq, M, 3 * D, D, bias=f32(bqkv))
         att = torch.empty((M, D), dtype=dt, device=x.device)
-        lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
-        check(lib().vg_attn_fwd(ptr(qkv), ptr(att), ptr(lse), ptr(slopes), B, T, H, ptr(lengths), dtype_id(dt),
-                                stream()), "vg_attn_fwd")
+        lse = torch.empty((H, M), dtype=torch.float32, device=x.device)
+        if pack is None:
+            check(lib().vg_attn_fwd(ptr(qkv), ptr(att), ptr(lse), ptr(slopes), B, T, H, ptr(lengths), dtype_id(dt),
+                                    stream()), "vg_attn_fwd")
+        else:
+            check(lib().vg_attn_fwd_varlen(ptr(qkv), ptr(att), ptr(lse), ptr(slopes), pack.nseq, T, H, ptr(pack.lengths),
+                                           ptr(pack.cu), M, dtype_id(dt), stream()), "vg_attn_fwd_varlen")
         x1 = gemm(att, so, M, D, D, bias=f32(bo), residual=x, lengths=lengths, T=T)
         n3, rstd3 = rmsnorm_fwd_raw(x1, sc3, eps, lengths, T)
         u = torch.empty((M, F_), dtype=dt, device=x.device)
@@ -877,6 +968,7 @@ class TransformerLayerFn(torch.autograd.Function):
                               lengths)
         ctx.params = (n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2)
         ctx.dims = (B, T, H)
+        ctx.pack = pack
         return y
 
     @staticmethod
@@ -885,6 +977,7 @@ class TransformerLayerFn(torch.autograd.Function):
          lengths) = ctx.saved_tensors
         n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2 = ctx.params
         B, T, H = ctx.dims
+        pack = ctx.pack
         M, D = x.shape
         F_ = s1.shape[0]
         dt = x.dtype
@@ -935,9 +1028,14 @@ class TransformerLayerFn(torch.autograd.Function):
         datt = gemm(dx1, so, M, D, D, b_tr=True)
         g_wo, g_bo = wgrad(wo, bo, dx1, att)
         dqkv = torch.empty_like(qkv)
-        delta = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
-        check(lib().vg_attn_bwd(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
-                                B, T, H, ptr(lengths), dtype_id(dt), stream()), "vg_attn_bwd")
+        delta = torch.empty((H, M), dtype=torch.float32, device=x.device)
+        if pack is None:
+            check(lib().vg_attn_bwd(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
+                                    B, T, H, ptr(lengths), dtype_id(dt), stream()), "vg_attn_bwd")
+        else:
+            check(lib().vg_attn_bwd_varlen(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
+                                           pack.nseq, T, H, ptr(pack.lengths), ptr(pack.cu), M, dtype_id(dt), stream()),
+                  "vg_attn_bwd_varlen")
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
         g_wq, g_bq = wgrad(wqkv, bqkv, dqkv, n1)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
@@ -969,11 +1067,11 @@ class TransformerLayerFn(torch.autograd.Function):
             sink_wgrad_group(group)
         ws.join()                                # before qkv / att / du ... can be released
         return (dx, g_n1, g_wq, g_bq, g_wo, g_bo, g_n3, g_w1, g_b1, g_w2, g_b2,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
-def transformer_layer(x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps):
-    return TransformerLayerFn.apply(x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps)
+def transformer_layer(x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps, pack=None):
+    return TransformerLayerFn.apply(x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps, pack)
 
 
 # ---------------------------------------------------------------- conv bottleneck block (channels-last)

@@ -52,12 +52,12 @@ class TransformerLayer(nn.Module):
 
     # ---- the fused path used by training and by the stack: 2-D activations in, 2-D out
     def forward_2d(self, x2: torch.Tensor, B: int, T: int, lens: Optional[torch.Tensor],
-                   slopes: torch.Tensor) -> torch.Tensor:
+                   slopes: torch.Tensor, pack=None) -> torch.Tensor:
         sa = self.self_attn
         return HF.transformer_layer(x2, self.norm1.scale, sa.in_proj.weight, sa.in_proj.bias,
                                     sa.out_proj.weight, sa.out_proj.bias, self.norm3.scale,
                                     self.linear1.weight, self.linear1.bias, self.linear2.weight,
-                                    self.linear2.bias, slopes, lens, B, T, sa.nheads, self.norm1.eps)
+                                    self.linear2.bias, slopes, lens, B, T, sa.nheads, self.norm1.eps, pack)
 
     def forward(self, tgt: TensorMask, memory: Optional[TensorMask] = None,
                 rpe_pair: Optional[Tuple[str, Any]] = None, rpe_bias=None,
@@ -107,11 +107,33 @@ class TransformerLayerStack(nn.Module):
         self.is_cross_attn = False
         self.final_norm = get_norm_fn(hp.layer.dim, hp.layer.norm) if hp.get("final_ln", True) else None
         self.first_norm = get_norm_fn(hp.layer.dim, hp.layer.norm) if hp.get("first_ln", False) else None
+        # Packed rows (hip.packed_rows): None = padded rows; "auto" = pack whenever the batch has enough padding (reads the
+        # lengths on the host: eager launches only); an int = pack into exactly that many rows (the trainer's hipGraph
+        # path, which picks the bucket before it picks the graph).  Plans (static index buffers) are cached per shape.
+        self.pack_rows = None
+        self.pack_granule = 256
+        self._pack_plans = {}
         self.rpe, self.rpe_id = None, None
         if hp.get("rpe", False):
             self.rpe_id = hp.rpe.identifier
             self.rpe = get_positional_encoding(self.rpe_id, hp.rpe, hp.layer.dim,
                                                hp.layer.self_attn.nheads)
+
+    def _pack_plan(self, B, T, lens, x2):
+        rows = self.pack_rows
+        if rows is None or lens is None or self.first_norm is not None:
+            return None
+        M = B * T
+        if rows == "auto":
+            rows = HF.pack_rows_bucket(int(lens.sum().item()), self.pack_granule)
+        rows = int(rows)
+        if rows > int(0.94 * M) or (x2.shape[1] * x2.element_size()) % 16:
+            return None                    # not enough padding to pay for the two gathers
+        key = (B, T, rows, x2.device)
+        plan = self._pack_plans.get(key)
+        if plan is None:
+            plan = self._pack_plans[key] = HF.PackPlan(B, T, rows, x2.device, self.pack_granule)
+        return plan.fill(lens)
 
     def _norm2d(self, norm, x2, lens, T, masked):
         return HF.rmsnorm(x2, norm.scale, norm.eps, lengths=lens if masked else None, T=T)
@@ -135,9 +157,14 @@ class TransformerLayerStack(nn.Module):
             x2 = self._norm2d(self.first_norm, x2, lens, T, masked=True)
         fast = past_kv is None and not return_attn and not return_kv
         layer_outs = []
+        plan = self._pack_plan(B, T, lens, x2) if fast else None
         if fast:
             slopes = _slopes_from((self.rpe_id, self.rpe), None, x2.device).slopes
             cut = getattr(self, "grad_cut_layer", None)
+            if plan is not None:
+                # the stack runs on the valid frames only (the padded ones are zero rows that every layer re-masks in
+                # the reference, utils/tensormask.py:63-67): gather once here, scatter back after the final norm
+                x2 = HF.pack_rows(x2, plan)
             for l, layer in enumerate(self.layers):
                 if cut is not None and l in cut and torch.is_grad_enabled() and x2.requires_grad:
                     # backward cut (trainers.speech.lvtr: segmented hipGraph replay): the tape stops at this leaf;
@@ -145,8 +172,9 @@ class TransformerLayerStack(nn.Module):
                     leaf = x2.detach().requires_grad_(True)
                     self.grad_cuts.append(((x2,), (leaf,)))
                     x2 = leaf
-                x2 = layer.forward_2d(x2, B, T, lens, slopes)
-                layer_outs.append(TensorMask(x2.view(B, T, D), mask))
+                x2 = layer.forward_2d(x2, B, T, lens, slopes, plan)
+                if plan is None:
+                    layer_outs.append(TensorMask(x2.view(B, T, D), mask))
         else:
             past = past_kv if past_kv is not None else [None] * len(self.layers)
             rpe_pair, rpe_bias = (self.rpe_id, self.rpe), None
@@ -165,8 +193,12 @@ class TransformerLayerStack(nn.Module):
             x2 = cur.value.reshape(B * T, D)
         if self.final_norm is not None:
             # the reference does not re-mask here (:186-189); zero rows stay zero under RMSNorm
-            x2 = self._norm2d(self.final_norm, x2, lens, T, masked=True)
+            x2 = self._norm2d(self.final_norm, x2, lens, T, masked=plan is None)
+            if plan is not None:
+                x2 = HF.unpack_rows(x2, plan)
             layer_outs.append(TensorMask(x2.view(B, T, D), mask))
+        elif plan is not None:
+            x2 = HF.unpack_rows(x2, plan)
         if self.out is not None:
             x2 = HF.linear(x2, self.out.weight, self.out.bias, lengths=lens, T=T)
         outputs["output"] = TensorMask(x2.view(B, T, -1), mask)

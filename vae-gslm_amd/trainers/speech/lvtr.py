@@ -68,6 +68,9 @@ class LVTRTrainer(BaseTrainer):
         self._fold_accum = os.environ.get("VG_FOLD_ACCUM", "1") != "0"
         # optional: the micro-batches of an accumulation window as one batch (same gradient, taller GEMMs)
         self.coalesce = bool(hip.get("coalesce_accumulation", False)) if hip is not None else False
+        # hip.packed_rows: the Transformer stack of a ragged batch runs on its valid frames only
+        self.packed_rows = bool(hip.get("packed_rows", False)) if hip is not None else False
+        self.packed_granule = int(hip.get("packed_rows_granule", 1024)) if hip is not None else 1024
         self._held = []
 
     # ------------------------------------------------------------ optimisation plumbing
@@ -273,6 +276,7 @@ class LVTRTrainer(BaseTrainer):
         if self.use_graph and noise is None:
             out = self._graphed_micro_step(batch, batch_idx, last)
         else:
+            self._choose_pack_rows(batch, eager=True)
             out = self._training_loop(batch, batch_idx, noise)
         if last:
             clip = self.hp.training.get("gradient_clip_val", None)
@@ -313,6 +317,27 @@ class LVTRTrainer(BaseTrainer):
             self.global_step += 1
         return out
 
+    # ------------------------------------------------------------ packed rows
+    def _choose_pack_rows(self, batch: Optional[Mapping], eager: bool = False):
+        """Sets ``TransformerLayerStack.pack_rows`` for the coming forward and returns it (None: padded rows)."""
+        stack = self.model.transformer[0] if hasattr(self.model, "transformer") else None
+        if stack is None or not hasattr(stack, "pack_rows"):
+            return None
+        rows = None
+        stack.pack_granule = self.packed_granule
+        if self.packed_rows and batch is not None:
+            tm = batch.get("tokens", batch.get("mel"))
+            if tm is not None and not getattr(tm.mask, "_vg_full", False):
+                if eager:
+                    rows = "auto"
+                else:
+                    from hipvg import functional as HF
+                    B, T = tm.mask.shape[:2]
+                    cand = HF.pack_rows_bucket(int(tm.mask.sum().item()), self.packed_granule)
+                    rows = cand if cand <= int(0.94 * B * T) else None
+        stack.pack_rows = rows
+        return rows
+
     # ------------------------------------------------------------ hipGraph replay of a micro-step
     def _pad_for_graph(self, batch: Mapping) -> Mapping:
         """Real batches have a different number of frames every step; one graph per length would mean a capture
@@ -343,6 +368,10 @@ class LVTRTrainer(BaseTrainer):
         last replay of the window (bulk, not overlapped with backward)."""
         batch = self._pad_for_graph(batch)
         key = tuple((k, tuple(v.value.shape), getattr(v.mask, "_vg_full", False)) for k, v in sorted(batch.items()))
+        # packed rows: the number of packed rows is part of the graph's shape.  It is chosen here, on the host, from
+        # the batch's valid-frame count (one small device -> host read per micro-step) and rounded up to the granule,
+        # so a ragged data stream needs one graph per (padded length, bucket) and not one per batch.
+        key = key + (self._choose_pack_rows(batch),)
         dev = batch["mel"].value.device
         if self._kw_dev is None:
             self._kw_dev = torch.zeros((), dtype=torch.float32, device=dev)
@@ -449,6 +478,7 @@ class LVTRTrainer(BaseTrainer):
         model_input = batch["mel"]
         if self.use_tokens:
             model_input = batch["tokens"].expand().cat(batch["mel"])
+        self._choose_pack_rows(batch, eager=True)     # never a stale row count from a training micro-step
         was_training = self.model.training
         self.model.eval()
         try:
