@@ -33,7 +33,10 @@ def run(fns):
 def main():
     hipvg.lib()
     g = torch.Generator(device="cpu").manual_seed(0)
-    for (N, K) in [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096), (1024, 3072)]:
+    shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096), (1024, 3072)]
+    if os.environ.get("SHAPES"):      # SHAPES=512x2048,2048x512  (N x K)
+        shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
+    for (N, K) in shapes:
         xs = [torch.randn(M, K, generator=g).to(dev).bfloat16() for _ in range(R)]
         ws = [(torch.randn(N, K, generator=g) * K ** -0.5).to(dev).bfloat16() for _ in range(R)]
         wt = [(torch.randn(K, N, generator=g) * K ** -0.5).to(dev).bfloat16() for _ in range(R)]

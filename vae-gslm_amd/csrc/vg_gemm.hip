@@ -294,6 +294,12 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
               p.colpart != nullptr, p.colsum_out != nullptr, (double)p.alpha);
     const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream, gemm_algorithmic_bytes(p, sizeof(T)));
     int rc = -1;
+    hipEvent_t lab0 = nullptr, lab1 = nullptr;
+    if (sig_debug == 3) {        // lab: one line per launch WITH its duration (synchronises: eager launches only)
+      hipEventCreate(&lab0);
+      hipEventCreate(&lab1);
+      hipEventRecord(lab0, stream);
+    }
     if (tile_cfg >= 10) {     // phase-pipelined 256x256 tile (vg_gemm_ph.hip); shapes it does not take run on cfg 3
       rc = vg_host::gemm_ph_launch(p, a_tr, b_tr, tile_cfg, splits, stream);
       if (rc != 0) rc = vg_host::gemm_dma_launch(p, a_tr, b_tr, 3, splits, stream);
@@ -301,6 +307,17 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
       rc = vg_host::gemm_dma_launch(p, a_tr, b_tr, tile_cfg, splits, stream);
     }
     vg_host::prof_end(tok, stream);
+    if (sig_debug == 3) {
+      float ms = 0.f;
+      hipEventRecord(lab1, stream);
+      hipEventSynchronize(lab1);
+      hipEventElapsedTime(&ms, lab0, lab1);
+      fprintf(stderr, "[vg_gemm_t] us=%.1f cfg=%d M=%d N=%d K=%d a_tr=%d b_tr=%d splits=%d act=%d dact=%d res=%d aux_out=%d f32=%d acc=%d "
+                      "colpart=%d\n", ms * 1e3, tile_cfg, p.M, p.N, p.K, a_tr, b_tr, splits, p.act, p.dact, p.residual != nullptr,
+              p.aux_out != nullptr, p.out_f32, p.accumulate, p.colpart != nullptr);
+      hipEventDestroy(lab0);
+      hipEventDestroy(lab1);
+    }
     if (rc == 0) return vg_host::check_launch("vg_gemm(dma)");
   }
   if (launch_thin<T>(p, a_tr, b_tr, splits, stream)) return vg_host::check_launch("vg_gemm(thin)");
@@ -497,8 +514,25 @@ extern "C" int vg_gemm_grouped(const vg_gemm_desc* descs, int n, hipStream_t str
     bytes += gemm_algorithmic_bytes(ps[i], 2);
   }
   const int tok = vg_host::prof_begin(VG_PROF_GEMM_BF16_TN, work, stream, bytes);
+  static const int lab_debug = [] { const char* e = getenv("VG_DEBUG_GEMM"); return e ? atoi(e) : 0; }();
+  hipEvent_t lab0 = nullptr, lab1 = nullptr;
+  if (lab_debug == 3) {
+    hipEventCreate(&lab0);
+    hipEventCreate(&lab1);
+    hipEventRecord(lab0, stream);
+  }
   const int rc = vg_host::gemm_group_launch(ps, splits, n, stream);
   vg_host::prof_end(tok, stream);
+  if (lab_debug == 3) {
+    float ms = 0.f;
+    hipEventRecord(lab1, stream);
+    hipEventSynchronize(lab1);
+    hipEventElapsedTime(&ms, lab0, lab1);
+    fprintf(stderr, "[vg_gemm_t] us=%.1f cfg=group M=%d N=%d K=%d a_tr=1 b_tr=1 splits=%d gflop=%.1f\n", ms * 1e3, ps[0].M, ps[0].N,
+            ps[0].K, n, work * 1e-9);
+    hipEventDestroy(lab0);
+    hipEventDestroy(lab1);
+  }
   if (rc != 0) {
     vg_host::set_error("vg_gemm_grouped: launch failed");
     return 3;
