@@ -265,7 +265,25 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
  *   pre-allocated caches [B][Tmax][H*64] at index pos[b], then the query attends over pos[b]+1 frames with
  *   the ALiBi bias of modules/position/alibi.py:9-33 (query position = last; attention.py:56-73).
  * vg_advance: pos[i] += by (device-side frame counter; keeps the step replayable from a hipGraph).
+ * Fused layer path (round 3; the residual stream of the step is fp32 [B][d]):
+ * vg_attn_layer_decode: the whole attention sub-layer of modules/transformer/layers.py:41-56 for one new frame in ONE
+ *   launch (one block per head and sequence): RMSNorm (norm_scale, norm_eps) of x[b], this head's rows of the QKV
+ *   projection (attention.py:52), cache append at pos[b] + attention over the cache (attention.py:56-77), this head's
+ *   64-column band of the out-projection (attention.py:79) ADDED to x1[b] with fp32 atomics; the h = 0 block adds
+ *   x[b] + bo.  x1 must be zero on entry (accumulation target); zero_buf (fp32 [B][d] or NULL) is cleared by this
+ *   launch -- pass the buffer the next layer accumulates into.  d = 64 H, a multiple of 256, at most 1024; weights and
+ *   caches in dtype, biases / slopes / norm_scale fp32.  The sum order of the H contributions, and with it the last bit
+ *   of x1, varies from run to run.
+ * vg_gemm_rows_mixed: vg_gemm_rows with fp32 input rows and fp32 residual (the fused path's residual stream) against
+ *   weights in dtype; zero_buf / zero_n: an fp32 buffer this launch clears (or NULL / 0).
  */
+int vg_attn_layer_decode(const float* x, const float* norm_scale, float norm_eps, const void* wqkv, const float* bqkv,
+                         const void* wo, const float* bo, void* kcache, void* vcache, const float* slopes,
+                         const int32_t* pos, float* x1, float* zero_buf, int B, int Tmax, int H, int dtype,
+                         vg_stream_t stream);
+int vg_gemm_rows_mixed(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* residual,
+                       int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act, int out_f32,
+                       const float* norm_scale, float norm_eps, float* zero_buf, int zero_n, int dtype, vg_stream_t stream);
 int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* residual,
                  int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act, int out_f32,
                  const float* norm_scale, float norm_eps, int dtype, vg_stream_t stream);

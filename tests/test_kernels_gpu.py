@@ -722,6 +722,71 @@ def test_attention_decode_append(F, dtype):
     assert torch.equal(kc[:, 299], kref[:, 299])          # untouched rows stay untouched
 
 
+@pytest.mark.parametrize("H", [4, 16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_layer_decode_fused(F, dtype, H):
+    """vg_attn_layer_decode (RMSNorm + QKV rows of a head + cache append + attention + out-projection band, accumulated
+    into x1 with fp32 atomics) against a float64 restatement of the sub-layer on the same (rounded) weights, per-sequence
+    positions including an empty cache, and against the three-launch path; the buffer it is told to clear is cleared,
+    cache rows other than pos[b] are untouched.  vg_gemm_rows_mixed (fp32 rows x weights in dtype) rides along."""
+    import hipvg
+    B, Tmax = 5, 500
+    D = H * 64
+    g = torch.Generator().manual_seed(7 + H)
+    x = torch.randn(B, D, generator=g).to(dev())
+    g1 = (1 + 0.1 * torch.randn(D, generator=g)).to(dev())
+    wqkv = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(dev()).to(dtype)
+    wo = (torch.randn(D, D, generator=g) * D ** -0.5).to(dev()).to(dtype)
+    bq, bo = (0.1 * torch.randn(3 * D, generator=g)).to(dev()), (0.1 * torch.randn(D, generator=g)).to(dev())
+    kc, vc = rnd(B, Tmax, D, dtype=dtype), rnd(B, Tmax, D, dtype=dtype, seed=1)
+    pos = torch.tensor([0, 1, 129, 400, 498], dtype=torch.int32, device=dev())
+    slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev())
+    k0, v0 = kc.clone(), vc.clone()
+    x1 = torch.zeros(B, D, device=dev())
+    dirty = torch.full((B, D), 3.0, device=dev())
+    F.attention_layer_decode(x, g1, 1e-6, wqkv, bq, wo, bo, kc, vc, slopes, pos, H, x1, zero=dirty)
+    assert torch.all(dirty == 0)
+    # float64 restatement; the projection and the context are rounded to dtype as the kernels do
+    xd = x.double()
+    xn = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * g1.double()
+    if dtype == torch.bfloat16:        # the bf16 kernel multiplies bf16(x * g) and applies rstd to the sums
+        rstd = torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6)
+        xn = (x * g1).to(dtype).double() * rstd
+    qkv = (xn @ wqkv.double().T + bq.double()).to(dtype)
+    for b in range(B):
+        n = int(pos[b]) + 1
+        assert torch.equal(kc[b, n - 1].float(), qkv[b, D:2 * D].float()) or torch.allclose(
+            kc[b, n - 1].float(), qkv[b, D:2 * D].float(), **tol(dtype))
+        kk, vv = k0[b].clone(), v0[b].clone()
+        kk[n - 1], vv[n - 1] = kc[b, n - 1], vc[b, n - 1]
+        q = qkv[b, :D].double().view(H, 1, 64)
+        k = kk[:n].double().view(n, H, 64).transpose(0, 1)
+        v = vv[:n].double().view(n, H, 64).transpose(0, 1)
+        s = q @ k.transpose(1, 2) / 8.0 - slopes.double()[:, None, None] * torch.arange(n - 1, -1, -1, device=dev())[None, None]
+        ctx = (torch.softmax(s, -1) @ v).reshape(D).to(dtype).double()
+        ref = xd[b] + bo.double() + wo.double() @ ctx
+        torch.testing.assert_close(x1[b].double(), ref, **tol(dtype))
+        keep = torch.ones(Tmax, dtype=torch.bool, device=dev())
+        keep[n - 1] = False
+        assert torch.equal(kc[b][keep], k0[b][keep]) and torch.equal(vc[b][keep], v0[b][keep])
+    # the three-launch path on the same inputs (input rows in dtype)
+    kc2, vc2 = k0.clone(), v0.clone()
+    q3 = F.rows_linear(x.to(dtype), wqkv, bq, norm_scale=g1, norm_eps=1e-6)
+    c3 = F.attention_decode_append(q3, kc2, vc2, slopes, pos, H)
+    y3 = F.rows_linear(c3, wo, bo, residual=x.to(dtype), out_f32=True)
+    torch.testing.assert_close(x1, y3, atol=3e-2 if dtype == torch.bfloat16 else 1e-4, rtol=3e-2 if dtype == torch.bfloat16 else 1e-4)
+    # fp32 rows x weights in dtype, norm fused, residual fp32, a buffer to clear
+    w1 = (torch.randn(2 * D, D, generator=g) * D ** -0.5).to(dev()).to(dtype)
+    dirty.fill_(1.0)
+    y = F.rows_linear_mixed(x1, w1, None, act=hipvg.ACT_GELU, norm_scale=g1, norm_eps=1e-6, out_f32=True, zero=dirty)
+    x1d = x1.double()
+    n1 = x1d * torch.rsqrt((x1d * x1d).mean(-1, keepdim=True) + 1e-6) * g1.double()
+    torch.testing.assert_close(y.double(), torch.nn.functional.gelu(n1 @ w1.double().T), **tol(dtype))
+    assert torch.all(dirty == 0)
+    z = F.rows_linear_mixed(y, (torch.randn(D, 2 * D, generator=g) * D ** -0.5).to(dev()).to(dtype), bo, residual=x1, out_f32=True)
+    assert z.dtype == torch.float32 and torch.isfinite(z).all()
+
+
 def test_rccl_bucket_allreduce_through_the_c_abi():
     """vg_comm_unique_id / vg_comm_init / vg_allreduce_bucket / vg_comm_destroy on a one-rank communicator (two
     ranks cannot share a device under RCCL): mean and sum over one rank leave fp32 and bf16 buckets unchanged, the

@@ -19,5 +19,7 @@ done
 python3 tools/lab/decode_timeline.py $O/raw/dec > $O/decode_timeline.txt 2>&1
 SHAPES=16x1000 ITERS=5 python3 tools/lab/pmc_any.py $O/raw/pmc_attn attn2_fwd,attn_bwd_dq,attn_bwd_dkv -- python3 tools/attn_bench.py > $O/pmc_attn_sq.txt 2>&1
 cp $O/raw/pmc_attn/summary.json $O/pmc_attn_sq.json 2>/dev/null
+SHAPE=ffn_out PMC_GROUPS=0,1 python3 tools/lab/pmc_any.py $O/raw/pmc_gemm_k4096 gemm_ph_kernel -- python3 tools/lab/one_gemm.py > $O/pmc_gemm_sq_k4096.txt 2>&1
+SHAPE=qkv PMC_GROUPS=0,1 python3 tools/lab/pmc_any.py $O/raw/pmc_gemm_k1024 gemm_ph_kernel -- python3 tools/lab/one_gemm.py > $O/pmc_gemm_sq_k1024.txt 2>&1
 rm -rf $O/raw
 ls -la $O

@@ -40,26 +40,84 @@ template <> struct Ld8<float> {
   }
 };
 
+// 8 consecutive elements kept as loaded (4 registers for bf16): kernels that keep dozens of loads in flight convert at use.
+// X8<T>: the 8 matching elements of the input vector -- packed bf16 pairs for bf16 weights, so that a dot product of 8 is
+// four v_dot2c_f32_bf16 (exact bf16 products, fp32 accumulation) instead of 8 conversions + 8 FMAs: the fused decode
+// kernels are bound by VALU issue, not by bytes.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <typename T> struct X8;
+template <> struct X8<bf16_t> {
+  bf16x2_t p[4];
+  VG_DEVICE void set(const float (&x)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = bf16x2_t{(__bf16)x[2 * i], (__bf16)x[2 * i + 1]};
+  }
+};
+template <> struct X8<float> {
+  float f[8];
+  VG_DEVICE void set(const float (&x)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = x[i];
+  }
+};
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  bf16x8 v;
+  VG_DEVICE void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  VG_DEVICE float dot(const X8<bf16_t>& x, float a) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{v[2 * i], v[2 * i + 1]}, x.p[i], a, false);
+    return a;
+  }
+  VG_DEVICE void get(float (&o)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+};
+template <> struct Raw8<float> {
+  f32x4 lo, hi;
+  VG_DEVICE void load(const float* p) {
+    lo = *reinterpret_cast<const f32x4*>(p);
+    hi = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  VG_DEVICE float dot(const X8<float>& x, float a) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a = fmaf(x.f[i], lo[i], a);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a = fmaf(x.f[4 + i], hi[i], a);
+    return a;
+  }
+  VG_DEVICE void get(float (&o)[8]) const {
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  }
+};
+
 // Block = 8 output columns x all of K; wave w owns k in [512 w, 512 w + 512), lane l the 8 elements at
 // 512 w + 8 l: every load is a fully coalesced 16-byte-per-lane row segment, the 8 weight rows of the
 // block are requested back to back (8 KiB in flight per wave) and the x rows are read once per lane.
 // Each lane then holds MM x 8 partial dot products; a recursive-halving exchange (xor 32, 16, .. 1; 63
 // shuffles for 64 values instead of 64 full reductions) leaves lane l with the wave-wide sum of value
 // index l (= row l / 8, column l % 8); the waves' sums meet in LDS and wave 0 applies the epilogue.
-template <typename T, int MM>
-__global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restrict__ x, long ldx,
+// TX: type of the input rows and of the residual (T, or float for the fp32 residual stream of the fused decode path:
+// vg_gemm_rows_mixed); zero_ptr: an fp32 buffer this launch clears (the next layer's accumulation target).
+template <typename TX, typename T, int MM>
+__global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const TX* __restrict__ x, long ldx,
                                                                const T* __restrict__ w, long ldw,
                                                                const float* __restrict__ bias,
-                                                               const T* __restrict__ residual, long ldr,
+                                                               const TX* __restrict__ residual, long ldr,
                                                                void* __restrict__ y, long ldy, int M, int N, int K,
                                                                int act, int out_f32,
-                                                               const float* __restrict__ norm_scale, float norm_eps) {
+                                                               const float* __restrict__ norm_scale, float norm_eps,
+                                                               float* __restrict__ zero_ptr, int zero_n) {
   constexpr int V = MM * RC;            // values per lane before the exchange
   constexpr int PER = V / 64;           // values per lane after it (1 for MM = 8, 2 for MM = 16)
   __shared__ float red[RMAXW][V];
   __shared__ float ssq[RMAXW][MM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int n0 = blockIdx.x * RC;
+  if (zero_ptr)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x) zero_ptr[i] = 0.f;
   float v[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) v[i] = 0.f;
@@ -82,7 +140,7 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
     if constexpr (MM <= 8) {
       float xv[MM][8];
 #pragma unroll
-      for (int m = 0; m < MM; ++m) Ld8<T>::get(x + (long)min(m, M - 1) * ldx + k0, xv[m]);
+      for (int m = 0; m < MM; ++m) Ld8<TX>::get(x + (long)min(m, M - 1) * ldx + k0, xv[m]);
 #pragma unroll
       for (int m = 0; m < MM; ++m) {
         if (norm_scale) {
@@ -105,7 +163,7 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
       for (int m = 0; m < MM; ++m) {
         if (m < M) {
           float xv[8];
-          Ld8<T>::get(x + (long)m * ldx + k0, xv);
+          Ld8<TX>::get(x + (long)m * ldx + k0, xv);
           if (norm_scale) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -164,7 +222,7 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const T* __restri
         if (act == VG_ACT_RELU) r = fmaxf(r, 0.f);
         else if (act == VG_ACT_GELU) r = gelu_erf(r);
         else if (act == VG_ACT_SILU) r = silu(r);
-        if (residual) r += to_f32<T>(residual[(long)m * ldr + n]);
+        if (residual) r += to_f32<TX>(residual[(long)m * ldr + n]);
         if (out_f32) reinterpret_cast<float*>(y)[(long)m * ldy + n] = r;
         else reinterpret_cast<T*>(y)[(long)m * ldy + n] = from_f32<T>(r);
       }
@@ -283,6 +341,296 @@ __global__ __launch_bounds__(256) void attn_decode_append_kernel(const T* __rest
   }
 }
 
+// Fused attention sub-layer of the decode step (round 3): one block of 4 waves per (head, sequence) does what
+// vg_gemm_rows (norm1 + QKV), vg_attn_decode_append and vg_gemm_rows (out-projection + residual) did in three
+// launches -- three graph nodes of ~4.5 us floor each for a few microseconds of work:
+//   xn      = x[b] * g1 (the row's rstd multiplies the finished dot products)          RMSNorm, reference norm.py:20-29
+//   q, k, v = rows {q, k, v} x {64 h .. 64 h + 63} of Wqkv . xn * rstd + bias           attention.py:52 (this head only)
+//   cache[b][pos[b]] <- k, v;   ctx = softmax(q . K^T / 8 - slope * distance) V         attention.py:56-77
+//   x1[b]  += Wo[:, 64 h .. 64 h + 63] . ctx  (+ x[b] + bo from the h = 0 block)        attention.py:79, layers.py:52
+// The residual stream is fp32 and x1 is an ACCUMULATION target: it must be zero when the launch starts (the H blocks of
+// a row add into it with fp32 atomics; the sum order, and with it the last bit, varies from run to run); `zero_buf` is
+// the buffer the NEXT layer accumulates into, cleared here.  Weight slices per block: 192 rows of Wqkv (384 KB at
+// d = 1024, bf16) + a 64-column band of Wo (128 KB): the B blocks of a head read the same slices (L2 / MALL hits).
+#ifdef VG_LAB_DSTAMP
+__device__ long long* g_dstamp = nullptr;     // diagnostic build only (tools/lab/variant.sh dstamp vg_decode.hip -DVG_LAB_DSTAMP)
+#define DSTAMP(i) do { if (g_dstamp && threadIdx.x == 0) g_dstamp[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
+// Latency, not bandwidth, bounds this kernel (a block's data is ~0.6 MB, but every dependent wait is a 1.5-2 us memory
+// round trip): 16 waves, so that each phase is ONE pass with all of its loads in flight -- 12 rows of Wqkv per wave
+// (24 loads of 16 bytes per lane, requested BEFORE the row is normalised: weights do not depend on it), 8 rows of the
+// Wo band per lane requested before the cache walk (they land while the soft-max runs), 384 cached frames per pass.
+// A first version with 4 waves and 8-row groups walked 14 round trips in sequence: 28 us per launch.
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_layer_decode_kernel(const float* __restrict__ x, const float* __restrict__ g1,
+                                                                    float eps, const T* __restrict__ wqkv,
+                                                                    const float* __restrict__ bqkv, const T* __restrict__ wo,
+                                                                    const float* __restrict__ bo, T* __restrict__ kc,
+                                                                    T* __restrict__ vc, const float* __restrict__ slopes,
+                                                                    const int* __restrict__ pos, int Tmax, int H,
+                                                                    float* __restrict__ x1, float* __restrict__ zero_buf) {
+  constexpr int DH = 64, DMAX = 1024, NT = NW * 64;
+  constexpr int RPW = 3 * DH / NW;                 // rows of the QKV projection per wave
+  constexpr int RG = sizeof(T) == 2 ? RPW / 2 : RPW / 4;              // rows per pass: 12 / 6 loads in flight per lane
+  // (all 12 rows at once need 96 registers of raw weights on top of the row itself: over the 128 of a 16-wave block)
+  constexpr int CH = 384 / (NW * 8) > 0 ? 384 / (NW * 8) : 1;         // cached frames per lane group and pass
+  static_assert(3 * DH % NW == 0 && RPW % RG == 0, "rows of the head's projection must divide among the waves");
+  __shared__ __attribute__((aligned(16))) float xn[DMAX];
+  __shared__ __attribute__((aligned(16))) float ypart[DMAX];
+  __shared__ float qkv_s[3 * DH];
+  __shared__ float part[NW][DH + 2];
+  __shared__ float ctx_s[DH];
+  __shared__ float redw[NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x, b = blockIdx.y;
+  const int D = H * DH;
+  const float* __restrict__ xr = x + (long)b * D;
+  DSTAMP(0);
+  const int k0 = lane * 8, k1 = lane * 8 + 512;
+  auto wrow = [&](int r) { return wqkv + ((long)(r >> 6) * D + h * DH + (r & 63)) * D; };
+  // ---- first pass of this wave's QKV rows: in flight while the row is normalised
+  Raw8<T> w0[RG], w1[RG];
+#pragma unroll
+  for (int c = 0; c < RG; ++c) {
+    const T* wr = wrow(wave * RPW + c);
+    w0[c].load(wr + min(k0, D - 8));
+    w1[c].load(wr + min(k1, D - 8));
+  }
+  // biases of this wave's rows: lane c holds row c's (a load inside the row loop is a dependent round trip per row and
+  // its wait drains every weight load in flight)
+  float bias_l = 0.f;
+  if (bqkv && lane < RPW) {
+    const int r = wave * RPW + lane;
+    bias_l = bqkv[(r >> 6) * D + h * DH + (r & 63)];
+  }
+  // ---- 1. the row, scaled by the norm weight; sum of squares
+  float ss = 0.f;
+  for (int i = tid * 4; i < D; i += NT * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(g1 + i);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    *reinterpret_cast<f32x4*>(xn + i) = f32x4{v[0] * g[0], v[1] * g[1], v[2] * g[2], v[3] * g[3]};
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) redw[wave] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) tot += redw[w];
+  const float rstd = rsqrtf(tot / (float)D + eps);
+  DSTAMP(1);
+  // ---- 2. this head's 192 rows of the QKV projection
+  {
+    X8<T> xv0, xv1;
+    {
+      float t0[8], t1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        t0[e] = k0 < D ? xn[k0 + e] : 0.f;
+        t1[e] = k1 < D ? xn[k1 + e] : 0.f;
+      }
+      xv0.set(t0);
+      xv1.set(t1);
+    }
+#pragma unroll
+    for (int g0 = 0; g0 < RPW; g0 += RG) {
+      if (g0 > 0) {
+#pragma unroll
+        for (int c = 0; c < RG; ++c) {
+          const T* wr = wrow(wave * RPW + g0 + c);
+          w0[c].load(wr + min(k0, D - 8));
+          w1[c].load(wr + min(k1, D - 8));
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < RG; ++c) {
+        float a = w1[c].dot(xv1, w0[c].dot(xv0, 0.f));
+        a = wave_sum(a);
+        const int r = wave * RPW + g0 + c;
+        const float bias = __shfl(bias_l, g0 + c, 64);
+        if (lane == 0) qkv_s[r] = to_f32<T>(from_f32<T>(a * rstd + bias));     // the projection's output dtype
+      }
+    }
+  }
+  DSTAMP(2);
+  // ---- this head's 64-column band of the out-projection, requested now: 8 lanes per weight row (one 128-byte line),
+  //      8 rows per wave-load; the rows land while the cache is walked
+  const int sub = lane >> 3, ch = lane & 7;
+  constexpr int WU = DMAX / (NW * 8);              // loads per lane that cover DMAX rows
+  Raw8<T> wv[WU];
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int n = min(u * (NW * 8) + wave * 8 + sub, D - 1);
+    wv[u].load(wo + (long)n * D + h * DH + ch * 8);
+  }
+  // ... and the first pass over the cache (the cached frames do not depend on this frame's projection either)
+  const int p0 = min(pos[b], Tmax - 1);
+  const long cbase = ((long)b * Tmax) * D + h * DH;
+  Raw8<T> kr[CH], vr[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int jc = max(min(wave * 8 + sub + NW * 8 * c, p0 - 1), 0);
+    kr[c].load(kc + cbase + (long)jc * D + ch * 8);
+    vr[c].load(vc + cbase + (long)jc * D + ch * 8);
+  }
+  __syncthreads();
+  DSTAMP(3);
+  // ---- 3. attention over the p0 cached frames (as attn_decode_append_kernel) and the new frame (from LDS)
+  constexpr float QSCALE = 0.125f * 1.44269504088896340736f;      // 1 / sqrt(64), log2 domain
+  X8<T> q8;
+  {
+    float t0[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t0[e] = qkv_s[ch * 8 + e];
+    q8.set(t0);            // exact: the projection was rounded to T above
+  }
+  const float slope = slopes[h] * 1.44269504088896340736f;
+  float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = wave * 8 + sub; j0 < p0; j0 += NW * 8 * CH) {
+    if (j0 >= NW * 8 * CH) {                       // later passes (more than 384 cached frames)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int jc = min(j0 + NW * 8 * c, p0 - 1);
+        kr[c].load(kc + cbase + (long)jc * D + ch * 8);
+        vr[c].load(vc + cbase + (long)jc * D + ch * 8);
+      }
+    }
+    float v8[CH][8];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) vr[c].get(v8[c]);
+    float sc[CH], cmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float t = kr[c].dot(q8, 0.f);
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      const int j = j0 + NW * 8 * c;
+      sc[c] = j < p0 ? t * QSCALE - slope * (float)(p0 - j) : -INFINITY;
+      cmax = fmaxf(cmax, sc[c]);
+    }
+    if (cmax > m) {
+      const float f = exp2f(m - cmax);
+      l *= f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= f;
+      m = cmax;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float pj = exp2f(sc[c] - m);
+      l += pj;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, v8[c][e], acc[e]);
+    }
+  }
+  DSTAMP(4);
+  if (wave == 0) {                                  // the cache rows of this frame, for the steps to come (row p0: not read above)
+    kc[cbase + (long)p0 * D + lane] = from_f32<T>(qkv_s[DH + lane]);
+    vc[cbase + (long)p0 * D + lane] = from_f32<T>(qkv_s[2 * DH + lane]);
+  }
+  {   // the new frame (distance 0): every lane group computes its score, group (wave 0, slot 0) owns it
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t = fmaf(qkv_s[ch * 8 + e], qkv_s[DH + ch * 8 + e], t);
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 4, 64);
+    t *= QSCALE;
+    if (wave == 0 && sub == 0) {
+      if (t > m) {
+        const float f = exp2f(m - t);
+        l *= f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= f;
+        m = t;
+      }
+      const float pj = exp2f(t - m);
+      l += pj;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, qkv_s[2 * DH + ch * 8 + e], acc[e]);
+    }
+  }
+  float mw = m;
+  mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
+  mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+  mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+  const float fw = m == -INFINITY ? 0.f : exp2f(m - mw);
+  l *= fw;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] *= fw;
+#pragma unroll
+  for (int o = 8; o <= 32; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave][ch * 8 + e] = acc[e];
+    if (ch == 0) {
+      part[wave][DH] = mw;
+      part[wave][DH + 1] = l;
+    }
+  }
+  __syncthreads();
+  if (tid < DH) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mx = fmaxf(mx, part[w][DH]);
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float mwv = part[w][DH];
+      const float f = mwv == -INFINITY ? 0.f : exp2f(mwv - mx);
+      den = fmaf(part[w][DH + 1], f, den);
+      num = fmaf(part[w][tid], f, num);
+    }
+    ctx_s[tid] = to_f32<T>(from_f32<T>(num / den));       // the attention output's dtype
+  }
+  __syncthreads();
+  DSTAMP(5);
+  // ---- 4. out-projection band x context
+  {
+    X8<T> c8;
+    {
+      float t0[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t0[e] = ctx_s[ch * 8 + e];
+      c8.set(t0);          // exact: the context was rounded to T above
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      float t = wv[u].dot(c8, 0.f);
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      const int n = u * (NW * 8) + wave * 8 + sub;
+      if (ch == 0 && n < D) ypart[n] = t;
+    }
+  }
+  DSTAMP(6);
+  float radd[DMAX / NT > 0 ? DMAX / NT : 1];         // the h = 0 block's x + bo, requested before the barrier
+#pragma unroll
+  for (int i = 0; i < (DMAX / NT > 0 ? DMAX / NT : 1); ++i) {
+    const int n = tid + i * NT;
+    radd[i] = (h == 0 && n < D) ? xr[n] + (bo ? bo[n] : 0.f) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < (DMAX / NT > 0 ? DMAX / NT : 1); ++i) {
+    const int n = tid + i * NT;
+    if (n < D) atomicAdd(x1 + (long)b * D + n, ypart[n] + radd[i]);
+  }
+  DSTAMP(7);
+  if (zero_buf && tid < DH) zero_buf[(long)b * D + h * DH + tid] = 0.f;
+#ifdef VG_LAB_DSTAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DSTAMP(8);
+#endif
+}
+
 // frame embedding of the step: out[b][c] = E[id_b][c] + relu(Wf[c][:] . z_b + bf[c])   (one wave per
 // sequence, lane-strided over the embedding width; models/speech/lvtr.py:161-168 fuse_inputs)
 template <typename T>
@@ -348,19 +696,21 @@ __global__ void advance_kernel(int* __restrict__ pos, int n, int by) {
   if (i < n) pos[i] += by;
 }
 
-template <typename T>
+template <typename TX, typename T>
 int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* bias, const void* res, long ldr, void* y,
                 long ldy, int M, int N, int K, int act, int out_f32, const float* norm_scale, float norm_eps,
-                hipStream_t stream) {
+                float* zero_ptr, int zero_n, hipStream_t stream) {
   int nwaves = (K + RCHUNK - 1) / RCHUNK;
   if (nwaves > RMAXW) nwaves = RMAXW;
   dim3 grid((N + RC - 1) / RC), block(nwaves * 64);
   if (M <= 8)
-    gemm_rows_kernel<T, 8><<<grid, block, 0, stream>>>((const T*)x, ldx, (const T*)w, ldw, bias, (const T*)res, ldr, y,
-                                                      ldy, M, N, K, act, out_f32, norm_scale, norm_eps);
+    gemm_rows_kernel<TX, T, 8><<<grid, block, 0, stream>>>((const TX*)x, ldx, (const T*)w, ldw, bias, (const TX*)res, ldr,
+                                                          y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps, zero_ptr,
+                                                          zero_n);
   else
-    gemm_rows_kernel<T, 16><<<grid, block, 0, stream>>>((const T*)x, ldx, (const T*)w, ldw, bias, (const T*)res, ldr, y,
-                                                       ldy, M, N, K, act, out_f32, norm_scale, norm_eps);
+    gemm_rows_kernel<TX, T, 16><<<grid, block, 0, stream>>>((const TX*)x, ldx, (const T*)w, ldw, bias, (const TX*)res, ldr,
+                                                           y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps, zero_ptr,
+                                                           zero_n);
   return vg_host::check_launch("vg_gemm_rows");
 }
 
@@ -374,10 +724,26 @@ extern "C" int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t l
   VG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "vg_gemm_rows: x / w must be 16-byte aligned");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_gemm_rows: bad dtype %d", dtype);
   if (dtype == VG_BF16)
-    return launch_rows<bf16_t>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps,
-                               stream);
-  return launch_rows<float>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps,
-                            stream);
+    return launch_rows<bf16_t, bf16_t>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale,
+                                       norm_eps, nullptr, 0, stream);
+  return launch_rows<float, float>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps,
+                                   nullptr, 0, stream);
+}
+
+extern "C" int vg_gemm_rows_mixed(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                                  const float* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act,
+                                  int out_f32, const float* norm_scale, float norm_eps, float* zero_buf, int zero_n,
+                                  int dtype, hipStream_t stream) {
+  VG_REQUIRE(M >= 1 && M <= RMAXM && N >= 1 && K >= 8, "vg_gemm_rows_mixed: M=%d (1..%d) N=%d K=%d", M, RMAXM, N, K);
+  VG_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "vg_gemm_rows_mixed: K, ldx, ldw must be multiples of 8");
+  VG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "vg_gemm_rows_mixed: x / w must be 16-byte aligned");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_gemm_rows_mixed: bad dtype %d", dtype);
+  VG_REQUIRE(zero_n >= 0 && (zero_n == 0 || zero_buf != nullptr), "vg_gemm_rows_mixed: zero_n=%d without a buffer", zero_n);
+  if (dtype == VG_BF16)
+    return launch_rows<float, bf16_t>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale,
+                                      norm_eps, zero_buf, zero_n, stream);
+  return launch_rows<float, float>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps,
+                                   zero_buf, zero_n, stream);
 }
 
 extern "C" int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,
@@ -392,6 +758,28 @@ extern "C" int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache
     attn_decode_append_kernel<float><<<grid, dim3(256), 0, stream>>>((const float*)qkv, (float*)kcache, (float*)vcache,
                                                                    (float*)out, slopes, pos, Tmax, H);
   return vg_host::check_launch("vg_attn_decode_append");
+}
+
+extern "C" int vg_attn_layer_decode(const float* x, const float* norm_scale, float norm_eps, const void* wqkv,
+                                    const float* bqkv, const void* wo, const float* bo, void* kcache, void* vcache,
+                                    const float* slopes, const int32_t* pos, float* x1, float* zero_buf, int B, int Tmax,
+                                    int H, int dtype, hipStream_t stream) {
+  VG_REQUIRE(B > 0 && Tmax > 0 && H > 0 && H * 64 <= 1024 && H % 4 == 0,
+             "vg_attn_layer_decode: B=%d Tmax=%d H=%d (model width 64 H: a multiple of 256, at most 1024)", B, Tmax, H);
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_layer_decode: bad dtype %d", dtype);
+  VG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)norm_scale % 16) == 0 && ((uintptr_t)wqkv % 16) == 0 &&
+                 ((uintptr_t)wo % 16) == 0 && ((uintptr_t)kcache % 16) == 0 && ((uintptr_t)vcache % 16) == 0,
+             "vg_attn_layer_decode: operands must be 16-byte aligned");
+  dim3 grid(H, B);
+  if (dtype == VG_BF16)
+    attn_layer_decode_kernel<bf16_t, 16><<<grid, dim3(1024), 0, stream>>>(x, norm_scale, norm_eps, (const bf16_t*)wqkv, bqkv,
+                                                                          (const bf16_t*)wo, bo, (bf16_t*)kcache,
+                                                                          (bf16_t*)vcache, slopes, pos, Tmax, H, x1, zero_buf);
+  else
+    attn_layer_decode_kernel<float, 16><<<grid, dim3(1024), 0, stream>>>(x, norm_scale, norm_eps, (const float*)wqkv, bqkv,
+                                                                         (const float*)wo, bo, (float*)kcache, (float*)vcache,
+                                                                         slopes, pos, Tmax, H, x1, zero_buf);
+  return vg_host::check_launch("vg_attn_layer_decode");
 }
 
 extern "C" int vg_advance(int32_t* pos, int n, int by, hipStream_t stream) {
@@ -417,3 +805,7 @@ extern "C" int vg_sample_token(const float* logits, int V, float temperature, co
   sample_token_kernel<<<dim3(B), dim3(64), 0, stream>>>(logits, V, 1.0f / temperature, uniform, frame, ldf, pos);
   return vg_host::check_launch("vg_sample_token");
 }
+
+#ifdef VG_LAB_DSTAMP
+extern "C" int vg_lab_set_dstamp(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dstamp), &buf, sizeof(buf)); }
+#endif

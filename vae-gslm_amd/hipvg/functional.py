@@ -1422,6 +1422,43 @@ def rows_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act
     return y
 
 
+def rows_linear_mixed(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
+                      residual: Optional[Tensor] = None, out_f32: bool = False, norm_scale: Optional[Tensor] = None,
+                      norm_eps: float = 0.0, zero: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """:func:`rows_linear` for the fused decode path: fp32 input rows (and fp32 residual) against ``weight`` in the
+    compute dtype; ``zero``: an fp32 buffer the launch clears (the next layer's accumulation target)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and weight.stride(1) == 1 and weight.shape[1] == K
+    assert residual is None or residual.dtype == torch.float32
+    assert zero is None or (zero.dtype == torch.float32 and zero.is_contiguous())
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32 if out_f32 else weight.dtype, device=x.device)
+    assert y.dtype == (torch.float32 if out_f32 else weight.dtype)
+    b = None if bias is None else bias.detach().float()
+    check(lib().vg_gemm_rows_mixed(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(b), ptr(residual),
+                                   0 if residual is None else residual.stride(0), ptr(y), y.stride(0), M, N, K, int(act),
+                                   int(out_f32), ptr(norm_scale), float(norm_eps), ptr(zero),
+                                   0 if zero is None else zero.numel(), dtype_id(weight.dtype), stream()),
+          "vg_gemm_rows_mixed")
+    return y
+
+
+def attention_layer_decode(x: Tensor, norm_scale: Tensor, norm_eps: float, wqkv: Tensor, bqkv: Optional[Tensor], wo: Tensor,
+                           bo: Optional[Tensor], kcache: Tensor, vcache: Tensor, slopes: Tensor, pos: Tensor, H: int,
+                           x1: Tensor, zero: Optional[Tensor] = None) -> Tensor:
+    """x1 += attention sub-layer of one new frame (vg_attn_layer_decode); x, x1 fp32 [B, 64 H], x1 zero on entry."""
+    B, D = x.shape
+    assert x.dtype == torch.float32 and x1.dtype == torch.float32 and x.is_contiguous() and x1.is_contiguous()
+    assert wqkv.is_contiguous() and wo.is_contiguous() and wqkv.shape == (3 * D, D) and wo.shape == (D, D) and D == 64 * H
+    assert zero is None or (zero.dtype == torch.float32 and zero.is_contiguous() and zero.shape == x.shape)
+    bq = None if bqkv is None else bqkv.detach().float()
+    b_o = None if bo is None else bo.detach().float()
+    check(lib().vg_attn_layer_decode(ptr(x), ptr(norm_scale), float(norm_eps), ptr(wqkv), ptr(bq), ptr(wo), ptr(b_o),
+                                     ptr(kcache), ptr(vcache), ptr(slopes), ptr(pos), ptr(x1), ptr(zero), B,
+                                     kcache.shape[1], H, dtype_id(wqkv.dtype), stream()), "vg_attn_layer_decode")
+    return x1
+
+
 def embed_fuse(frame: Tensor, emb: Tensor, wf: Tensor, bf: Optional[Tensor], dtype: torch.dtype) -> Tensor:
     """frame [B, 1 + latent] fp32 (token id, z) -> E[id] + relu(Wf z + bf) as [B, E] in ``dtype``."""
     B, E = frame.shape[0], emb.shape[1]

@@ -76,6 +76,16 @@ class DecodeSession:
             self._flow_packed = HF.pack_flow_params(self._flow_params)
             hi, lo = flow.layers[0].scale_range
             self._flow_kw = dict(eps=flow.layers[0].norm.eps, hi=float(hi), lo=float(lo))
+        # fused layer path (round 3): fp32 residual stream, the attention sub-layer as ONE launch per layer
+        # (vg_attn_layer_decode: three graph nodes become one) that accumulates into one of two zero-initialised buffers.
+        # A (head, sequence) block then pulls 0.5 MB of weights through one CU's 134 GB/s instead of 384 blocks sharing
+        # them, so the node it saves is worth it from 4 sequences up (measured per frame, fused / five launches per layer:
+        # B = 1 0.675 / 0.663 ms, 4 0.663 / 0.673, 8 0.663 / 0.684, 16 0.93 / 1.16).  VG_DECODE_FUSED=1 / 0 forces it.
+        import os
+        mode = os.environ.get("VG_DECODE_FUSED", "auto")
+        fits = self.D % 256 == 0 and self.D <= 1024 and self.D == 64 * self.H
+        self._fused = fits and (mode == "1" or (mode != "0" and self.B >= 4))
+        self._x1 = [torch.zeros(self.B, self.D, dtype=torch.float32, device=self.dev) for _ in range(2)]
         self._graph = None
         self._last = {}
 
@@ -115,10 +125,25 @@ class DecodeSession:
         x = HF.embed_fuse(frame2d, m.token_embedding.weight.detach(), fuser.weight.detach(),
                           None if fuser.bias is None else fuser.bias.detach(), dt)
         st = self.stack
+        fused = self._fused
         if st.linear is not None:
-            x = HF.rows_linear(x, self._w(st.linear.weight), st.linear.bias)
+            x = HF.rows_linear(x, self._w(st.linear.weight), st.linear.bias, out_f32=fused)
+        elif fused:
+            x = x.float()
+        if fused and self.L % 2 == 1:          # layer l accumulates into _x1[l % 2] and clears the other one
+            self._x1[0].zero_()
         for l, layer in enumerate(st.layers):
             att = layer.self_attn
+            if fused:
+                # fp32 residual stream; the attention sub-layer is ONE launch that adds into x1 (zero on entry)
+                x1 = HF.attention_layer_decode(x, layer.norm1.scale.detach(), layer.norm1.eps,
+                                               self._w(att.in_proj.weight), att.in_proj.bias,
+                                               self._w(att.out_proj.weight), att.out_proj.bias, self.kc[l], self.vc[l],
+                                               self.slopes, self.pos, self.H, self._x1[l % 2], zero=self._x1[(l + 1) % 2])
+                mid = HF.rows_linear_mixed(x1, self._w(layer.linear1.weight), layer.linear1.bias, act=hipvg.ACT_GELU,
+                                           norm_scale=layer.norm3.scale.detach(), norm_eps=layer.norm3.eps, out_f32=True)
+                x = HF.rows_linear_mixed(mid, self._w(layer.linear2.weight), layer.linear2.bias, residual=x1, out_f32=True)
+                continue
             qkv = HF.rows_linear(x, self._w(att.in_proj.weight), att.in_proj.bias,
                                  norm_scale=layer.norm1.scale.detach(), norm_eps=layer.norm1.eps)
             ctx = HF.attention_decode_append(qkv, self.kc[l], self.vc[l], self.slopes, self.pos, self.H)
@@ -128,13 +153,14 @@ class DecodeSession:
             x = HF.rows_linear(mid, self._w(layer.linear2.weight), layer.linear2.bias, residual=x1)
         fn = dict(norm_scale=st.final_norm.scale.detach(), norm_eps=st.final_norm.eps)
         qs, ts, tp = m.q_spliter.linear, m.token_spliter.linear, m.token_predictor.linear
-        cond = HF.rows_linear(x, self._w(qs.weight), qs.bias, act=hipvg.ACT_RELU, **fn)
+        head_linear = HF.rows_linear_mixed if fused else HF.rows_linear
+        cond = head_linear(x, self._w(qs.weight), qs.bias, act=hipvg.ACT_RELU, **fn)
         heads = HF.rows_linear(cond, self._heads_w, self._heads_b, out_f32=True)    # (B, 2 latent + L*128): prior | FiLM
         mu_ls, wb = heads[:, :2 * lat_dim], heads[:, 2 * lat_dim:]
         eps = noise if noise is not None else torch.randn(B, lat_dim, device=self.dev)
         HF.coupling_flow_reverse(eps.reshape(B, lat_dim), wb, self._flow_params, packed=self._flow_packed,
                                  mu_ls=mu_ls, temperature=self.temperature, out=frame2d[:, 1:], **self._flow_kw)
-        hid = HF.rows_linear(x, self._w(ts.weight), ts.bias, act=hipvg.ACT_RELU, **fn)
+        hid = head_linear(x, self._w(ts.weight), ts.bias, act=hipvg.ACT_RELU, **fn)
         logits = HF.rows_linear(hid, self._w(tp.weight), tp.bias, out_f32=True)      # (B, vocab)
         u01 = uniform if uniform is not None else torch.rand(B, device=self.dev)
         HF.sample_token(logits, self.token_temperature, u01, frame2d, self.pos)      # also pos += 1
