@@ -252,7 +252,7 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
 
 /* ---------------------------------------------------------------- autoregressive decode step
  * LVTR.step (models/speech/lvtr.py:227-286): one new frame per sequence.
- * vg_gemm_rows: y[M][N] = act(x[M][K] W[N][K]^T + bias) + residual for M <= 16 rows (HBM-bound on W; exact
+ * vg_gemm_rows: y[M][N] = act(x[M][K] W[N][K]^T + bias) + residual for M <= 64 rows, in groups of 8 (HBM-bound on W; exact
  *   fp32 accumulation; replaces nn.Linear at modules/attention/attention.py:52,79,
  *   modules/transformer/layers.py:82, modules/linear/layers.py:192 on the decode path).
  *   x, W, residual in dtype; y in dtype or fp32 (out_f32); K, ldx, ldw multiples of 8.  norm_scale (fp32 [K]

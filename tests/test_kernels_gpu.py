@@ -644,9 +644,9 @@ def test_flat_adamw_matches_torch(F):
 # ------------------------------------------------------------------ decode-step kernels
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(1, 200, 1024), (3, 8, 1024), (8, 3072, 1024), (8, 1024, 4096), (16, 136, 64),
-                                   (5, 24, 8192)])
+                                   (5, 24, 8192), (9, 72, 512), (33, 256, 1024), (64, 40, 256)])
 def test_gemm_rows(F, dtype, shape):
-    """vg_gemm_rows (the Linear of the autoregressive step) vs fp64: row counts 1..16, column counts that are
+    """vg_gemm_rows (the Linear of the autoregressive step) vs fp64: row counts 1..64 (groups of 8 along grid.y), column counts that are
     not multiples of 8, reduction lengths from 64 to 8192, bias / GELU / residual epilogue, fp32 output."""
     M, N, K = shape
     x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=K ** -0.5)

@@ -1,6 +1,6 @@
 // Kernels of the autoregressive decode step: one new frame per sequence.
 //
-//  * vg_gemm_rows: y[M<=16][N] = epi(x[M][K] W[N][K]^T) -- the Linear layers of LVTR.step
+//  * vg_gemm_rows: y[M<=64][N] = epi(x[M][K] W[N][K]^T) -- the Linear layers of LVTR.step
 //    (reference models/speech/lvtr.py:227-286 -> modules/transformer/layers.py:41-93,
 //    modules/attention/attention.py:52,79, modules/linear/layers.py:192) when only a handful of
 //    rows exist.  The product is bound by streaming W once from HBM (403 MB of bf16 weights per step at
@@ -22,7 +22,7 @@ namespace {
 constexpr int RC = 8;           // output columns per block
 constexpr int RCHUNK = 512;     // k range of one wave (64 lanes x 8 elements: 1 KiB of a bf16 weight row per load)
 constexpr int RMAXW = 8;        // waves per block = min(8, ceil(K / 512)); longer K: a wave walks several ranges
-constexpr int RMAXM = 16;
+constexpr int RMAXM = 64;       // rows per launch: groups of 8 along grid.y
 
 template <typename T> struct Ld8;     // 8 consecutive elements as floats
 template <> struct Ld8<bf16_t> {
@@ -116,8 +116,16 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const TX* __restr
   __shared__ float ssq[RMAXW][MM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int n0 = blockIdx.x * RC;
-  if (zero_ptr)
+  if (zero_ptr && blockIdx.y == 0)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x) zero_ptr[i] = 0.f;
+  // more than MM rows: blockIdx.y picks a group of MM (the groups read the same weight rows: the second one from L2)
+  {
+    const int r0 = blockIdx.y * MM;
+    x += (long)r0 * ldx;
+    if (residual) residual += (long)r0 * ldr;
+    y = out_f32 ? (void*)(reinterpret_cast<float*>(y) + (long)r0 * ldy) : (void*)(reinterpret_cast<T*>(y) + (long)r0 * ldy);
+    M = min(M - r0, MM);
+  }
   float v[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) v[i] = 0.f;
@@ -702,8 +710,13 @@ int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* b
                 float* zero_ptr, int zero_n, hipStream_t stream) {
   int nwaves = (K + RCHUNK - 1) / RCHUNK;
   if (nwaves > RMAXW) nwaves = RMAXW;
-  dim3 grid((N + RC - 1) / RC), block(nwaves * 64);
-  if (M <= 8)
+  // more than 8 rows run as groups of up to 8 (grid.y) on the 8-row kernel: its 16-row instance keeps one input row
+  // in registers at a time (128 accumulators) and walks the rows' loads one after the other -- B = 16 decode 1.16 ms per
+  // frame against 0.68 at B = 8 before this
+  static const int rows16 = [] { const char* e = getenv("VG_ROWS16"); return e ? atoi(e) : 0; }();
+  if (M > 16) VG_REQUIRE(!rows16, "vg_gemm_rows: VG_ROWS16 takes at most 16 rows (M=%d)", M);
+  dim3 grid((N + RC - 1) / RC, (M > 8 && !rows16) ? (M + 7) / 8 : 1), block(nwaves * 64);
+  if (M <= 8 || !rows16)
     gemm_rows_kernel<TX, T, 8><<<grid, block, 0, stream>>>((const TX*)x, ldx, (const T*)w, ldw, bias, (const TX*)res, ldr,
                                                           y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps, zero_ptr,
                                                           zero_n);

@@ -1408,7 +1408,7 @@ def coupling_flow_reverse(u, wb, params, *, eps, hi, lo, packed: Optional[Tensor
 def rows_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
                 residual: Optional[Tensor] = None, out_f32: bool = False, norm_scale: Optional[Tensor] = None,
                 norm_eps: float = 0.0) -> Tensor:
-    """y = act(x W^T + b) + residual for a handful of rows (M <= 16): the HBM-bound Linear of the
+    """y = act(x W^T + b) + residual for a handful of rows (M <= 64, groups of 8): the HBM-bound Linear of the
     autoregressive step (vg_gemm_rows).  ``weight`` must already be in x's dtype (see :func:`shadow`)."""
     M, K = x.shape
     N = weight.shape[0]

@@ -46,8 +46,8 @@ class DecodeSession:
         dev = device if device is not None else next(model.parameters()).device
         self.dev = torch.device(dev)
         self.dt = hipvg.compute_dtype()
-        if self.B > 16:
-            raise NotImplementedError("vg_gemm_rows handles up to 16 sequences per session")
+        if self.B > 64:
+            raise NotImplementedError("vg_gemm_rows handles up to 64 sequences per session")
         head = model.transformer[1]
         if not head.plain:
             raise NotImplementedError("DecodeSession needs the plain (mean, logstd) prior head")
