@@ -277,6 +277,11 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
  * vg_gemm_rows_mixed: vg_gemm_rows with fp32 input rows and fp32 residual (the fused path's residual stream) against
  *   weights in dtype; zero_buf / zero_n: an fp32 buffer this launch clears (or NULL / 0).
  */
+/* vg_decode_noise: the random draws of one decode step in one launch, from a counter-based generator (Philox 4x32-10) keyed
+ *   by (seed, b, pos[b]): normal[b][0..n_normal) ~ N(0, 1) (Box-Muller), uniform[b] in [0, 1).  pos is the device-side frame
+ *   counter, so a replayed hipGraph draws fresh numbers (replaces torch.randn / torch.rand of lvtr.py:262-284 on that path). */
+int vg_decode_noise(uint64_t seed, const int32_t* pos, float* normal, int n_normal, float* uniform, int B,
+                    vg_stream_t stream);
 int vg_attn_layer_decode(const float* x, const float* norm_scale, float norm_eps, const void* wqkv, const float* bqkv,
                          const void* wo, const float* bo, void* kcache, void* vcache, const float* slopes,
                          const int32_t* pos, float* x1, float* zero_buf, int B, int Tmax, int H, int dtype,

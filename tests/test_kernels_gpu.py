@@ -665,6 +665,36 @@ def test_gemm_rows(F, dtype, shape):
                                atol=5e-5 if dtype == torch.float32 else 5e-3, rtol=2e-4)
 
 
+def test_decode_noise(F):
+    """vg_decode_noise: a function of (seed, sequence, pos) only; standard normals and uniforms in [0, 1) by their
+    moments over 64 sequences x 400 frames; a different seed, sequence or frame gives different numbers."""
+    B, n = 64, 4
+    pos = torch.zeros(B, dtype=torch.int32, device=dev())
+    draws_n, draws_u = [], []
+    for t in range(400):
+        pos.fill_(t)
+        a, u = F.decode_noise(1234, pos, n)
+        draws_n.append(a)
+        draws_u.append(u)
+    a2, u2 = F.decode_noise(1234, pos, n)
+    assert torch.equal(a2, draws_n[-1]) and torch.equal(u2, draws_u[-1])          # same key, same numbers
+    a3, _ = F.decode_noise(1235, pos, n)
+    assert not torch.equal(a3, a2)
+    z, u = torch.stack(draws_n).double(), torch.stack(draws_u).double()
+    assert torch.isfinite(z).all() and float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.03 and abs(float((z ** 4).mean()) - 3.0) < 0.2
+    assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float(u.var()) - 1.0 / 12.0) < 0.005
+    # no two (sequence, frame) cells share their numbers; the four normals of a cell are uncorrelated
+    flat = z.reshape(-1, n)
+    assert torch.unique(flat[:, 0]).numel() > 0.999 * flat.shape[0]
+    c = torch.corrcoef(flat.T)
+    assert float((c - torch.eye(n, dtype=c.dtype, device=c.device)).abs().max()) < 0.03
+    # odd counts: 1 and 7 normals per sequence
+    for nn in (1, 7):
+        a, _ = F.decode_noise(7, pos, nn)
+        assert a.shape == (B, nn) and torch.isfinite(a).all()
+
+
 def test_decode_sampling_kernels(F):
     """vg_embed_fuse == embedding + relu(Linear); vg_sample_token draws by inverse CDF (exact index for given
     uniforms, frame counter advanced, empirical frequencies follow softmax(logits / T))."""

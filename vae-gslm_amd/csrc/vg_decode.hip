@@ -699,6 +699,47 @@ __global__ __launch_bounds__(64) void sample_token_kernel(const float* __restric
   }
 }
 
+// Random draws of one decode step from a counter-based generator (Philox 4x32-10, Salmon et al. 2011) keyed by
+// (seed, sequence, pos[b]): normal[b][0..nn) (Box-Muller on pairs) and uniform[b] in [0, 1) in ONE launch.  A replayed
+// hipGraph draws fresh numbers because pos advances on the device; torch's graph-safe generator costs two fill launches
+// per replay plus one launch per distribution (4 graph nodes of ~4.7 us per frame).
+VG_DEVICE void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__global__ __launch_bounds__(64) void decode_noise_kernel(unsigned long long seed, const int* __restrict__ pos,
+                                                          float* __restrict__ normal, int nn, float* __restrict__ uniform,
+                                                          int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const unsigned p = (unsigned)pos[b], k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  auto pair = [&](unsigned w0, unsigned w1, int o) {      // Box-Muller: two words -> normals o, o + 1
+    const float u0 = ((float)w0 + 0.5f) * 2.3283064365386963e-10f;          // (0, 1]: 2^-32 (w + 1/2)
+    const float u1 = ((float)w1 + 0.5f) * 2.3283064365386963e-10f;
+    const float r = sqrtf(-2.f * logf(u0)), a = 6.28318530717958647692f * u1;
+    if (o < nn) normal[(long)b * nn + o] = r * cosf(a);
+    if (o + 1 < nn) normal[(long)b * nn + o + 1] = r * sinf(a);
+  };
+  // block 0 of this (sequence, frame): words 0, 1 -> normals 0, 1; word 3 -> the uniform draw (24 bits: never 1.0)
+  unsigned c[4] = {p, (unsigned)b, 0u, 0x5eedu};
+  philox4x32_10(c, k0, k1);
+  if (uniform) uniform[b] = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+  pair(c[0], c[1], 0);
+  for (int k = 1; 4 * k - 2 < nn; ++k) {                  // block k -> normals 4 k - 2 .. 4 k + 1
+    unsigned d[4] = {p, (unsigned)b, (unsigned)k, 0x5eedu};
+    philox4x32_10(d, k0, k1);
+    pair(d[0], d[1], 4 * k - 2);
+    pair(d[2], d[3], 4 * k);
+  }
+}
+
 __global__ void advance_kernel(int* __restrict__ pos, int n, int by) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) pos[i] += by;
@@ -817,6 +858,13 @@ extern "C" int vg_sample_token(const float* logits, int V, float temperature, co
   VG_REQUIRE(B > 0 && V > 0 && temperature > 0.f, "vg_sample_token: B=%d V=%d temperature=%g", B, V, temperature);
   sample_token_kernel<<<dim3(B), dim3(64), 0, stream>>>(logits, V, 1.0f / temperature, uniform, frame, ldf, pos);
   return vg_host::check_launch("vg_sample_token");
+}
+
+extern "C" int vg_decode_noise(uint64_t seed, const int32_t* pos, float* normal, int n_normal, float* uniform, int B,
+                               hipStream_t stream) {
+  VG_REQUIRE(B > 0 && n_normal >= 0 && pos != nullptr, "vg_decode_noise: B=%d n_normal=%d", B, n_normal);
+  decode_noise_kernel<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(seed, pos, normal, n_normal, uniform, B);
+  return vg_host::check_launch("vg_decode_noise");
 }
 
 #ifdef VG_LAB_DSTAMP

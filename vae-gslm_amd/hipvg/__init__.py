@@ -81,6 +81,7 @@ SIGNATURES = {
     "vg_embed_fuse": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "vg_sample_token": [_vp, _i, _f, _vp, _vp, _i, _vp, _i, _vp],
     "vg_attn_decode_append": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vg_decode_noise": [C.c_uint64, _vp, _vp, _i, _vp, _i, _vp],
     "vg_attn_layer_decode": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vg_gemm_rows_mixed": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp],
     "vg_advance": [_vp, _i, _i, _vp],

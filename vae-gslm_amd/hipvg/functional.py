@@ -1443,6 +1443,17 @@ def rows_linear_mixed(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, 
     return y
 
 
+def decode_noise(seed: int, pos: Tensor, n_normal: int) -> Tuple[Tensor, Tensor]:
+    """(normal [B, n_normal], uniform [B]) for the frame at pos[b] of every sequence (vg_decode_noise): a function of
+    (seed, b, pos[b]) only, so hipGraph replays draw fresh numbers as the device-side counter advances."""
+    B = pos.numel()
+    normal = torch.empty((B, n_normal), dtype=torch.float32, device=pos.device)
+    uniform = torch.empty((B,), dtype=torch.float32, device=pos.device)
+    check(lib().vg_decode_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(pos), ptr(normal), n_normal, ptr(uniform), B, stream()),
+          "vg_decode_noise")
+    return normal, uniform
+
+
 def attention_layer_decode(x: Tensor, norm_scale: Tensor, norm_eps: float, wqkv: Tensor, bqkv: Optional[Tensor], wo: Tensor,
                            bo: Optional[Tensor], kcache: Tensor, vcache: Tensor, slopes: Tensor, pos: Tensor, H: int,
                            x1: Tensor, zero: Optional[Tensor] = None) -> Tensor:

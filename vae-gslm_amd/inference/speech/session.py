@@ -85,6 +85,8 @@ class DecodeSession:
         mode = os.environ.get("VG_DECODE_FUSED", "auto")
         fits = self.D % 256 == 0 and self.D <= 1024 and self.D == 64 * self.H
         self._fused = fits and (mode == "1" or (mode != "0" and self.B >= 4))
+        # seed of this session's draws (vg_decode_noise), taken from torch's CPU generator: torch.manual_seed reproduces a run
+        self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self._x1 = [torch.zeros(self.B, self.D, dtype=torch.float32, device=self.dev) for _ in range(2)]
         self._graph = None
         self._last = {}
@@ -157,12 +159,17 @@ class DecodeSession:
         cond = head_linear(x, self._w(qs.weight), qs.bias, act=hipvg.ACT_RELU, **fn)
         heads = HF.rows_linear(cond, self._heads_w, self._heads_b, out_f32=True)    # (B, 2 latent + L*128): prior | FiLM
         mu_ls, wb = heads[:, :2 * lat_dim], heads[:, 2 * lat_dim:]
-        eps = noise if noise is not None else torch.randn(B, lat_dim, device=self.dev)
+        # the step's random draws: one launch keyed by (session seed, sequence, frame counter) instead of torch.randn +
+        # torch.rand (under graph replay those cost two fill launches for the generator state and one launch each)
+        drawn = None
+        if noise is None or uniform is None:
+            drawn = HF.decode_noise(self._seed, self.pos, lat_dim)
+        eps = noise if noise is not None else drawn[0]
         HF.coupling_flow_reverse(eps.reshape(B, lat_dim), wb, self._flow_params, packed=self._flow_packed,
                                  mu_ls=mu_ls, temperature=self.temperature, out=frame2d[:, 1:], **self._flow_kw)
         hid = head_linear(x, self._w(ts.weight), ts.bias, act=hipvg.ACT_RELU, **fn)
         logits = HF.rows_linear(hid, self._w(tp.weight), tp.bias, out_f32=True)      # (B, vocab)
-        u01 = uniform if uniform is not None else torch.rand(B, device=self.dev)
+        u01 = uniform if uniform is not None else drawn[1]
         HF.sample_token(logits, self.token_temperature, u01, frame2d, self.pos)      # also pos += 1
         self._last = {"logits": logits.view(B, 1, -1), "mu_ls": heads[:, None, :2 * lat_dim], "hidden": x}
         if self.keep_latent:      # the normalised state itself is only needed by tests / callers that ask for it
@@ -170,17 +177,23 @@ class DecodeSession:
             self._last["transformer_latent"] = lat.view(B, 1, -1)
 
     @torch.no_grad()
-    def step(self, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def step(self, noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Consumes the frame produced by the previous call (or by :meth:`prefill`) and returns the next
-        one, (B, 1, 1 + latent).  With ``noise`` (teacher-forced tests) the step runs eagerly."""
+        one, (B, 1, 1 + latent) -- a copy, or ``out`` (same shape) filled in place (``generate`` hands in the slice of its
+        result: one copy per frame instead of two).  With ``noise`` (teacher-forced tests) the step runs eagerly."""
+        def result():
+            if out is None:
+                return self.frame.clone()
+            out.copy_(self.frame)
+            return out
         if noise is not None or not self.use_graph:
             self._step_body(noise)
-            return self.frame.clone()
+            return result()
         if self._graph is None:
             # lazy initialisations (weight casts, allocator) happen on the first, eager, frame; the
             # second frame is captured and every later one replays it
             self._step_body()
-            out, eager_last = self.frame.clone(), self._last
+            first, eager_last = result(), self._last
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream())
             graph = torch.cuda.CUDAGraph()
@@ -190,10 +203,10 @@ class DecodeSession:
             torch.cuda.current_stream().wait_stream(side)
             self._graph, self._graph_last = graph, self._last     # the capture's output buffers
             self._last = eager_last
-            return out
+            return first
         self._graph.replay()
         self._last = self._graph_last
-        return self.frame.clone()
+        return result()
 
     def force_frame(self, frame: torch.Tensor) -> None:
         """Overwrite the frame the next :meth:`step` consumes (teacher forcing)."""
@@ -205,5 +218,5 @@ class DecodeSession:
         assert int(self.pos.max()) + length <= self.Tmax, "cache too small for the requested continuation"
         out = torch.empty(self.B, length, self.frame.shape[-1], dtype=torch.float32, device=self.dev)
         for t in range(length):
-            out[:, t:t + 1] = self.step()
+            self.step(out=out[:, t:t + 1])
         return out
