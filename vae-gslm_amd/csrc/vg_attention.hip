@@ -1055,10 +1055,16 @@ static int attn_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// VG_ATTN_V1=1 selects the round-1/2 forward kernel for bf16 as well (A/B measurements)
-static bool attn_v1() {
-  static const bool v = [] { const char* e = getenv("VG_ATTN_V1"); return e && atoi(e) != 0; }();
-  return v;
+// Which bf16 forward kernel: attn2_fwd_kernel works on blocks of 256 queries, the round-1/2 kernel on blocks of 128.  When
+// the last 256-query block of a sequence would be at most half full, or when 256-query blocks do not give every CU two
+// blocks, the 128-query kernel is the faster one (B = 16, H = 16; us per launch, 256 / 128: T = 250 12.4 / 9.8, 384
+// 21.4 / 15.7, 640 37.6 / 32.7, 896 57.3 / 52.3, 1150 81.9 / 76.3 -- and 500 23.8 / 24.7, 1000 59.4 / 63.2, 1280
+// 85.4 / 94.6 the other way).  VG_ATTN_V1=1 / 0 forces one of them (A/B measurements).
+static bool attn_v1(int Tn, long bh) {
+  static const int v = [] { const char* e = getenv("VG_ATTN_V1"); return e ? atoi(e) : -1; }();
+  if (v >= 0) return v != 0;
+  const int w256 = (Tn + 255) / 256 * 256 - Tn, w128 = (Tn + 127) / 128 * 128 - Tn;
+  return w256 - w128 >= 128 || (long)((Tn + 255) / 256) * bh < 512;
 }
 
 // Tiles whose every probability is below 2^-thr of its row's sum are dropped by the bf16 kernels (ALiBi makes the far
@@ -1081,7 +1087,7 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_FWD, 256.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   const int sched = attn_env("VG_ATTN_SCHED", 0);
   if constexpr (sizeof(T) == 2) {
-    if (!attn_v1()) {
+    if (!attn_v1(Tn, (long)B * H)) {
       dim3 grid2(((Tn + QB2 - 1) / QB2) * H * B);
       if (attn_env("VG_ATTN_FWD_DESC", 1))
         hipLaunchKernelGGL(attn2_fwd_kernel<true>, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
