@@ -117,3 +117,15 @@ def test_roctx_ranges_wrap_the_entry_points(monkeypatch):
             % os.path.join(ROOT, "vae-gslm_amd"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VG_ROCTX="1"), capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("VG_RUN_ASAN", "0") != "1",
+                    reason="host ASan + UBSan build of the library (about a minute of hipcc): VG_RUN_ASAN=1 python -m pytest tests/test_cabi.py")
+def test_host_code_is_clean_under_asan_and_ubsan():
+    """tools/asan_host_check.py: every source built with -fsanitize=address,undefined for the HOST side (-fno-gpu-sanitize;
+    GPU sanitizers do not exist on this pool), then the tile-choice cost model over 55 k descriptors, the block-count
+    helpers and the argument validation of the launchers run under the sanitizer runtime without a report."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_host_check.py")], capture_output=True, text=True)
+    assert r.returncode == 0 and "no report" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
