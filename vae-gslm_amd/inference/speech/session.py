@@ -10,15 +10,20 @@ This session produces the same frames from a different machine model:
 * the prompt is consumed by ONE pass of the training-path kernels (flash attention over the whole prompt),
   whose per-layer key/value projections are copied into the caches;
 * every Linear of the step is ``vg_gemm_rows`` (HBM-bound: the step streams the 403 MB of bf16 weights
-  once), norms / flow reverse / Gaussian sample are the row kernels of the training path;
+  once; more than 8 sequences run as groups of 8 rows), norms / flow reverse are the row kernels of the training path;
+  from 4 sequences up the attention sub-layer of a layer is ONE launch on an fp32 residual stream
+  (``vg_attn_layer_decode``: RMSNorm, QKV rows of a head, cache append, attention, out-projection band);
+* the step's random draws (Gaussian latent noise, the uniform number of the token draw) come from one launch of a
+  counter-based generator keyed by (session seed, sequence, device-side frame counter) (``vg_decode_noise``);
 * the whole step -- embedding of the previous output, 16 layers, prior head, reverse flow, token
   soft-max and draw, write-back of the new frame into the step's own input buffer, ``pos += 1`` -- is
-  captured once into a hipGraph and replayed per frame; the random draws use the graph-safe generator.
+  captured once into a hipGraph and replayed per frame (58 graph nodes at the full config).
 
 Only the token + flow model of ``vae-gslm.yaml`` is covered (the same scope as ``LVTR.forward``).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -81,7 +86,6 @@ class DecodeSession:
         # A (head, sequence) block then pulls 0.5 MB of weights through one CU's 134 GB/s instead of 384 blocks sharing
         # them, so the node it saves is worth it from 4 sequences up (measured per frame, fused / five launches per layer:
         # B = 1 0.675 / 0.663 ms, 4 0.663 / 0.673, 8 0.663 / 0.684, 16 0.93 / 1.16).  VG_DECODE_FUSED=1 / 0 forces it.
-        import os
         mode = os.environ.get("VG_DECODE_FUSED", "auto")
         fits = self.D % 256 == 0 and self.D <= 1024 and self.D == 64 * self.H
         self._fused = fits and (mode == "1" or (mode != "0" and self.B >= 4))
