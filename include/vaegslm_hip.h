@@ -204,7 +204,7 @@ int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, float* out, in
               vg_stream_t stream);
 /* up to VG_COLSUM_MAX_TASKS independent fp32 column sums (dst[cols] (+)= sum over rows of src[rows][ld]) in one
  * launch: the partial-sum arrays behind the bias / norm-scale gradients of one backward node */
-enum { VG_COLSUM_MAX_TASKS = 8 };
+enum { VG_COLSUM_MAX_TASKS = 32 };
 typedef struct vg_colsum_task {
   const float* src;
   int rows, cols;

@@ -42,7 +42,7 @@ class ColsumTask(C.Structure):
     _fields_ = [("src", _vp), ("rows", _i), ("cols", _i), ("ld", _i64), ("dst", _vp), ("accumulate", _i)]
 
 
-COLSUM_MAX_TASKS = 8
+COLSUM_MAX_TASKS = 32
 
 # name -> argtypes (restype is always int); must list EVERY symbol of the header
 SIGNATURES = {

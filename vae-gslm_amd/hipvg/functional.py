@@ -226,12 +226,67 @@ def colsum(x: Tensor, into: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+# Deferred second stage of the small column sums (bias / norm-scale gradients).  A backward pass produces ~100 of them;
+# each finishing launch is ~4.5 us of graph-node floor for a few KB of work.  Between defer_vec_grads(True) and
+# flush_vec_grads() the (partial-sum array -> parameter gradient) tasks of sunk parameters are queued and leave in
+# launches of up to COLSUM_MAX_TASKS; the trainer brackets every backward piece that nothing reads gradients inside of.
+_DEFER = {"on": False, "tasks": [], "keep": [], "fire": []}
+
+
+def defer_vec_grads(on: bool) -> None:
+    if not on:
+        flush_vec_grads()
+    _DEFER["on"] = bool(on) and _COLSUM_MULTI and _flag("VG_DEFER_COLSUM", "1")
+
+
+def reset_vec_grads() -> None:
+    """Drop the queue without launching (a backward piece that raised, e.g. inside a failed graph capture: the queued
+    addresses belong to tensors of that attempt)."""
+    _DEFER["on"] = False
+    _DEFER["tasks"], _DEFER["keep"], _DEFER["fire"] = [], [], []
+
+
+def flush_vec_grads() -> None:
+    import hipvg
+    tasks, fire = _DEFER["tasks"], _DEFER["fire"]
+    for i in range(0, len(tasks), hipvg.COLSUM_MAX_TASKS):
+        chunk = tasks[i:i + hipvg.COLSUM_MAX_TASKS]
+        arr = (hipvg.ColsumTask * len(chunk))(*chunk)
+        check(lib().vg_colsum_multi(arr, len(chunk), stream()), "vg_colsum_multi")
+    _DEFER["tasks"], _DEFER["keep"], _DEFER["fire"] = [], [], []
+    for p in fire:
+        _fire(p)
+
+
+def _small_f32(src: Tensor, n: int) -> bool:
+    return (src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1 and src.shape[0] <= 2048
+            and src.shape[1] % 4 == 0 and src.stride(0) % 4 == 0 and src.data_ptr() % 16 == 0 and src.shape[1] == n)
+
+
+def _defer_task(p: Tensor, src: Tensor) -> None:
+    import hipvg
+    dst = _grad_buffer(p).view(-1)
+    _DEFER["tasks"].append(hipvg.ColsumTask(src.data_ptr(), src.shape[0], src.shape[1], src.stride(0), dst.data_ptr(), 1))
+    _DEFER["keep"].append((src, dst))
+    _DEFER["fire"].append(p)
+    if len(_DEFER["tasks"]) >= 4 * hipvg.COLSUM_MAX_TASKS:
+        flush_vec_grads()
+
+
 def vec_grad(p, src2d: Tensor):
     """Gradient of a vector-like parameter = column sums of ``src2d``: accumulated straight into
     ``p.grad`` when the gradient sink applies (returns None), else returned as a tensor."""
     if p is None:
         return None
     if _sinkable(p):
+        if _DEFER["on"] and src2d.dim() == 2:
+            if _small_f32(src2d, p.numel()):
+                _defer_task(p, src2d)
+                return None
+            parts = colsum_partials([src2d]) if src2d.shape[1] == p.numel() else None
+            if parts is not None and _small_f32(parts[0], p.numel()):
+                _defer_task(p, parts[0])        # first stage now (the matrix is alive), second stage with the others
+                return None
         sink_colsum(p, src2d)
         return None
     return colsum(src2d).view_as(p)
@@ -251,6 +306,9 @@ def vec_grads(pairs):
               and src.data_ptr() % 16 == 0 and src.shape[1] == p.numel() and len(tasks) < hipvg.COLSUM_MAX_TASKS)
         if not ok:
             out[i] = vec_grad(p, src)
+            continue
+        if _DEFER["on"] and _sinkable(p):
+            _defer_task(p, src)
             continue
         if _sinkable(p):
             dst, acc = _grad_buffer(p).view(-1), 1

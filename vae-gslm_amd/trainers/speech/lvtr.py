@@ -160,10 +160,24 @@ class LVTRTrainer(BaseTrainer):
         if segment is not None:
             n = len(self._cut_layers)
             cuts = cuts[segment:segment + 1] if segment < n - 1 else cuts[n - 1:]
-        for below, leaves in cuts:
-            pairs = [(t, l.grad) for t, l in zip(below, leaves) if l.grad is not None]
-            if pairs:
-                torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+        from hipvg import functional as HF
+        HF.defer_vec_grads(self._defer_colsums())
+        try:
+            for below, leaves in cuts:
+                pairs = [(t, l.grad) for t, l in zip(below, leaves) if l.grad is not None]
+                if pairs:
+                    torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+        except BaseException:
+            HF.reset_vec_grads()
+            raise
+        HF.defer_vec_grads(False)          # flushes: every bucket of this piece is complete when it returns
+
+    def _defer_colsums(self) -> bool:
+        """The finishing launches of the bias / scale column sums may wait for the end of a backward piece wherever
+        nothing acts on "gradient ready" inside it: one rank, a non-final micro-step, or a captured segment (its
+        buckets are reduced after the replay)."""
+        return (self.reducer is None or self.reducer.world == 1 or not self.reducer.sync_now
+                or getattr(self, "_segmented", False))
 
     def _training_loop(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None,
                        kld_weight=None, backward_tail: bool = True):
@@ -200,7 +214,14 @@ class LVTRTrainer(BaseTrainer):
             fold = [(p, p.grad) for p in self._owned if p.grad is not None]
             for p, _ in fold:
                 p.grad = None
-        loss.backward()
+        from hipvg import functional as HF
+        HF.defer_vec_grads(self._defer_colsums())
+        try:
+            loss.backward()
+        except BaseException:
+            HF.reset_vec_grads()
+            raise
+        HF.defer_vec_grads(False)
         if backward_tail:
             self._backward_tail()
         if fold is not None:
