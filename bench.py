@@ -355,14 +355,24 @@ def main():
             ms, nbytes, n = hipvg.prof_read(k)
             if n:
                 hbm_kernels[k] = {"launches": n, "avg_us": 1e3 * ms / n, "gb_per_s": nbytes / (ms * 1e-3) / 1e9}
-        hipvg.prof_enable(False)
         achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
+        # attention kernels: causal-exact FLOP, the backward counted as 2 x forward (no recompute credit)
         a_ms = a_work = 0.0
         for k in ("attn_fwd", "attn_bwd"):
-            if k in kinds:
-                a_ms += kinds[k]["launches"] * kinds[k]["avg_us"] * 1e-3
-                a_work += kinds[k]["tflops"] * 1e12 * kinds[k]["launches"] * kinds[k]["avg_us"] * 1e-6
+            ms, work, n = hipvg.prof_read(k)
+            a_ms += ms
+            a_work += work
         path_tflops = (tot_work + a_work) / ((tot_ms + a_ms) * 1e-3) / 1e12 if tot_ms + a_ms else 0.0
+        # the north_star's gate, "attention + FFN path": the Transformer layers' own GEMMs (QKV, out-projection, FFN x
+        # {forward, dgrad, wgrad}: every launch recorded inside TransformerLayerFn) + the attention kernels, without
+        # the conv stacks, heads and input projection that the family figure above also holds
+        l_ms = l_work = 0.0
+        for k in ("gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn"):
+            ms, work, n = hipvg.prof_read_tag(k, hipvg.PROF_TAG_LAYER)
+            l_ms += ms
+            l_work += work
+        layer_tflops = (l_work + a_work) / ((l_ms + a_ms) * 1e-3) / 1e12 if l_ms + a_ms else 0.0
+        hipvg.prof_enable(False)
         peaks = hipvg.probe_peaks(device)          # this box, this run: register-fed MFMA chains and a 1 GiB copy
         # HBM-side bytes per launch of the same kernel family: bench.py cannot collect PMC counters itself, so
         # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
@@ -390,7 +400,10 @@ def main():
                                       if args.coalesce and accum > 1 else ""),
                        "micro_batch": B, "grad_accum": accum, "seq_len": T_SEQ,
                        "parallelism": f"dp{world}", "loss": float(out["loss"]),
-                       "lengths": "U{T/2..T}, valid frames counted" if args.ragged else "full",
+                       "lengths": ("U{T/2..T}, valid frames counted; the timed batches were stepped once before the timed "
+                                   "region (untimed) so that every (padded length, row bucket) hipGraph exists: "
+                                   "the timed steps replay, on weights those extra steps have already updated")
+                                  if args.ragged else "full",
                        "inputs": ("pinned host batches, asynchronous H2D two steps ahead (PCIe inside the timed region)"
                                   if args.host_batches else "resident in HBM before the timed region"),
                        "accumulation": "one launch sequence over B x accum sequences" if args.coalesce else "per micro-batch"},
@@ -406,6 +419,9 @@ def main():
                          "hbm_copy_measured_tb_per_s": peaks["hbm_copy_tb_per_s"], "hbm_peak_tb_per_s": 8.0,
                          # the north_star's gate: bf16 GEMMs and attention kernels together (causal-exact FLOP)
                          "attn_gemm_path_tflops": path_tflops, "attn_gemm_path_frac": path_tflops / (PEAK_BF16 / 1e12),
+                         # ... and the gate as the north_star words it: Transformer-layer GEMMs + attention only
+                         "attn_ffn_path_tflops": layer_tflops, "attn_ffn_path_frac": layer_tflops / (PEAK_BF16 / 1e12),
+                         "attn_ffn_path_ms": l_ms + a_ms,
                          "hbm_kernels": hbm_kernels,
                          "measured_on": ("one eager optimizer step right after the timed hipGraph replays"
                                          if args.graph else "the timed region"),
@@ -426,11 +442,8 @@ def main():
                             "graph_bucket_mb": hp.hip.get("graph_bucket_mb", None),
                             "graph_cut_layers": list(getattr(trainer, "graph_cuts", [])) if args.graph else None,
                             "eager_bucket_mb": hp.hip.get("bucket_mb", None),
-                            "predicted_exposed_ms_at_8_gpus": 1.9,
                             "note": "allreduce_ms: events on the communication stream (rank 0); comm_exposed_ms: "
-                                    "ms_per_step minus the same steps with the collectives skipped; "
-                                    "predicted_exposed_ms_at_8_gpus: DESIGN.md section 5 (the last 24 % of 908 MB at "
-                                    "~7 x 45 GB/s effective + the pipelined AdamW tail), to be falsified by the first 8-GPU run"}
+                                    "ms_per_step minus the same steps with the collectives skipped"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

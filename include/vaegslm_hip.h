@@ -278,10 +278,12 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
  *   weights in dtype; zero_buf / zero_n: an fp32 buffer this launch clears (or NULL / 0).
  */
 /* vg_decode_noise: the random draws of one decode step in one launch, from a counter-based generator (Philox 4x32-10) keyed
- *   by (seed, b, pos[b]): normal[b][0..n_normal) ~ N(0, 1) (Box-Muller), uniform[b] in [0, 1).  pos is the device-side frame
- *   counter, so a replayed hipGraph draws fresh numbers (replaces torch.randn / torch.rand of lvtr.py:262-284 on that path). */
-int vg_decode_noise(uint64_t seed, const int32_t* pos, float* normal, int n_normal, float* uniform, int B,
-                    vg_stream_t stream);
+ *   by (seed, epoch[0], b, pos[b]): normal[b][0..n_normal) ~ N(0, 1) (Box-Muller), uniform[b] in [0, 1).  pos is the
+ *   device-side frame counter, so a replayed hipGraph draws fresh numbers (replaces torch.randn / torch.rand of
+ *   lvtr.py:262-284 on that path); epoch (one device int32, or NULL = 0) is read by the launch, so the caller bumps it
+ *   whenever pos is rewound (a new prompt on the same session) and the replayed graph leaves the old stream of draws. */
+int vg_decode_noise(uint64_t seed, const int32_t* pos, const int32_t* epoch, float* normal, int n_normal, float* uniform,
+                    int B, vg_stream_t stream);
 int vg_attn_layer_decode(const float* x, const float* norm_scale, float norm_eps, const void* wqkv, const float* bqkv,
                          const void* wo, const float* bo, void* kcache, void* vcache, const float* slopes,
                          const int32_t* pos, float* x1, float* zero_buf, int B, int Tmax, int H, int dtype,
@@ -415,6 +417,13 @@ enum { VG_PROF_GEMM_BF16_NT = 0, VG_PROF_GEMM_BF16_NN = 1, VG_PROF_GEMM_BF16_TN 
        VG_PROF_DWNORM_FWD = 9, VG_PROF_DWNORM_BWD = 10, VG_PROF_KINDS = 11 };
 int vg_prof_enable(int on);
 int vg_prof_read(int kind, double* total_ms, double* total_work, int* launches);
+/* Scope tags: vg_prof_tag(t) marks every launch recorded from now on with t and returns the previous tag (the layer
+ * function brackets its forward and backward with VG_PROF_TAG_LAYER, so bench.py can report the north_star's
+ * "attention + FFN path" -- the Transformer layers' GEMMs and attention kernels -- apart from the conv stacks and
+ * heads); vg_prof_read_tag() is vg_prof_read() restricted to one tag. */
+enum { VG_PROF_TAG_NONE = 0, VG_PROF_TAG_LAYER = 1 };
+int vg_prof_tag(int tag);
+int vg_prof_read_tag(int kind, int tag, double* total_ms, double* total_work, int* launches);
 /* summed ALGORITHMIC bytes (operands and results once each) of the recorded launches of one kind (GEMM kinds) */
 int vg_prof_read_bytes(int kind, double* total_bytes);
 

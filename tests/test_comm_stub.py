@@ -113,10 +113,15 @@ comm.destroy()
 assert comm.world() == 0
 dist.barrier()
 dist.destroy_process_group()
-print('ok', rank)
+# one write per rank into its own file: two ranks printing into one pipe interleave ("okok  01")
+with open(os.path.join(os.environ['VG_TEST_OUT'], f'rank{rank}.ok'), 'w') as f:
+    f.write(f'ok {rank}')
 """
 
 
 def test_two_rank_id_handoff_over_gloo(fake_rccl, tmp_path):
-    r = run(TWO_RANK, {"VG_RCCL_LIB": fake_rccl, "MASTER_ADDR": "127.0.0.1"}, nproc=2, tmp=str(tmp_path))
-    assert r.returncode == 0 and "ok 0" in r.stdout and "ok 1" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    r = run(TWO_RANK, {"VG_RCCL_LIB": fake_rccl, "MASTER_ADDR": "127.0.0.1", "VG_TEST_OUT": str(tmp_path)}, nproc=2,
+            tmp=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    for rank in (0, 1):
+        assert (tmp_path / f"rank{rank}.ok").read_text() == f"ok {rank}", r.stdout[-2000:] + r.stderr[-3000:]

@@ -1112,8 +1112,9 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
                void* dqkv, float* delta, int B, int Tn, int H, const int32_t* lengths, const int32_t* cu, int Mtot,
                hipStream_t stream) {
   const long nthreads = (long)Mtot * H * 8;
-  // algorithmic work of the backward: 5 products (S, dP, dV, dK, dQ) = 2.5 x forward
-  const int tok = vg_host::prof_begin(VG_PROF_ATTN_BWD, 640.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
+  // algorithmic work of the backward: 2 x forward (training = 3 x forward, no credit for the scores the
+  // backward recomputes; the kernels execute 5 products -- S, dP, dV, dK, dQ -- i.e. 2.5 x)
+  const int tok = vg_host::prof_begin(VG_PROF_ATTN_BWD, 512.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
                      (const T*)out, (const T*)dout, delta, Mtot, H);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);

@@ -715,11 +715,14 @@ VG_DEVICE void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
   }
 }
 __global__ __launch_bounds__(64) void decode_noise_kernel(unsigned long long seed, const int* __restrict__ pos,
-                                                          float* __restrict__ normal, int nn, float* __restrict__ uniform,
-                                                          int B) {
+                                                          const int* __restrict__ epoch, float* __restrict__ normal, int nn,
+                                                          float* __restrict__ uniform, int B) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   const unsigned p = (unsigned)pos[b], k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  // draw epoch (device word the caller bumps whenever the frame counter is rewound: a new prompt on the same session):
+  // the fourth counter word, so the same (sequence, frame) draws fresh numbers in every epoch
+  const unsigned tag = 0x5eedu + (epoch ? (unsigned)epoch[0] * 0x9E3779B9u : 0u);
   auto pair = [&](unsigned w0, unsigned w1, int o) {      // Box-Muller: two words -> normals o, o + 1
     const float u0 = ((float)w0 + 0.5f) * 2.3283064365386963e-10f;          // (0, 1]: 2^-32 (w + 1/2)
     const float u1 = ((float)w1 + 0.5f) * 2.3283064365386963e-10f;
@@ -728,12 +731,12 @@ __global__ __launch_bounds__(64) void decode_noise_kernel(unsigned long long see
     if (o + 1 < nn) normal[(long)b * nn + o + 1] = r * sinf(a);
   };
   // block 0 of this (sequence, frame): words 0, 1 -> normals 0, 1; word 3 -> the uniform draw (24 bits: never 1.0)
-  unsigned c[4] = {p, (unsigned)b, 0u, 0x5eedu};
+  unsigned c[4] = {p, (unsigned)b, 0u, tag};
   philox4x32_10(c, k0, k1);
   if (uniform) uniform[b] = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
   pair(c[0], c[1], 0);
   for (int k = 1; 4 * k - 2 < nn; ++k) {                  // block k -> normals 4 k - 2 .. 4 k + 1
-    unsigned d[4] = {p, (unsigned)b, (unsigned)k, 0x5eedu};
+    unsigned d[4] = {p, (unsigned)b, (unsigned)k, tag};
     philox4x32_10(d, k0, k1);
     pair(d[0], d[1], 4 * k - 2);
     pair(d[2], d[3], 4 * k);
@@ -860,10 +863,10 @@ extern "C" int vg_sample_token(const float* logits, int V, float temperature, co
   return vg_host::check_launch("vg_sample_token");
 }
 
-extern "C" int vg_decode_noise(uint64_t seed, const int32_t* pos, float* normal, int n_normal, float* uniform, int B,
-                               hipStream_t stream) {
+extern "C" int vg_decode_noise(uint64_t seed, const int32_t* pos, const int32_t* epoch, float* normal, int n_normal,
+                               float* uniform, int B, hipStream_t stream) {
   VG_REQUIRE(B > 0 && n_normal >= 0 && pos != nullptr, "vg_decode_noise: B=%d n_normal=%d", B, n_normal);
-  decode_noise_kernel<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(seed, pos, normal, n_normal, uniform, B);
+  decode_noise_kernel<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(seed, pos, epoch, normal, n_normal, uniform, B);
   return vg_host::check_launch("vg_decode_noise");
 }
 

@@ -575,6 +575,11 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
 #endif
   TileCtx<A_TR, B_TR, BM> c;
   c.init(p, blockIdx.x, blockIdx.z, wave, lane);
+  // (Round 4, measured and rejected: running half of the first round's blocks on half their K tiles so that the CUs fall
+  // out of step and their epilogues no longer meet at the HBM -- with the removed work paid back by extra blocks, so that
+  // the makespan in tile units stays the same -- made the FFN-in products 15-19 % SLOWER, 134.7 -> 160.3 us plain and
+  // 183.5 -> 218.6 us with GELU + stored derivative at M = 16384: the blocks of an XCD read the same K slice of a few
+  // operand panels at the same time, and that lockstep is what keeps the panels L2 hits.)
   f32x4 acc[BM / 32][4];           // [a * 4 + i][b * 2 + j]; SCHED 2: [a * (BM / 64) + i][j]
   zero_acc(acc);
   if constexpr (SCHED == 1) ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);

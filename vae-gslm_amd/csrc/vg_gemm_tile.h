@@ -11,6 +11,18 @@ namespace {
 
 constexpr int BK = 64;
 
+// Results and epilogue operands are streamed once: non-temporal stores / loads keep them from evicting the operand panels
+// the other blocks of the XCD are still reading out of L2 (round 4, measured in one call on cold operands: QKV forward
+// 105-110 -> 97-101 us, N = K = 1024 34.4 -> 31.4 (NN 41 -> 34.5), N = 2048 / K = 512 45 -> 39, FFN-in 138-142 -> 134-137; in the
+// training step 485.6 -> 497.7 k tokens/s).  -DVG_EPI_TEMPORAL restores the plain forms for A/B builds.
+#ifndef VG_EPI_TEMPORAL
+#define VG_EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define VG_EPI_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define VG_EPI_STORE(ptr, val) (*(ptr) = (val))
+#define VG_EPI_LOAD(ptr) (*(ptr))
+#endif
+
 // ---- issue the LDS-DMA loads of one operand tile
 //  ROW image: [R rows][128 B], chunk position p of row r holds source chunk p ^ ((r >> 1) & 7)
 //  TR  image: R/128 sub-images of [64 krows][256 B]; 64-B granule position g of krow k holds
@@ -98,13 +110,13 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
         if (act == VG_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
       }
     }
-    if (p.aux_out) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx) = o;
+    if (p.aux_out) VG_EPI_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx), o);
   } else {
     if (p.aux_out) {
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx) = o;
+      VG_EPI_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx), o);
     }
     if (act == VG_ACT_RELU) {
 #pragma unroll
@@ -157,7 +169,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
+    VG_EPI_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + idx), o);
   }
 }
 
@@ -339,6 +351,7 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
 // N % 8 == 0, T >= 16 when lengths are given.  colpart is supported (the dgrad that also reduces the bias gradient).
 enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3, EPI_SILU_SAVE = 4 };
 
+
 template <int BM, int BN, int WM, int WN, bool ILV, bool ILVC, int EPI>
 VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0) {
   constexpr int NW = WM * WN;
@@ -384,7 +397,7 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
           const int m = m0 + band_row(i) + ps * RPP + crow;
-          if (col_ok && m < p.M) g[i][ps] = *reinterpret_cast<const bf16x8*>(src + (long)m * p.ldc + n);
+          if (col_ok && m < p.M) g[i][ps] = VG_EPI_LOAD(reinterpret_cast<const bf16x8*>(src + (long)m * p.ldc + n));
         }
     }
   }
@@ -433,7 +446,7 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
           v[e] *= cdf[0];
           v[e + 1] *= cdf[1];
         }
-        *reinterpret_cast<bf16x8*>(aout + idx[ps]) = o;
+        VG_EPI_STORE(reinterpret_cast<bf16x8*>(aout + idx[ps]), o);
       } else if constexpr (EPI == EPI_SILU_SAVE) {
         if (p.pre_add != nullptr) {
 #pragma unroll
@@ -446,7 +459,7 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
           o[e] = (bf16_t)(sg * (1.0f + v[e] * (1.0f - sg)));
           v[e] *= sg;
         }
-        *reinterpret_cast<bf16x8*>(aout + idx[ps]) = o;
+        VG_EPI_STORE(reinterpret_cast<bf16x8*>(aout + idx[ps]), o);
       } else if constexpr (EPI == EPI_DACT) {
         if (p.dact == VG_ACT_STORED) {
 #pragma unroll
@@ -474,7 +487,7 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-      *reinterpret_cast<bf16x8*>(cout + idx[ps]) = o;
+      VG_EPI_STORE(reinterpret_cast<bf16x8*>(cout + idx[ps]), o);
       if (p.colpart) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) cp[e] += v[e];

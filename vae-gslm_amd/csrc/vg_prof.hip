@@ -11,8 +11,9 @@
 #include "../../include/vaegslm_hip.h"
 
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double work, bytes; };
+struct Rec { hipEvent_t a, b; int kind, tag; double work, bytes; };
 std::atomic<int> g_on{0};
+std::atomic<int> g_tag{0};            // caller-set scope of the launches recorded from now on (vg_prof_tag)
 std::mutex g_mu;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -31,7 +32,7 @@ int prof_begin(int kind, double work, hipStream_t stream, double bytes) {
   if (!g_on.load(std::memory_order_relaxed)) return -1;
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_recs.size() >= MAX_RECS) return -1;
-  Rec r{take_event(), take_event(), kind, work, bytes};
+  Rec r{take_event(), take_event(), kind, g_tag.load(std::memory_order_relaxed), work, bytes};
   hipEventRecord(r.a, stream);
   g_recs.push_back(r);
   return (int)g_recs.size() - 1;
@@ -51,12 +52,15 @@ extern "C" int vg_prof_enable(int on) {
   return 0;
 }
 
-extern "C" int vg_prof_read(int kind, double* total_ms, double* total_work, int* launches) {
+extern "C" int vg_prof_tag(int tag) { return g_tag.exchange(tag); }
+
+namespace {
+int read_recs(int kind, int tag, double* total_ms, double* total_work, int* launches) {
   std::lock_guard<std::mutex> lk(g_mu);
   double ms = 0.0, work = 0.0;
   int n = 0;
   for (auto& r : g_recs) {
-    if (r.kind != kind) continue;
+    if (r.kind != kind || (tag >= 0 && r.tag != tag)) continue;
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
@@ -66,6 +70,14 @@ extern "C" int vg_prof_read(int kind, double* total_ms, double* total_work, int*
   if (total_work) *total_work = work;
   if (launches) *launches = n;
   return 0;
+}
+}  // namespace
+
+extern "C" int vg_prof_read(int kind, double* total_ms, double* total_work, int* launches) {
+  return read_recs(kind, -1, total_ms, total_work, launches);
+}
+extern "C" int vg_prof_read_tag(int kind, int tag, double* total_ms, double* total_work, int* launches) {
+  return read_recs(kind, tag, total_ms, total_work, launches);
 }
 
 // summed ALGORITHMIC bytes (operands and results once each) of the recorded launches of one kind

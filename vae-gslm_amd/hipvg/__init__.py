@@ -81,7 +81,7 @@ SIGNATURES = {
     "vg_embed_fuse": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "vg_sample_token": [_vp, _i, _f, _vp, _vp, _i, _vp, _i, _vp],
     "vg_attn_decode_append": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "vg_decode_noise": [C.c_uint64, _vp, _vp, _i, _vp, _i, _vp],
+    "vg_decode_noise": [C.c_uint64, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "vg_attn_layer_decode": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vg_gemm_rows_mixed": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp],
     "vg_advance": [_vp, _i, _i, _vp],
@@ -111,6 +111,8 @@ SIGNATURES = {
     "vg_prof_enable": [_i],
     "vg_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
     "vg_prof_read_bytes": [_i, C.POINTER(C.c_double)],
+    "vg_prof_tag": [_i],
+    "vg_prof_read_tag": [_i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
     "vg_probe_mfma": [_vp, _i, _i, _vp],
     "vg_probe_copy": [_vp, _vp, _i64, _i, _vp],
 }
@@ -156,6 +158,20 @@ def prof_enable(on: bool) -> None:
 def prof_read(kind: str):
     ms, work, n = C.c_double(), C.c_double(), _i()
     lib().vg_prof_read(PROF_KINDS[kind], C.byref(ms), C.byref(work), C.byref(n))
+    return ms.value, work.value, n.value
+
+
+PROF_TAG_NONE, PROF_TAG_LAYER = 0, 1
+
+
+def prof_tag(tag: int) -> int:
+    """Scope tag of the launches recorded from now on; returns the previous one."""
+    return lib().vg_prof_tag(int(tag))
+
+
+def prof_read_tag(kind: str, tag: int):
+    ms, work, n = C.c_double(), C.c_double(), _i()
+    lib().vg_prof_read_tag(PROF_KINDS[kind], int(tag), C.byref(ms), C.byref(work), C.byref(n))
     return ms.value, work.value, n.value
 
 

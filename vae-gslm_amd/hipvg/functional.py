@@ -248,12 +248,15 @@ def reset_vec_grads() -> None:
 
 def flush_vec_grads() -> None:
     import hipvg
-    tasks, fire = _DEFER["tasks"], _DEFER["fire"]
+    # the queue is emptied BEFORE the launches: if one of them raises, nothing stale (task pointers into tensors of
+    # this attempt) is left for the next flush to relaunch; `keep` holds the tensors alive until the launches are queued
+    tasks, fire, keep = _DEFER["tasks"], _DEFER["fire"], _DEFER["keep"]
+    _DEFER["tasks"], _DEFER["keep"], _DEFER["fire"] = [], [], []
     for i in range(0, len(tasks), hipvg.COLSUM_MAX_TASKS):
         chunk = tasks[i:i + hipvg.COLSUM_MAX_TASKS]
         arr = (hipvg.ColsumTask * len(chunk))(*chunk)
         check(lib().vg_colsum_multi(arr, len(chunk), stream()), "vg_colsum_multi")
-    _DEFER["tasks"], _DEFER["keep"], _DEFER["fire"] = [], [], []
+    del keep
     for p in fire:
         _fire(p)
 
@@ -995,8 +998,28 @@ class TransformerLayerFn(torch.autograd.Function):
     all ops are row-local or causal), which is what lets the un-masked wgrad /
     bias-grad reductions match the reference's masked ones."""
 
+    # every launch of the node carries the measurement scope "Transformer layer" (vg_prof_tag: bench.py reports the
+    # attention + FFN path of the north_star apart from the conv stacks and heads)
     @staticmethod
-    def forward(ctx, x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps, pack=None):
+    def forward(ctx, *args):
+        import hipvg
+        prev = hipvg.prof_tag(hipvg.PROF_TAG_LAYER)
+        try:
+            return TransformerLayerFn._forward(ctx, *args)
+        finally:
+            hipvg.prof_tag(prev)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import hipvg
+        prev = hipvg.prof_tag(hipvg.PROF_TAG_LAYER)
+        try:
+            return TransformerLayerFn._backward(ctx, dy)
+        finally:
+            hipvg.prof_tag(prev)
+
+    @staticmethod
+    def _forward(ctx, x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, lengths, B, T, H, eps, pack=None):
         M, D = x.shape
         F_ = w1.shape[0]
         dt = x.dtype
@@ -1030,7 +1053,7 @@ class TransformerLayerFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def _backward(ctx, dy):
         (x, n1, rstd1, qkv, att, lse, x1, n3, rstd3, u, h, sq, so, s1, s2, sc1, sc3, slopes,
          lengths) = ctx.saved_tensors
         n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2 = ctx.params
@@ -1501,14 +1524,15 @@ def rows_linear_mixed(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, 
     return y
 
 
-def decode_noise(seed: int, pos: Tensor, n_normal: int) -> Tuple[Tensor, Tensor]:
+def decode_noise(seed: int, pos: Tensor, n_normal: int, epoch: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """(normal [B, n_normal], uniform [B]) for the frame at pos[b] of every sequence (vg_decode_noise): a function of
-    (seed, b, pos[b]) only, so hipGraph replays draw fresh numbers as the device-side counter advances."""
+    (seed, epoch[0], b, pos[b]) only, so hipGraph replays draw fresh numbers as the device-side counter advances;
+    ``epoch`` (one int32 on the device) is bumped by the caller whenever ``pos`` is rewound."""
     B = pos.numel()
     normal = torch.empty((B, n_normal), dtype=torch.float32, device=pos.device)
     uniform = torch.empty((B,), dtype=torch.float32, device=pos.device)
-    check(lib().vg_decode_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(pos), ptr(normal), n_normal, ptr(uniform), B, stream()),
-          "vg_decode_noise")
+    check(lib().vg_decode_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(pos), ptr(epoch) if epoch is not None else None,
+                                ptr(normal), n_normal, ptr(uniform), B, stream()), "vg_decode_noise")
     return normal, uniform
 
 

@@ -91,6 +91,10 @@ class DecodeSession:
         self._fused = fits and (mode == "1" or (mode != "0" and self.B >= 4))
         # seed of this session's draws (vg_decode_noise), taken from torch's CPU generator: torch.manual_seed reproduces a run
         self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # draw epoch: a device word the captured graph READS (the seed itself is baked into the graph by value); every
+        # prefill() bumps it, so a second generation on this session -- the frame counter starts over -- does not replay
+        # the first one's Gaussian / uniform stream
+        self._epoch = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._x1 = [torch.zeros(self.B, self.D, dtype=torch.float32, device=self.dev) for _ in range(2)]
         self._graph = None
         self._last = {}
@@ -114,6 +118,7 @@ class DecodeSession:
             self.kc[l][:, :Tp + 1].copy_(kv["key"])
             self.vc[l][:, :Tp + 1].copy_(kv["value"])
         self.pos.fill_(Tp + 1)
+        self._epoch += 1
         first = out["output"][:, -1:].float()
         self.frame.copy_(first)
         self._last = {"transformer_latent": out["transformer_latent"].value[:, -1:], "logits": out["logits"][:, -1:],
@@ -167,7 +172,7 @@ class DecodeSession:
         # torch.rand (under graph replay those cost two fill launches for the generator state and one launch each)
         drawn = None
         if noise is None or uniform is None:
-            drawn = HF.decode_noise(self._seed, self.pos, lat_dim)
+            drawn = HF.decode_noise(self._seed, self.pos, lat_dim, self._epoch)
         eps = noise if noise is not None else drawn[0]
         HF.coupling_flow_reverse(eps.reshape(B, lat_dim), wb, self._flow_params, packed=self._flow_packed,
                                  mu_ls=mu_ls, temperature=self.temperature, out=frame2d[:, 1:], **self._flow_kw)

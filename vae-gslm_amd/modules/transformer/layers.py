@@ -126,6 +126,17 @@ class TransformerLayerStack(nn.Module):
         M = B * T
         if rows == "auto":
             rows = HF.pack_rows_bucket(int(lens.sum().item()), self.pack_granule)
+        else:
+            # an explicit row count is the caller's promise that the batch fits it (the trainer's hipGraph path chooses
+            # it from this batch and clears it afterwards).  Outside a capture the promise is cheap to check, and a
+            # broken one would index out of bounds in the gathers (more valid frames than rows) or leave rows no
+            # sequence covers (far fewer): fall back to padded rows instead.
+            rows = int(rows)
+            if not torch.cuda.is_current_stream_capturing():
+                total = int(lens.sum().item())
+                npseudo = -(-min(rows, self.pack_granule or rows) // T)
+                if total > rows or rows - total > npseudo * T:
+                    return None
         rows = int(rows)
         if rows > int(0.94 * M) or (x2.shape[1] * x2.element_size()) % 16:
             return None                    # not enough padding to pay for the two gathers

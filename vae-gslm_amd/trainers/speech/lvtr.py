@@ -260,6 +260,10 @@ class LVTRTrainer(BaseTrainer):
             else:
                 out[k] = TensorMask(value, torch.cat([torch.nn.functional.pad(b[k].mask, (0, T - b[k].mask.shape[1]))
                                                       for b in batches], 0))
+                counts = [b[k].value.shape[0] * b[k].value.shape[1] if getattr(b[k].mask, "_vg_full", False)
+                          else getattr(b[k].mask, "_vg_valid", None) for b in batches]
+                if all(c is not None for c in counts):
+                    out[k].mask._vg_valid = int(sum(counts))
         return out
 
     def training_step(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None):
@@ -295,7 +299,12 @@ class LVTRTrainer(BaseTrainer):
         if self.reducer is not None:
             self.reducer.sync_now = last
         if self.use_graph and noise is None:
-            out = self._graphed_micro_step(batch, batch_idx, last)
+            try:
+                out = self._graphed_micro_step(batch, batch_idx, last)
+            finally:
+                # the row count chosen for this capture / replay must not outlive it: a later direct call of the model
+                # (likelihood(), a user's forward) would pack a different batch into it
+                self._clear_pack_rows()
         else:
             self._choose_pack_rows(batch, eager=True)
             out = self._training_loop(batch, batch_idx, noise)
@@ -354,10 +363,20 @@ class LVTRTrainer(BaseTrainer):
                 else:
                     from hipvg import functional as HF
                     B, T = tm.mask.shape[:2]
-                    cand = HF.pack_rows_bucket(int(tm.mask.sum().item()), self.packed_granule)
+                    # the valid-frame count rides with the mask when the loader knew it on the host
+                    # (training_lib.prefetch: `_vg_valid`); a device -> host read is the fallback
+                    total = getattr(tm.mask, "_vg_valid", None)
+                    if total is None:
+                        total = int(tm.mask.sum().item())
+                    cand = HF.pack_rows_bucket(int(total), self.packed_granule)
                     rows = cand if cand <= int(0.94 * B * T) else None
         stack.pack_rows = rows
         return rows
+
+    def _clear_pack_rows(self) -> None:
+        stack = self.model.transformer[0] if hasattr(self.model, "transformer") else None
+        if stack is not None and hasattr(stack, "pack_rows"):
+            stack.pack_rows = None
 
     # ------------------------------------------------------------ hipGraph replay of a micro-step
     def _pad_for_graph(self, batch: Mapping) -> Mapping:
@@ -378,6 +397,8 @@ class LVTRTrainer(BaseTrainer):
             if pad:
                 val = torch.nn.functional.pad(v.value, (0, 0) * (v.value.dim() - 2) + (0, pad))
                 out[k] = TensorMask(val, torch.nn.functional.pad(v.mask, (0, pad)))
+                if hasattr(v.mask, "_vg_valid"):
+                    out[k].mask._vg_valid = v.mask._vg_valid
         return out
 
     def _graphed_micro_step(self, batch: Mapping, batch_idx: int, last: bool):

@@ -70,6 +70,10 @@ class DevicePrefetcher:
                     full = getattr(v.mask, "_vg_full", False)
                     dev[k] = TensorMask(self._to_device(v.value), None if full else self._to_device(v.mask),
                                         axis=v.axis)
+                    if not full and not v.mask.is_cuda:
+                        # host-side valid-frame count: the trainer picks its packed-row bucket from it without a
+                        # device -> host read (trainers.speech.lvtr._choose_pack_rows)
+                        dev[k].mask._vg_valid = int(v.mask.sum())
                 elif torch.is_tensor(v):
                     dev[k] = self._to_device(v)
                 else:
