@@ -103,8 +103,10 @@ int vg_gemm_tile_rows(const vg_gemm_desc* desc);
  * and combines whole-K segments with plain adds, head / tail pieces with fp32 atomics), no epilogue fields.  Replaces
  * the four dW = dY^T X launches of one Transformer layer's backward (the nn.Linear weight gradients autograd computes
  * for modules/transformer/layers.py:52,79,82,151 of the reference) and the two or three of a conv bottleneck block
- * (modules/conv/layers.py): one persistent grid of 256 blocks with equal (tile, K tile) unit counts. */
-enum { VG_GROUP_MAX = 8 };
+ * (modules/conv/layers.py): one persistent grid of 256 blocks with equal (tile, K tile) unit counts.  Round 4: up to
+ * VG_GROUP_MAX = 48 products per launch (the host side queues the weight gradients of several backward nodes -- four
+ * Transformer layers are 768 tiles = three whole rounds of 256 CUs -- and flushes them together). */
+enum { VG_GROUP_MAX = 48 };
 int vg_gemm_grouped(const vg_gemm_desc* descs, int n, vg_stream_t stream);
 
 /* ---------------------------------------------------------------- RMSNorm

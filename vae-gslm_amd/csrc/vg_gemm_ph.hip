@@ -824,20 +824,32 @@ int launch_duo(const GemmParams& p, int splits, hipStream_t stream) {
 //    blocks of an XCD read the SAME K slice of a few dY / X panels: one HBM fetch serves a whole row / column of
 //    the rectangle out of that XCD's L2 (6 x 4 heads + 2 x 4 tails: 16 panel slices per 32 units instead of 64;
 //    measured 0.81 GB fetched per layer, 339 us).
+//  * round 4: a last round that at least 7/8 of the blocks would take part in is run as a WHOLE round with the other
+//    blocks idle (plan.rounds counts it, nothing is left over): its tiles keep their whole K range and add with plain
+//    16-byte accesses -- 240 tiles split over 256 blocks would mean 30 heads + 2 tails per XCD, a plan the lockstep
+//    rules refuse, i.e. the stream plan with two atomic epilogues per tile.
 struct GroupPlan {
   int lockstep;
   int rounds;                       // whole rounds of one full-K tile per block
   int first[9];                     // XCD x owns leftover tiles [first[x], first[x + 1]) of the tile line
   int epi;                          // what one segment's epilogue costs a block, in K tiles (balances heads and tails)
 };
+// One product of the group as the kernel needs it (48 bytes: VG_GROUP_MAX of them fit the 4 KB kernel-argument block,
+// which a full GemmParams per problem would not)
+struct GroupProb {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+};
 struct GroupParams {
-  GemmParams p[VG_GROUP_MAX];
+  GroupProb q[VG_GROUP_MAX];
   int unit0[VG_GROUP_MAX + 1];      // first work unit (one K tile of one output tile) of problem g; [n] = total
   int tile0[VG_GROUP_MAX + 1];      // first tile of problem g on the tile line
   int nkt[VG_GROUP_MAX];            // K tiles per output tile
   int n;
   GroupPlan plan;
 };
+static_assert(sizeof(GroupParams) <= 4096, "GroupParams must fit the kernel-argument block");
 
 // the next segment of this block: problem g, tile (problem-local), first K tile, K tile count; false when done
 struct GroupWalk {
@@ -876,9 +888,8 @@ struct GroupWalk {
     if (!gp.plan.lockstep) {
       if (u >= uend) return false;
       g = 0;
-#pragma unroll
-      for (int i = 1; i < VG_GROUP_MAX; ++i)
-        if (i < gp.n && u >= gp.unit0[i]) g = i;
+      for (int i = 1; i < gp.n; ++i)
+        if (u >= gp.unit0[i]) g = i;
       const int nkt = gp.nkt[g], local = u - gp.unit0[g];
       tile = local / nkt;
       kt = local - tile * nkt;
@@ -891,6 +902,7 @@ struct GroupWalk {
       kt = 0;
       count = gp.nkt[0];
       ++stage;
+      if (line >= gp.tile0[gp.n]) return false;     // a block that sits out the last (partly filled) round
     } else if (stage == gp.plan.rounds && slot < tx) {
       ++stage;
       if (kh == 0) return false;
@@ -907,9 +919,8 @@ struct GroupWalk {
       u += count;
     }
     g = 0;
-#pragma unroll
-    for (int i = 1; i < VG_GROUP_MAX; ++i)
-      if (i < gp.n && line >= gp.tile0[i]) g = i;
+    for (int i = 1; i < gp.n; ++i)
+      if (line >= gp.tile0[i]) g = i;
     tile = line - gp.tile0[g];
     return true;
   }
@@ -924,7 +935,12 @@ __global__ __launch_bounds__(512) void gemm_ring_group_kernel(GroupParams gp) {
   walk.init(gp);
   int g, tile, kt, count;
   while (walk.next(gp, g, tile, kt, count)) {
-    const GemmParams& p = gp.p[g];
+    const GroupProb& q = gp.q[g];
+    GemmParams p{};
+    p.A = q.A; p.B = q.B; p.C = q.C;
+    p.M = q.M; p.N = q.N; p.K = q.K;
+    p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+    p.k_per_split = q.K;
     TileCtx<A_TR, B_TR> c;
     c.init_range(p, tile, kt * BK, count, gp.plan.lockstep ? 2 : 0, wave, lane);
     f32x4 acc[8][4];
@@ -1008,7 +1024,8 @@ int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_
   bool same_k = true;
   for (int i = 0; i < n; ++i) {
     if (splits[i] != 1) return -1;
-    gp.p[i] = ps[i];
+    if (ps[i].lda > 0x7fffffffL || ps[i].ldb > 0x7fffffffL || ps[i].ldc > 0x7fffffffL) return -1;
+    gp.q[i] = GroupProb{ps[i].A, ps[i].B, ps[i].C, ps[i].M, ps[i].N, ps[i].K, (int)ps[i].lda, (int)ps[i].ldb, (int)ps[i].ldc};
     gp.nkt[i] = ps[i].K / BK;
     gp.unit0[i] = (int)units;
     gp.tile0[i] = (int)tiles;
@@ -1044,9 +1061,13 @@ int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_
   for (int x = 0; x <= 8; ++x) gp.plan.first[x] = 0;
   if (mode != 0 && same_k && blocks == cus && cus % 8 == 0 && n > 0) {
     const int per = cus / 8;
-    const int rounds = (int)(tiles / cus), left = (int)(tiles - (long)rounds * cus);
+    int rounds = (int)(tiles / cus), left = (int)(tiles - (long)rounds * cus);
+    if (left * 8 >= cus * 7) {        // a nearly full last round: whole tiles, the few other blocks sit it out
+      ++rounds;
+      left = 0;
+    }
     bool ok = true;
-    for (int x = 0; x <= 8; ++x) gp.plan.first[x] = rounds * cus + (int)((long)left * x / 8);
+    for (int x = 0; x <= 8; ++x) gp.plan.first[x] = left == 0 ? (int)tiles : rounds * cus + (int)((long)left * x / 8);
     for (int x = 0; x < 8 && ok; ++x) {
       const int tx = gp.plan.first[x + 1] - gp.plan.first[x], ntail = per - tx;
       // a tail block walks tx / ntail tile tails: keep that short (each ends in an atomic epilogue), and every

@@ -171,42 +171,117 @@ def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -
     return max(1, min(s, k_red // 256))
 
 
-def sink_wgrad_group(items, fire: bool = True) -> None:
+GROUP_MAX = 48        # VG_GROUP_MAX of include/vaegslm_hip.h: products per vg_gemm_grouped launch
+
+
+def _wgrad_grad_view(w, x, col0):
+    N = w.shape[0]
+    return _grad_buffer(w).view(N, -1)[:, col0:col0 + x.shape[1]]
+
+
+def _wgrad_item_ok(w, dy, x, col0) -> bool:
+    """Can ``w.grad[:, col0:col0 + K] += dy^T x`` be one product of a vg_gemm_grouped launch?"""
+    N, K, M = w.shape[0], x.shape[1], x.shape[0]
+    return (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and M % 64 == 0 and M >= 1024
+            and N % 8 == 0 and K % 8 == 0 and col0 % 4 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and w.is_contiguous()
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dy.shape[0] == M and dy.shape[1] == N)
+
+
+def _wgrad_tiles(w, x) -> int:
+    return ((w.shape[0] + 255) // 256) * ((x.shape[1] + 255) // 256)
+
+
+def _launch_wgrad_items(items) -> None:
+    """One vg_gemm_grouped launch for ``items`` (all qualified, same reduction length, at most GROUP_MAX), or one
+    split-K launch each when they are too few tiles to be worth a persistent grid."""
+    total = sum(_wgrad_tiles(w, x) for w, _, x, _ in items)
+    if not _PH_GROUP or total < _GROUP_MIN_TILES:
+        for w, dy, x, col0 in items:
+            N, K, M = w.shape[0], x.shape[1], x.shape[0]
+            sp = wgrad_splits(N, K, M, x.dtype)
+            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=_wgrad_grad_view(w, x, col0), split_k=sp, accumulate=(sp == 1))
+        return
+    descs = (GemmDesc * len(items))()
+    for d, (w, dy, x, col0) in zip(descs, items):
+        g = _wgrad_grad_view(w, x, col0)
+        d.A, d.B, d.C = ptr(dy), ptr(x), ptr(g)
+        d.M, d.N, d.K = w.shape[0], x.shape[1], x.shape[0]
+        d.lda, d.ldb, d.ldc = dy.stride(0), x.stride(0), g.stride(0)
+        d.a_tr, d.b_tr, d.dtype = 1, 1, dtype_id(torch.bfloat16)
+        d.out_f32, d.accumulate, d.split_k, d.alpha = 1, 1, 1, 1.0
+    check(lib().vg_gemm_grouped(descs, len(items), stream()), "vg_gemm_grouped")
+
+
+# Deferred weight gradients (round 4).  Nothing reads a weight gradient before the optimizer (or the bucket exchange),
+# so between defer_vec_grads(True) and the flush at the end of the backward piece the qualified dW += dY^T X products
+# are queued -- their operands kept alive -- and leave as FEW, LARGE grouped launches: the four products of a Transformer
+# layer are 192 tiles of 256x256 (three quarters of a round of 256 CUs: a head / tail split with fp32 atomics), those
+# of four layers are 768 = three whole rounds of full-K tiles that add with plain 16-byte accesses; the conv blocks'
+# two or three products each (32-40 tiles, eight-way split with 67 MB of atomics per launch) and the ~20 small split-12
+# launches of the heads become one launch of ~240 whole tiles.  A queue (one per tag, so that the layer stack keeps
+# its own rhythm) is flushed when it holds a whole number of rounds (>= 2), when a weight comes back a second time
+# (two products adding into one gradient inside one launch would race), and at the end of the piece.
+_WDEFER = {"on": False, "q": {}, "keys": {}, "fire": []}
+
+
+def _wgrad_enqueue(items, fire: bool, tag: str) -> None:
+    q = _WDEFER["q"].setdefault(tag, [])
+    keys = _WDEFER["keys"].setdefault(tag, set())
+    new_keys = [(_wgrad_grad_view(w, x, col0).data_ptr(), w.shape[0], x.shape[1]) for w, _, x, col0 in items]
+    if any(k in keys for k in new_keys):
+        flush_wgrads(tag)
+        q = _WDEFER["q"].setdefault(tag, [])
+        keys = _WDEFER["keys"].setdefault(tag, set())
+    q.extend(items)
+    keys.update(new_keys)
+    if fire:
+        _WDEFER["fire"].extend(w for w, _, _, _ in items)
+    tiles = sum(_wgrad_tiles(w, x) for w, _, x, _ in q)
+    if tiles >= 512 and tiles % 256 == 0:
+        flush_wgrads(tag)
+
+
+def flush_wgrads(tag: Optional[str] = None) -> None:
+    tags = [tag] if tag is not None else list(_WDEFER["q"].keys())
+    for t in tags:
+        q = _WDEFER["q"].pop(t, [])
+        _WDEFER["keys"].pop(t, None)
+        by_m = {}
+        for it in q:                              # one launch shares its reduction length (lockstep plan)
+            by_m.setdefault(it[2].shape[0], []).append(it)
+        for same in by_m.values():
+            for i in range(0, len(same), GROUP_MAX):
+                _launch_wgrad_items(same[i:i + GROUP_MAX])
+    if not _WDEFER["q"]:
+        fire, _WDEFER["fire"] = _WDEFER["fire"], []
+        seen = set()
+        for w in fire:
+            if id(w) not in seen:
+                seen.add(id(w))
+                _fire(w)
+
+
+def sink_wgrad_group(items, fire: bool = True, tag: str = "misc") -> None:
     """``items``: (weight, dy[M, N], x[M, K]) or (weight, dy, x, col0) of one backward node.  The weight gradients
     ``weight.grad[N, col0:col0 + K] += dy^T x`` of all of them in ONE launch (``vg_gemm_grouped``: persistent grid of
     256x256 tiles with equal K ranges per CU) when every product qualifies and together they are at least
     ``VG_GROUP_MIN_TILES`` tiles; one split-K launch each otherwise.  ``col0`` addresses a column slice of a weight
-    whose input is a concatenation (the conv block's [u | cond] Linear)."""
+    whose input is a concatenation (the conv block's [u | cond] Linear).  Inside a deferral bracket
+    (``defer_vec_grads``) qualified products are queued instead and leave with the products of other nodes."""
     items = [it if len(it) == 4 else (*it, 0) for it in items if it is not None]
     if not items:
         return
-
-    def grad_view(w, x, col0):
-        N = w.shape[0]
-        return _grad_buffer(w).view(N, -1)[:, col0:col0 + x.shape[1]]
-    ok = _PH_GROUP and len(items) <= 8
-    total = 0
-    for w, dy, x, col0 in items:
-        N, K, M = w.shape[0], x.shape[1], x.shape[0]
-        ok = ok and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and M % 64 == 0 and M >= 1024
-        ok = ok and N % 8 == 0 and K % 8 == 0 and col0 % 4 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and w.is_contiguous()
-        ok = ok and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
-        total += ((N + 255) // 256) * ((K + 255) // 256)
-    if not ok or total < _GROUP_MIN_TILES:
+    ok = _PH_GROUP and len(items) <= GROUP_MAX and all(_wgrad_item_ok(*it) for it in items)
+    if ok and _WDEFER["on"]:
+        _wgrad_enqueue(items, fire, tag)
+        return
+    if ok and len({it[2].shape[0] for it in items}) == 1:
+        _launch_wgrad_items(items)
+    else:
         for w, dy, x, col0 in items:
             N, K, M = w.shape[0], x.shape[1], x.shape[0]
-            s = wgrad_splits(N, K, M, x.dtype)
-            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=grad_view(w, x, col0), split_k=s, accumulate=(s == 1))
-    else:
-        descs = (GemmDesc * len(items))()
-        for d, (w, dy, x, col0) in zip(descs, items):
-            g = grad_view(w, x, col0)
-            d.A, d.B, d.C = ptr(dy), ptr(x), ptr(g)
-            d.M, d.N, d.K = w.shape[0], x.shape[1], x.shape[0]
-            d.lda, d.ldb, d.ldc = dy.stride(0), x.stride(0), g.stride(0)
-            d.a_tr, d.b_tr, d.dtype = 1, 1, dtype_id(torch.bfloat16)
-            d.out_f32, d.accumulate, d.split_k, d.alpha = 1, 1, 1, 1.0
-        check(lib().vg_gemm_grouped(descs, len(items), stream()), "vg_gemm_grouped")
+            sp = wgrad_splits(N, K, M, x.dtype)
+            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=_wgrad_grad_view(w, x, col0), split_k=sp, accumulate=(sp == 1))
     if fire:
         seen = set()
         for w, _, _, _ in items:
@@ -234,9 +309,12 @@ _DEFER = {"on": False, "tasks": [], "keep": [], "fire": []}
 
 
 def defer_vec_grads(on: bool) -> None:
+    """Bracket of a backward piece nothing reads gradients inside of: the finishing launches of the small column sums
+    and (round 4) the qualified weight-gradient products wait for its end."""
     if not on:
         flush_vec_grads()
     _DEFER["on"] = bool(on) and _COLSUM_MULTI and _flag("VG_DEFER_COLSUM", "1")
+    _WDEFER["on"] = bool(on) and _PH_GROUP and _flag("VG_DEFER_WGRAD", "1")
 
 
 def reset_vec_grads() -> None:
@@ -244,10 +322,13 @@ def reset_vec_grads() -> None:
     addresses belong to tensors of that attempt)."""
     _DEFER["on"] = False
     _DEFER["tasks"], _DEFER["keep"], _DEFER["fire"] = [], [], []
+    _WDEFER["on"] = False
+    _WDEFER["q"], _WDEFER["keys"], _WDEFER["fire"] = {}, {}, []
 
 
 def flush_vec_grads() -> None:
     import hipvg
+    flush_wgrads()
     # the queue is emptied BEFORE the launches: if one of them raises, nothing stale (task pointers into tensors of
     # this attempt) is left for the next flush to relaunch; `keep` holds the tensors alive until the launches are queued
     tasks, fire, keep = _DEFER["tasks"], _DEFER["fire"], _DEFER["keep"]
@@ -901,6 +982,10 @@ def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor, bias: Optional[Tensor] = None, 
     N = p.shape[0]
     K = p.numel() // N
     M = x.shape[0]
+    if (bias is None and _WDEFER["on"] and x.dim() == 2 and x.shape[1] == K and p.is_contiguous()
+            and _wgrad_item_ok(p, dy, x, 0)):
+        _wgrad_enqueue([(p, dy, x, 0)], fire, "misc")      # leaves with the other products of this backward piece
+        return
     g = _grad_buffer(p).view(N, K)
     s = wgrad_splits(N, K, M, x.dtype)
     bg = None if bias is None else _grad_buffer(bias).view(-1)
@@ -1145,7 +1230,7 @@ class TransformerLayerFn(torch.autograd.Function):
         if bqkv is not None and id(bqkv) in folded:
             g_bq = folded[id(bqkv)]
         if group is not None:
-            sink_wgrad_group(group)
+            sink_wgrad_group(group, tag="layer")
         ws.join()                                # before qkv / att / du ... can be released
         return (dx, g_n1, g_wq, g_bq, g_wo, g_bo, g_n3, g_w1, g_b1, g_w2, g_b2,
                 None, None, None, None, None, None, None)
