@@ -42,6 +42,7 @@ _COLPART = _flag("VG_COLPART", "1")             # dgrad launches also reduce the
 _SPLIT_SLABS = _flag("VG_SPLIT_SLABS", "0")
 _PH_WGRAD = _flag("VG_PH_WGRAD", "1")           # weight gradients on 256x256 ring tiles (split sized for one block per CU)
 _GROUP_MIN_TILES = int(os.environ.get("VG_GROUP_MIN_TILES", "24"))   # fewer 256x256 tiles than this: one launch per product
+_TRACE_TN = _flag("VG_TRACE_TN", "0")
 _PH_GROUP = _flag("VG_PH_GROUP", "1")           # a layer's four weight gradients as one grouped launch
 _GRAD_SINK = _flag("VG_GRAD_SINK", "1")         # wgrad / column sums write straight into param.grad
 # sunk weight gradients of a layer on a second stream (parallel graph branch): measured slower, 55.4 vs 53.2 ms
@@ -108,6 +109,11 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
          colsum_out: Optional[Tensor] = None, colpart: Optional[list] = None) -> Tensor:
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
+    if _TRACE_TN and a_tr and b_tr:      # who still launches a weight gradient of its own (VG_TRACE_TN=1, eager runs)
+        import sys
+        import traceback
+        fr = [f"{f.name}:{f.lineno}" for f in traceback.extract_stack(limit=7)[:-1]]
+        print(f"[vg_tn] M={M} N={N} K={K} split={split_k} dtype={A.dtype} <- {' < '.join(reversed(fr))}", file=sys.stderr)
     if A.data_ptr() % 16:      # e.g. a channel slice of a single frame: the kernels need 16-byte aligned operands
         A = A.clone()
     if B.data_ptr() % 16:
@@ -195,6 +201,10 @@ def _launch_wgrad_items(items) -> None:
     """One vg_gemm_grouped launch for ``items`` (all qualified, same reduction length, at most GROUP_MAX), or one
     split-K launch each when they are too few tiles to be worth a persistent grid."""
     total = sum(_wgrad_tiles(w, x) for w, _, x, _ in items)
+    if _TRACE_TN:
+        import sys
+        print(f"[vg_tn] group of {len(items)} products, {total} tiles, K={items[0][2].shape[0]}: "
+              + " ".join(f"{w.shape[0]}x{x.shape[1]}" for w, _, x, _ in items), file=sys.stderr)
     if not _PH_GROUP or total < _GROUP_MIN_TILES:
         for w, dy, x, col0 in items:
             N, K, M = w.shape[0], x.shape[1], x.shape[0]
@@ -234,8 +244,12 @@ def _wgrad_enqueue(items, fire: bool, tag: str) -> None:
         keys = _WDEFER["keys"].setdefault(tag, set())
     q.extend(items)
     keys.update(new_keys)
-    if fire:
-        _WDEFER["fire"].extend(w for w, _, _, _ in items)
+    if fire:                                      # one "gradient ready" report per weight and node, as without the queue
+        seen = set()
+        for w, _, _, _ in items:
+            if id(w) not in seen:
+                seen.add(id(w))
+                _WDEFER["fire"].append(w)
     tiles = sum(_wgrad_tiles(w, x) for w, _, x, _ in q)
     if tiles >= 512 and tiles % 256 == 0:
         flush_wgrads(tag)
@@ -254,11 +268,8 @@ def flush_wgrads(tag: Optional[str] = None) -> None:
                 _launch_wgrad_items(same[i:i + GROUP_MAX])
     if not _WDEFER["q"]:
         fire, _WDEFER["fire"] = _WDEFER["fire"], []
-        seen = set()
         for w in fire:
-            if id(w) not in seen:
-                seen.add(id(w))
-                _fire(w)
+            _fire(w)
 
 
 def sink_wgrad_group(items, fire: bool = True, tag: str = "misc") -> None:
@@ -327,8 +338,13 @@ def reset_vec_grads() -> None:
 
 
 def flush_vec_grads() -> None:
-    import hipvg
+    """End of a deferral bracket: the queued weight gradients, then the queued column-sum tasks."""
     flush_wgrads()
+    _flush_vec_tasks()
+
+
+def _flush_vec_tasks() -> None:
+    import hipvg
     # the queue is emptied BEFORE the launches: if one of them raises, nothing stale (task pointers into tensors of
     # this attempt) is left for the next flush to relaunch; `keep` holds the tensors alive until the launches are queued
     tasks, fire, keep = _DEFER["tasks"], _DEFER["fire"], _DEFER["keep"]
@@ -354,7 +370,7 @@ def _defer_task(p: Tensor, src: Tensor) -> None:
     _DEFER["keep"].append((src, dst))
     _DEFER["fire"].append(p)
     if len(_DEFER["tasks"]) >= 4 * hipvg.COLSUM_MAX_TASKS:
-        flush_vec_grads()
+        _flush_vec_tasks()
 
 
 def vec_grad(p, src2d: Tensor):
@@ -535,6 +551,100 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act=None
            out_f32: bool = False) -> Tensor:
     return LinearFn.apply(x, weight, bias, residual, lengths, T, ACT_IDS[act] if not isinstance(act, int) else act,
                           out_f32)
+
+
+class SliceLinearFn(torch.autograd.Function):
+    """y = x W[:, col0:col0 + K]^T (+ b) (+ residual) for a column slice of a PARAMETER (a k = 1 Conv1d whose input is
+    a concatenation computed piece by piece: the UNet's skip convolutions, modules/conv/layers.py of the reference).
+    The weight-gradient slice goes straight into ``W.grad[:, col0:col0 + K]`` (deferred with the other products of the
+    backward piece); passing the slice itself to ``linear`` would hand autograd a dense dW per piece plus the
+    zero-fill / copy / add launches that assemble them."""
+
+    @staticmethod
+    def forward(ctx, x, wparam, col0, bias, residual):
+        M, K = x.shape
+        N = wparam.shape[0]
+        ws = shadow(wparam, x.dtype).view(N, -1)[:, col0:col0 + K]
+        b = None if bias is None else bias.detach().float()
+        y = gemm(x, ws, M, N, K, bias=b, residual=residual)
+        ctx.save_for_backward(x, ws)
+        ctx.params = (wparam, bias)
+        ctx.meta = (col0, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ws = ctx.saved_tensors
+        wparam, bias = ctx.params
+        col0, has_res = ctx.meta
+        M, K = x.shape
+        N = wparam.shape[0]
+        dy = _as(dy, x.dtype)
+        dx = gemm(dy, ws, M, K, N, b_tr=True) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            if _sinkable(wparam) and wparam.is_contiguous():
+                sink_wgrad_group([(wparam, dy, x, col0)])
+            else:
+                dW = torch.zeros((N, wparam.numel() // N), dtype=torch.float32, device=x.device)
+                gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=dW[:, col0:col0 + K], split_k=1, accumulate=True)
+                dW = dW.view_as(wparam)
+        db = vec_grad(bias, dy) if (bias is not None and ctx.needs_input_grad[3]) else None
+        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        return dx, dW, None, db, dres
+
+
+def slice_linear(x: Tensor, wparam: Tensor, col0: int, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None):
+    return SliceLinearFn.apply(x, wparam, int(col0), bias, residual)
+
+
+class StackedLinearFn(torch.autograd.Function):
+    """y = x [W_0; W_1; ...]^T + [b_0; b_1; ...]: several Linears of one input as ONE product (the coupling stack's four
+    FiLM projections, modules/flow/layers.py:15-40 of the reference, computed from the same conditioning rows).
+    ``torch.cat`` of the parameters in front of ``linear`` would hand autograd a dense gradient of the concatenation
+    (one split-K launch) plus the slice / accumulate launches that take it apart; here each W_i's gradient is a
+    column block of dY and goes into ``W_i.grad`` with the other weight gradients of the backward piece."""
+
+    @staticmethod
+    def forward(ctx, x, out_f32, n, *params):
+        weights, biases = params[:n], params[n:]
+        M, K = x.shape
+        ws = torch.cat([shadow(w, x.dtype).view(w.shape[0], -1) for w in weights], 0)
+        N = ws.shape[0]
+        b = torch.cat([bb.detach().float() for bb in biases], 0) if biases else None
+        y = gemm(x, ws, M, N, K, bias=b, out_f32=bool(out_f32))
+        ctx.save_for_backward(x, ws)
+        ctx.params = (weights, biases)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ws = ctx.saved_tensors
+        weights, biases = ctx.params
+        n = len(weights)
+        M, K = x.shape
+        N = ws.shape[0]
+        dy = _as(dy, x.dtype)
+        dx = gemm(dy, ws, M, K, N, b_tr=True) if ctx.needs_input_grad[0] else None
+        offs = [0]
+        for w in weights:
+            offs.append(offs[-1] + w.shape[0])
+        gw = [None] * n
+        if all(_sinkable(w) and w.is_contiguous() for w in weights):
+            sink_wgrad_group([(w, dy[:, offs[i]:offs[i + 1]], x, 0) for i, w in enumerate(weights)])
+        else:
+            dW = gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out_f32=True, split_k=wgrad_splits(N, K, M, x.dtype))
+            gw = [dW[offs[i]:offs[i + 1]].view_as(w) for i, w in enumerate(weights)]
+        gb = []
+        if biases:
+            db = colsum(dy)
+            gb = [db[offs[i]:offs[i + 1]] for i in range(n)]
+        return (dx, None, None, *gw, *gb)
+
+
+def stacked_linear(x: Tensor, weights, biases=None, out_f32: bool = False) -> Tensor:
+    biases = list(biases) if biases is not None and all(b is not None for b in biases) else []
+    return StackedLinearFn.apply(x, bool(out_f32), len(weights), *weights, *biases)
 
 
 # ---------------------------------------------------------------- fused FFN

@@ -194,8 +194,9 @@ class BottleNeckResNet(nn.Module):
                 if self.skip_concat:
                     W = self.skip_conv[i].weight
                     Cw = h.shape[1]
-                    part = HF.linear(h, W[:, :Cw, 0], self.skip_conv[i].bias)
-                    h = HF.linear(history[src], W[:, Cw:, 0], None, residual=part)
+                    # the k = 1 convolution over cat([h, history[src]]) as two products on column slices of its weight
+                    part = HF.slice_linear(h, W, 0, self.skip_conv[i].bias)
+                    h = HF.slice_linear(history[src], W, Cw, None, residual=part)
                 else:
                     h = h + history[src]
             history.append(h)

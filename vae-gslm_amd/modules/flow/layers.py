@@ -113,9 +113,13 @@ class CouplingStack(nn.Module):
 
     def _hip_args(self, c):
         cv = c.value if isinstance(c, TensorMask) else c
-        W = torch.cat([l.film.linear.weight for l in self.layers], 0)
-        Bv = torch.cat([l.film.linear.bias for l in self.layers], 0)
-        wb = dense_2d(cv, W, Bv, out_f32=True).reshape(-1, 128 * len(self.layers))
+        from hipvg import functional as HF
+        import hipvg
+        # the layers' FiLM projections as one product, each weight's gradient sunk on its own (HF.stacked_linear)
+        x2 = cv.reshape(-1, cv.shape[-1]).to(hipvg.compute_dtype()).contiguous()
+        wb = HF.stacked_linear(x2, [l.film.linear.weight for l in self.layers],
+                               [l.film.linear.bias for l in self.layers], out_f32=True)
+        wb = wb.reshape(-1, 128 * len(self.layers))
         params = []
         for l in self.layers:
             params += [l.linear1.weight, l.linear1.bias, l.norm.weight, l.norm.bias, l.linear2.weight, l.linear2.bias]

@@ -221,9 +221,12 @@ class LVTRTrainer(BaseTrainer):
         except BaseException:
             HF.reset_vec_grads()
             raise
-        HF.defer_vec_grads(False)
         if backward_tail:
+            # the pieces below the model's own cuts (the posterior encoder sits below the reparameterised sample) belong
+            # to the same bracket: their weight gradients leave with this pass's instead of as a small launch of their own
             self._backward_tail()
+        else:
+            HF.defer_vec_grads(False)
         if fold is not None:
             pairs = [(v, p.grad) for p, v in fold if p.grad is not None]
             if pairs:
