@@ -724,7 +724,7 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           const float* __restrict__ lse,
-                                                          const float* __restrict__ delta,
+                                                          float* __restrict__ delta, const T* __restrict__ out_o,
                                                           const float* __restrict__ slopes, T* __restrict__ dqkv,
                                                           int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched,
                                                           const int* __restrict__ cu, int Mtot) {
@@ -750,6 +750,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   if (q0 >= len) {
     f32x16 z[2] = {zero16(), zero16()};
     if (query < Tr) store_rows_T<T>(dqbase + (long)query * rs, z, 0.f, lane);
+    if (query < Tr && lane < 32) delta[(long)h * Mtot + soff + query] = 0.f;     // the dK/dV pass reads every row's delta
     return;
   }
   const int qend = min(q0 + QB, len);
@@ -763,7 +764,27 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   // +inf for padded queries -> p = exp2(-inf) = 0 without a compare
   const float Lq = qvalid ? lse[(long)h * Mtot + soff + query] * LOG2E + slope2 * (float)(query - qw0) : INFINITY;
-  const float dl = qvalid ? delta[(long)h * Mtot + soff + query] : 0.f;
+  // delta = rowsum(dO * O) of this wave's 32 queries, from the dO row fragments it holds anyway and the matching O row
+  // fragments (round 4: the stand-alone delta kernel -- a 15 us launch per layer that re-read O and dO -- is gone);
+  // written out for the dK/dV pass, which runs after this launch.  Lanes l and l + 32 hold the two halves of a row.
+  float dl;
+  {
+    RowRegs<T> of;
+    of.load(out_o + ((long)soff + qc) * D + h * DH, lane);
+    float part = 0.f;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)dof.f[s][e] * (float)of.f[s][e];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 32; ++s) part += dof.f[s] * of.f[s];
+    }
+    const float whole = xhalf_sum(part);       // cross-lane: every lane takes part
+    dl = qvalid ? whole : 0.f;
+    if (query < Tr && lane < 32) delta[(long)h * Mtot + soff + query] = dl;
+  }
   f32x16 kinit, dinit;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -1115,14 +1136,13 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   // algorithmic work of the backward: 2 x forward (training = 3 x forward, no credit for the scores the
   // backward recomputes; the kernels execute 5 products -- S, dP, dV, dK, dQ -- i.e. 2.5 x)
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_BWD, 512.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
-  hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
-                     (const T*)out, (const T*)dout, delta, Mtot, H);
+  (void)nthreads;      // (the stand-alone attn_delta_kernel is no longer launched: the dQ pass computes and stores delta)
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   const int sched = attn_env("VG_ATTN_SCHED", 0);
   const size_t lds_q = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   const float skip = sizeof(T) == 2 ? attn_skip_thr() : INFINITY;     // the fp32 parity path keeps every tile
   hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
-                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot);
+                     delta, (const T*)out, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot);
   const size_t lds_k = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float));
   static bool attr[2] = {false, false};
   if (!attr[sizeof(T) == 2]) {
