@@ -34,10 +34,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     const int gi = group_of_chunk[c] & 3;
     const float lr = G.lr[gi], decay = 1.0f - lr * G.wd[gi], step = lr * inv_bc1;
     const long i = c * 256 + lane * 4;
-    f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
-    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
-    f32x4 mv = *reinterpret_cast<const f32x4*>(m + i);
-    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i);
+    // the seven fp32 streams are touched once per step: non-temporal loads / stores (338 -> 321 us per 57 M-parameter
+    // bucket in the step, round 4; the same switch on the row kernels -- RMSNorm, channel norms -- measured 0.4 % slower
+    // end to end and was not kept).  The bf16 copy, which the next step's GEMMs read, keeps the default policy.
+#ifndef VG_ADAM_TEMPORAL
+#define VG_AD_LD(ptr) __builtin_nontemporal_load(ptr)
+#define VG_AD_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define VG_AD_LD(ptr) (*(ptr))
+#define VG_AD_ST(ptr, val) (*(ptr) = (val))
+#endif
+    f32x4 pv = VG_AD_LD(reinterpret_cast<const f32x4*>(p + i));
+    f32x4 gv = VG_AD_LD(reinterpret_cast<const f32x4*>(g + i));
+    f32x4 mv = VG_AD_LD(reinterpret_cast<const f32x4*>(m + i));
+    f32x4 vv = VG_AD_LD(reinterpret_cast<const f32x4*>(v + i));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = gv[e] * gs;
@@ -46,14 +56,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       const float denom = fmaf(sqrtf(vv[e]), inv_sqrt_bc2, eps);
       pv[e] = fmaf(-step, mv[e] / denom, pv[e] * decay);
     }
-    *reinterpret_cast<f32x4*>(p + i) = pv;
-    *reinterpret_cast<f32x4*>(m + i) = mv;
-    *reinterpret_cast<f32x4*>(v + i) = vv;
+    VG_AD_ST(reinterpret_cast<f32x4*>(p + i), pv);
+    VG_AD_ST(reinterpret_cast<f32x4*>(m + i), mv);
+    VG_AD_ST(reinterpret_cast<f32x4*>(v + i), vv);
     if (shadow) {
       bf16x4 sv = {(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
       *reinterpret_cast<bf16x4*>(shadow + i) = sv;
     }
-    if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (zero_grad) VG_AD_ST(reinterpret_cast<f32x4*>(g + i), (f32x4{0.f, 0.f, 0.f, 0.f}));
   }
 }
 
