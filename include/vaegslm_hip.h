@@ -215,6 +215,20 @@ typedef struct vg_colsum_task {
   int accumulate;
 } vg_colsum_task;
 int vg_colsum_multi(const vg_colsum_task* tasks, int n, vg_stream_t stream);
+/* Masked means of up to VG_MEAN_MAX_TASKS small fp32 row tensors in one launch: out[k] = sum over valid frames and
+ * columns of x_k (or |x_k|) / (cols_k * valid frames) -- TensorMask.mean() (utils/tensormask.py:135-140) of the step's
+ * monitors (models/speech/lvtr.py:210-224, trainers/speech/lvtr.py:131-145).  lengths may be NULL (every frame valid).
+ * Two small launches (per-block sums, then one wave folds them): deterministic, no atomics. */
+enum { VG_MEAN_MAX_TASKS = 8 };
+typedef struct vg_mean_task {
+  const float* src;       /* [M][ld] fp32 */
+  int64_t ld;
+  int32_t cols;           /* <= 64 */
+  int32_t absolute;       /* 1: mean of |x| */
+} vg_mean_task;
+int vg_masked_means_blocks(int M);     /* partial: fp32 [vg_masked_means_blocks(M)][VG_MEAN_MAX_TASKS + 1] scratch */
+int vg_masked_means(const vg_mean_task* tasks, int n, int M, const int32_t* lengths, int T, float* partial, float* out,
+                    vg_stream_t stream);
 /* first stage of up to VG_COLSUM_MAX_TASKS LARGE column sums in one launch (the bias gradients of one Transformer
  * layer: column sums of the incoming gradient, of the attention-output gradient and of dQKV): src is [rows][ld] of
  * `dtype` (passed through the float* field), dst receives nb rows of cols fp32 partial sums (nb as vg_colsum_blocks),

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, cfg, use_graph, out, overlap=True):
+def _worker(rank, world, port, cfg, use_graph, out, overlap=True, comm="torch"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
@@ -31,7 +31,7 @@ def _worker(rank, world, port, cfg, use_graph, out, overlap=True):
     from training_lib.synthetic import make_batch
     cfg = copy.deepcopy(cfg)
     cfg.setdefault("hip", {})
-    cfg["hip"].update(precision="bf16", graph=use_graph, bucket_mb=4, graph_bucket_mb=4, overlap=overlap)
+    cfg["hip"].update(precision="bf16", graph=use_graph, bucket_mb=4, graph_bucket_mb=4, overlap=overlap, comm=comm)
     torch.manual_seed(11)                      # same initial weights on every rank
     tr = LVTRTrainer(Hparams.from_dict(cfg)).to(dev)
     for p in tr.model.parameters():
@@ -87,6 +87,38 @@ def test_two_rank_segmented_replay_matches_one_graph(full_cfg, monkeypatch):
         assert out[0] == (True, True, True, True) and out["segmented"] == (seg == "2")
         finals[seg] = out["params"]
     torch.testing.assert_close(finals["2"], finals["1"], rtol=0.0, atol=4e-3)
+
+
+def test_two_rank_abi_exchange_matches_the_torch_exchange(full_cfg, monkeypatch, tmp_path):
+    """hip.comm=abi with two ranks END TO END: the segmented hipGraph step -- bucket exchanges
+    between the replayed graphs, pipelined per-bucket AdamW -- with every gradient bucket going through
+    vg_allreduce_bucket -> ncclAllReduce of a test double that really reduces across the two processes
+    (tests/stubs/fake_rccl.c with FAKE_RCCL_DIR; real RCCL cannot put two ranks on one device), against the same run with
+    the exchange on torch.distributed (gloo).  Both average two fp32 buffers, so the parameters after three optimizer
+    steps must agree to rounding of the bf16 forward passes that follow (the first step's gradients are bitwise equal)."""
+    import subprocess
+    from oracle.lvtr_oracle import small_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", fake, os.path.join(root, "tests", "stubs", "fake_rccl.c"), "-ldl"],
+                   check=True)
+    cfg = copy.deepcopy(full_cfg)
+    cfg["model"] = small_config(full_cfg["model"])
+    finals = {}
+    for comm in ("torch", "abi"):
+        if comm == "abi":
+            ex = tmp_path / "exchange"
+            ex.mkdir()
+            monkeypatch.setenv("VG_RCCL_LIB", fake)
+            monkeypatch.setenv("FAKE_RCCL_DIR", str(ex))
+        mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), cfg, True, out, True, comm), nprocs=2, join=True)
+        assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True) and out["segmented"]
+        finals[comm] = out["params"]
+        if comm == "abi":
+            assert any(f.name.endswith(".done") for f in ex.iterdir()), "the exchange never went through the test double"
+    torch.testing.assert_close(finals["abi"], finals["torch"], rtol=0.0, atol=4e-3)
 
 
 def test_bench_two_ranks_full_model_one_device():

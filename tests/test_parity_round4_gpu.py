@@ -141,3 +141,98 @@ def test_mixed_reduction_lengths_leave_in_separate_launches(F, monkeypatch):
     for weights, refs in ((wa, ra), (wb, rb)):
         for key, w in weights.items():
             assert torch.equal(w.grad.double(), refs[key]), key
+
+
+def test_masked_means_match_tensormask_mean(F):
+    """vg_masked_means == TensorMask(x, mask).mean() / .abs().mean() (utils/tensormask.py:135-140 of the reference) for
+    strided column slices, ragged lengths, an empty sequence and the no-mask case."""
+    from utils.tensormask import TensorMask
+    g = torch.Generator().manual_seed(5)
+    B, T = 5, 333
+    lengths = torch.tensor([333, 200, 0, 1, 77])
+    mask = (torch.arange(T)[None] < lengths[:, None]).to(dev())
+    both = torch.randn(B, T, 8, generator=g).to(dev())
+    four = torch.randn(B, T, 4, generator=g).to(dev())
+    lens32 = lengths.to(dev()).int()
+    items = [(both.view(B * T, 8)[:, 4:], False), (both.view(B * T, 8)[:, :4], False), (four.view(B * T, 4), False),
+             (four.view(B * T, 4), True)]
+    got = F.masked_means(items, lens32, T)
+    want = [TensorMask(both[..., 4:], mask).mean(), TensorMask(both[..., :4], mask).mean(), TensorMask(four, mask).mean(),
+            TensorMask(four, mask).abs().mean()]
+    for a, b in zip(got, want):
+        assert abs(float(a) - float(b)) <= 1e-6 + 1e-5 * abs(float(b)), (float(a), float(b))
+    got = F.masked_means(items[2:], None, T)
+    want = [TensorMask(four).mean(), TensorMask(four).abs().mean()]
+    for a, b in zip(got, want):
+        assert abs(float(a) - float(b)) <= 1e-6 + 1e-5 * abs(float(b)), (float(a), float(b))
+
+
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_full_config_decode_session_fp32_matches_oracle(full_cfg, fused, monkeypatch):
+    """BASELINE config 4 at the size the decode bench runs it (VERDICT r03 "What's weak" 1): the FULL model (L = 16,
+    d = 1024, H = 16), a 150-frame prompt through ``DecodeSession.prefill`` and 24 teacher-forced single-frame steps on
+    the pre-allocated KV cache, both decode paths (five launches per layer / the fused attention sub-layer), fp32,
+    against ``oracle.lvtr_oracle`` run with its own KV cache on the CPU (reference: models/speech/lvtr.py:227-286,
+    modules/attention/attention.py:56-73).  Tolerances of ``test_decode_session_fp32_matches_reference``."""
+    import copy
+
+    import numpy as np
+
+    import hipvg
+    from hparams.hp import Hparams
+    from inference.speech.session import DecodeSession
+    from models.speech.lvtr import LVTR
+    from oracle import lvtr_oracle as O
+    from oracle.weights import fill_like
+    monkeypatch.setenv("VG_DECODE_FUSED", fused)
+    cfg = full_cfg["model"]
+    rng = np.random.default_rng(404)
+    B, Tp, n = 4, 150, 24
+    x = torch.cat([torch.from_numpy(rng.integers(0, 200, (B, Tp + n, 1))).float(),
+                   torch.from_numpy(rng.standard_normal((B, Tp + n, 4)).astype(np.float32))], -1)
+    init = torch.from_numpy(rng.random((B, 1, 64)).astype(np.float32)) * 2 - 1
+    filled = fill_like(O.param_shapes(cfg), 20250620)
+    sd = {k: torch.from_numpy(v) for k, v in filled.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 32))
+    # ---- oracle: prefill (init state pushed in front) + single-frame steps with the KV cache
+    tr = cfg["transformer"]
+    past, want = None, dict(lat=[], mean=[], logstd=[], logits=[])
+    with torch.no_grad():
+        for i in range(n + 1):
+            xi = x[:, :Tp] if i == 0 else x[:, Tp + i - 1: Tp + i]
+            tok = sd["token_embedding.weight"][xi[..., 0].long()]
+            fused_in = tok + torch.relu(O.dense(sd, "token_fuser.linear", xi[..., 1:]))
+            if i == 0:
+                fused_in = torch.cat([init, fused_in], 1)
+            m = torch.ones(B, fused_in.shape[1], dtype=torch.bool)
+            hT, past, _ = O.transformer_stack(sd, "transformer.0", fused_in, m, tr, past)
+            c = torch.relu(O.dense(sd, "q_spliter.linear", hT))
+            want["lat"].append(hT[:, -1])
+            want["mean"].append(O.dense(sd, "transformer.1.mean", c)[:, -1])
+            want["logstd"].append(O.dense(sd, "transformer.1.logstd", c)[:, -1])
+            want["logits"].append(O.dense(sd, "token_predictor.linear",
+                                          torch.relu(O.dense(sd, "token_spliter.linear", hT)))[:, -1])
+    # ---- the HIP session
+    hipvg.set_precision("fp32")
+    model = LVTR(Hparams.from_dict(copy.deepcopy(cfg)), input_dim=80)
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda().eval()
+    xd, zeros = x.to(dev()), torch.zeros(B, 4, device=dev())
+    sess = DecodeSession(model, B, Tp + n + 2, use_graph=False, keep_latent=True)
+    assert sess._fused == (fused == "1")
+    sess.prefill(xd[:, :Tp], init_state=init.to(dev()), noise=torch.zeros(B, Tp + 1, 4, device=dev()))
+    got = dict(lat=[sess._last["transformer_latent"][:, -1].float()], mean=[sess._last["prior"].mean.value[:, -1].float()],
+               logstd=[sess._last["prior"].logstd.value[:, -1].float()], logits=[sess._last["logits"][:, -1].float()])
+    for i in range(1, n + 1):
+        sess.force_frame(xd[:, Tp + i - 1: Tp + i])
+        sess.step(noise=zeros)
+        got["lat"].append(sess._last["transformer_latent"][:, 0].float())
+        got["mean"].append(sess._last["mu_ls"][:, 0, :4])
+        got["logstd"].append(sess._last["mu_ls"][:, 0, 4:])
+        got["logits"].append(sess._last["logits"][:, 0])
+    for key, tol in (("lat", 1e-4), ("mean", 1e-4), ("logstd", 1e-4), ("logits", 5e-4)):
+        np.testing.assert_allclose(torch.stack(got[key], 1).cpu().numpy(), torch.stack(want[key], 1).numpy(),
+                                   atol=tol, rtol=2e-4, err_msg=key)
+    # the layer-0 key cache holds the oracle's keys of all Tp + 1 + n frames
+    cache = sess.kc[0][:, : Tp + 1 + n].float().cpu().numpy()
+    np.testing.assert_allclose(cache[:, ::7, ::13], past[0][0].numpy()[:, ::7, ::13], atol=2e-5)

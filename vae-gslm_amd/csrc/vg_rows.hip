@@ -681,6 +681,85 @@ extern "C" int vg_colsum(const void* x, int M, int N, int64_t ld, float* ws, flo
   return vg_host::check_launch("vg_colsum");
 }
 
+// =====================================================================================
+// Masked means of several small fp32 row tensors in ONE launch (round 4): out[k] = sum over valid frames m and
+// columns c of f_k(x_k[m][c]) / (cols_k * number of valid frames), f = identity or |.|.  These are the step's
+// monitors -- TensorMask.mean() of the prior / posterior mean and log-std, |posterior mean|, log p, log q
+// (utils/tensormask.py:135-140 called from models/speech/lvtr.py:210-224 and trainers/speech/lvtr.py:131-145 of the
+// reference) -- seven reductions that cost five tiny stock launches each (where, div, sum, sum of lengths, div).
+// Two launches: up to 64 blocks (one frame per thread and pass) leave per-block sums, one wave folds them and divides --
+// deterministic, no atomics (a first version as ONE block of 1024 threads took ~100 us: 16 dependent passes of
+// latency-bound row reads on one CU).
+// =====================================================================================
+namespace {
+struct MeanTasks {
+  vg_mean_task t[VG_MEAN_MAX_TASKS];
+  int n;
+};
+constexpr int MEAN_SLOTS = VG_MEAN_MAX_TASKS + 1;          // the tasks' sums + the valid-frame count
+__global__ __launch_bounds__(256) void masked_means_partial_kernel(MeanTasks tk, int M, const int* __restrict__ lengths,
+                                                                   int T, float* __restrict__ partial) {
+  __shared__ float red[4][MEAN_SLOTS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[MEAN_SLOTS];
+#pragma unroll
+  for (int k = 0; k < MEAN_SLOTS; ++k) acc[k] = 0.f;
+  for (int m = blockIdx.x * 256 + tid; m < M; m += gridDim.x * 256) {
+    if (!row_valid(lengths, T, m)) continue;
+    acc[VG_MEAN_MAX_TASKS] += 1.0f;
+#pragma unroll
+    for (int k = 0; k < VG_MEAN_MAX_TASKS; ++k) {
+      if (k < tk.n) {
+        const float* row = tk.t[k].src + (long)m * tk.t[k].ld;
+        float a = 0.f;
+        for (int c = 0; c < tk.t[k].cols; ++c) a += tk.t[k].absolute ? fabsf(row[c]) : row[c];
+        acc[k] += a;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MEAN_SLOTS; ++k) {
+    const float w = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = w;
+  }
+  __syncthreads();
+  if (tid < MEAN_SLOTS) partial[blockIdx.x * MEAN_SLOTS + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+__global__ __launch_bounds__(64) void masked_means_final_kernel(MeanTasks tk, const float* __restrict__ partial, int nblocks,
+                                                                float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float frames = 0.f;
+  for (int b = 0; b < nblocks; ++b) frames += partial[b * MEAN_SLOTS + VG_MEAN_MAX_TASKS];
+  if (lane < tk.n) {
+    float t = 0.f;
+    for (int b = 0; b < nblocks; ++b) t += partial[b * MEAN_SLOTS + lane];
+    out[lane] = t / ((float)tk.t[lane].cols * frames);
+  }
+}
+}  // namespace
+
+extern "C" int vg_masked_means_blocks(int M) {
+  const int b = (M + 255) / 256;
+  return b < 64 ? (b < 1 ? 1 : b) : 64;
+}
+
+extern "C" int vg_masked_means(const vg_mean_task* tasks, int n, int M, const int32_t* lengths, int T, float* partial,
+                               float* out, hipStream_t stream) {
+  VG_REQUIRE(tasks != nullptr && n >= 1 && n <= VG_MEAN_MAX_TASKS && M > 0 && out != nullptr && partial != nullptr,
+             "vg_masked_means: n=%d M=%d", n, M);
+  MeanTasks tk;
+  tk.n = n;
+  for (int i = 0; i < n; ++i) {
+    VG_REQUIRE(tasks[i].src != nullptr && tasks[i].cols > 0 && tasks[i].cols <= 64 && tasks[i].ld >= tasks[i].cols,
+               "vg_masked_means: task %d: cols=%d ld=%ld", i, tasks[i].cols, (long)tasks[i].ld);
+    tk.t[i] = tasks[i];
+  }
+  const int nb = vg_masked_means_blocks(M);
+  masked_means_partial_kernel<<<dim3(nb), dim3(256), 0, stream>>>(tk, M, lengths, T > 0 ? T : 1, partial);
+  masked_means_final_kernel<<<dim3(1), dim3(64), 0, stream>>>(tk, partial, nb, out);
+  return vg_host::check_launch("vg_masked_means");
+}
+
 extern "C" int vg_sum_f32(const float* x, int64_t n, float* out, hipStream_t stream) {
   sum_kernel<<<dim3(1), dim3(1024), 0, stream>>>(x, (long)n, out);
   return vg_host::check_launch("vg_sum_f32");

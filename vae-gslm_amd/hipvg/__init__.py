@@ -44,6 +44,13 @@ class ColsumTask(C.Structure):
 
 COLSUM_MAX_TASKS = 32
 
+
+class MeanTask(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int64), ("cols", C.c_int32), ("absolute", C.c_int32)]
+
+
+MEAN_MAX_TASKS = 8
+
 # name -> argtypes (restype is always int); must list EVERY symbol of the header
 SIGNATURES = {
     "vg_version": [],
@@ -70,6 +77,8 @@ SIGNATURES = {
     "vg_colsum_blocks": [_i],
     "vg_colsum": [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp],
     "vg_colsum_multi": [C.POINTER(ColsumTask), _i, _vp],
+    "vg_masked_means": [C.POINTER(MeanTask), _i, _i, _vp, _i, _vp, _vp, _vp],
+    "vg_masked_means_blocks": [_i],
     "vg_colsum_partials_multi": [C.POINTER(ColsumTask), _i, _i, _i, _vp],
     "vg_colsum_segments": [_vp, _i, _i, _i, _i64, _vp, _i, _vp, _i, _vp],
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],

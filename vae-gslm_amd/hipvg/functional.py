@@ -448,6 +448,27 @@ def colsum_partials(mats):
     return parts
 
 
+def masked_means(items, lengths: Optional[Tensor], T: int) -> Optional[Tensor]:
+    """``items``: [(x [M, cols] fp32 with unit column stride, absolute: bool)] -> fp32 [len(items)] of
+    ``TensorMask(x, mask).mean()`` (or of |x|) in ONE launch (``vg_masked_means``); None when an item does not qualify
+    (the caller falls back to the stock expression).  Detached: these are monitors."""
+    import hipvg
+    if not items or len(items) > hipvg.MEAN_MAX_TASKS:
+        return None
+    M = items[0][0].shape[0]
+    for x, _ in items:
+        if (x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != M or x.stride(1) != 1 or x.shape[1] > 64
+                or not x.is_cuda):
+            return None
+    keep = [x.detach() for x, _ in items]
+    arr = (hipvg.MeanTask * len(items))(*[hipvg.MeanTask(k.data_ptr(), k.stride(0), k.shape[1], int(bool(a)))
+                                          for k, (_, a) in zip(keep, items)])
+    out = torch.empty(len(items), dtype=torch.float32, device=keep[0].device)
+    part = torch.empty((lib().vg_masked_means_blocks(M), hipvg.MEAN_MAX_TASKS + 1), dtype=torch.float32, device=out.device)
+    check(lib().vg_masked_means(arr, len(items), M, ptr(lengths), int(T), ptr(part), ptr(out), stream()), "vg_masked_means")
+    return out
+
+
 def segment_colsum(x: Tensor, nseg: int) -> Tensor:
     """``x.view(nseg, -1, C).float().sum(1)`` for [M, C] rows (M = nseg * T) in two small launches
     (``vg_colsum_segments``): fp32 [nseg, C]."""

@@ -279,7 +279,7 @@ class ConvNormAct(nn.Module):
         else:
             y = self.act(channel_norm_rows(y, self.norm, t_out))
         y = y.view(B, t_out, -1)
-        if self.factor != 1:
+        if self.factor != 1 and length is not None:      # None: every sequence is full and stays full (see CNNStack.forward)
             length = torch.clamp(TensorMask.resize_length(length, float(self.factor)), max=t_out)
         return y, length
 
@@ -316,11 +316,18 @@ class CNNStack(nn.Module):
             B, T = x.mask.shape
             if self.linear is not None:
                 h = dense_2d(h, self.linear.weight, self.linear.bias, lengths=x.lengths32, T=T)
-            length = x.length
+            # An input without padding (the fixed-length utterance crops) stays without padding: a down-sampling layer
+            # MULTIPLIES the lengths by its factor (reference modules/conv/layers.py:568,588-591) and clamps them to the new
+            # frame count, so full lengths map to full lengths at every level -- no length arithmetic (six tiny launches
+            # per layer), no mask build and no re-mask of the output
+            full = getattr(x.mask, "_vg_full", False) and all(l.factor >= 1 for l in self.layers)
+            length = None if full else x.length
             for layer in self.layers:
                 h, length = layer.forward_rows(h, length)
             if self.out_linear is not None:
                 h = dense_2d(h, self.out_linear.weight, self.out_linear.bias, out_f32=True)
+            if full:
+                return TensorMask(h.float())
             return TensorMask.fromlength(h.float(), length).apply_mask()
         if self.linear is not None:
             h = TensorMask(self.linear(h), x.mask).apply_mask().value

@@ -237,10 +237,15 @@ class LVTRTrainer(BaseTrainer):
             # after the first backward: who was never written by the library?
             self._owned = [p for p in self.model.parameters()
                            if p.requires_grad and p.grad is not None and not getattr(p, "_vg_sunk", False)]
-        result = {"kld": kld.detach(), "rec_loss": rec.detach(), "log_p": -out["log_p"].mean().detach(),
+        # (log_p_mean / log_q_mean: the same masked means from the model's fused monitor launch, when it ran)
+        lp_mean = out.get("log_p_mean")
+        lq_mean = out.get("log_q_mean")
+        result = {"kld": kld.detach(), "rec_loss": rec.detach(),
+                  "log_p": -(lp_mean if lp_mean is not None else out["log_p"].mean()).detach(),
                   "length": out["log_p"].length.sum(), "kld_weight": kld_weight,
                   "logstd": out["logstd"].detach(), "q_logstd": out["q_logstd"].detach(),
-                  "log_q": -out["log_q"].mean().detach(), "q_mean_abs": out["q_mean_abs"].detach(),
+                  "log_q": -(lq_mean if lq_mean is not None else out["log_q"].mean()).detach(),
+                  "q_mean_abs": out["q_mean_abs"].detach(),
                   "loss": loss.detach()}
         if self.use_tokens:
             result["token_kld"] = out["ce_loss"].detach()
