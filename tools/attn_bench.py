@@ -51,7 +51,7 @@ def main():
         bwd = lambda: L.vg_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(slopes), p(dqkv), p(delta), B, T, H, None, 1, st)
         fl = 256.0 * B * H * 0.5 * T * (T + 1)
         tf, tb = timeit(fwd), timeit(bwd)
-        print(f"B={B} T={T}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF | bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF", flush=True)
+        print(f"B={B} T={T}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF | bwd {tb*1e6:7.1f} us {2.0*fl/tb/1e12:6.1f} TF (2 x forward, SURVEY 8d)", flush=True)
 
 
 if __name__ == "__main__":
