@@ -22,13 +22,17 @@ def run(fns):
         f()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(ITERS):
-        for f in fns:
-            f()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / (ITERS * len(fns)) * 1e3
+    best = None
+    for _ in range(2):           # twice, the faster one: the first timed pass over fresh buffers occasionally takes 5-50x
+        a.record()               # (page mapping of the output tensors), for either library
+        for _ in range(ITERS):
+            for f in fns:
+                f()
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) / (ITERS * len(fns)) * 1e3
+        best = t if best is None else min(best, t)
+    return best
 
 
 hipvg.lib()

@@ -385,6 +385,7 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bias[e] = b0[e]; bias[4 + e] = b1[e]; }
   }
+  const float relu_floor = (p.act & 15) == VG_ACT_RELU ? 0.f : -INFINITY;
   float cp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // the tile's global operands (residual / stored derivative: 16 x 16 bytes per lane) are all requested here, ahead
   // of the barrier and of the first LDS transpose: one exposed memory round trip per tile instead of one per band
@@ -469,20 +470,23 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
           for (int e = 0; e < 8; ++e) v[e] = ((float)g[i][ps][e] > 0.f) ? v[e] : 0.f;
         }
       } else {
-        if ((p.act & 15) == VG_ACT_RELU) {
+        // ReLU as a max against a wave-uniform floor (0 or -inf): one v_max per value whether the launch asks for it or
+        // not -- the per-value select the compiler made of `if (act == RELU)` cost two more instructions per value in
+        // every plain launch (436 of the epilogue's 1465 vector instructions)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], relu_floor);
         if (res != nullptr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)g[i][ps][e];
         }
       }
-      const int t = t0 + rloc;
-      const bool keep = t < p.T ? t < len0 : t - p.T < len1;
-      if (!keep) {
+      if (p.lengths != nullptr) {          // wave-uniform: launches without a row mask skip the test and the selects
+        const int t = t0 + rloc;
+        const bool keep = t < p.T ? t < len0 : t - p.T < len1;
+        if (!keep) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
       }
       bf16x8 o;
 #pragma unroll
