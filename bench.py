@@ -52,8 +52,8 @@ def cpu_model_name() -> str:
 
 def cpu_baseline(threads_note=True):
     """Oracle (CPU port of the reference fp32 path): full config, B=2, T=1000,
-    forward+backward after a short warm-up at T=64.  `cores` reports the host's core count; the run itself uses at
-    most 32 intra-op threads (`threads`): on these shapes more threads only add synchronisation cost -- a 256-thread
+    forward+backward after a short warm-up at T=64.  `cores` reports the intra-op threads the sample used (at most 32;
+    `host_cores` is the box's core count): on these shapes more threads only add synchronisation cost -- a 256-thread
     pool made the same sample take minutes instead of seconds."""
     import yaml
     from oracle import lvtr_oracle as O
@@ -97,8 +97,9 @@ def cpu_baseline(threads_note=True):
             one(T, 3 + i)
         steps += more
         dt = time.perf_counter() - t0
-    return {"value": steps * B * T / dt, "unit": "tokens/s", "cores": os.cpu_count() or 1, "kind": "port",
-            "cpu_model": cpu_model_name(), "threads": torch.get_num_threads(),
+    # `cores` = the threads the sample actually ran on (the contract's meaning); the host's core count beside it
+    return {"value": steps * B * T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model_name(), "host_cores": os.cpu_count() or 1,
             "sample": f"oracle fp32 fwd+bwd, full config, B={B}, T={T}, {steps} step(s) ({dt:.1f} s) after a warm-up"}
 
 
@@ -378,9 +379,9 @@ def main():
         # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
         # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v9.json), valid for the default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
         if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
         if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16" and args.coalesce and not args.ragged:
             with open(pmc) as f:
                 traffic = json.load(f)["bf16_gemm_family"]["traffic_bytes_per_launch"]
