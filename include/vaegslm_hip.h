@@ -122,6 +122,12 @@ int vg_rmsnorm_bwd_blocks(int M);
 int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rstd, const void* dx_add,
                    void* dx, float* dscale_partial, int M, int C, const int32_t* lengths, int T, int dtype,
                    vg_stream_t stream);
+/* the same launch, which also leaves the column sums of the dx it stores: dx_colsum_partial fp32 [nblocks][C] (C at most
+ * 128 16-byte vectors; NULL = vg_rmsnorm_bwd).  dx of a layer's first norm is the incoming gradient of the layer below,
+ * whose FFN-out bias gradient is the column sum of exactly that tensor (modules/transformer/layers.py:82-86). */
+int vg_rmsnorm_bwd_colsum(const void* dy, const void* x, const float* scale, const float* rstd, const void* dx_add,
+                          void* dx, float* dscale_partial, float* dx_colsum_partial, int M, int C,
+                          const int32_t* lengths, int T, int dtype, vg_stream_t stream);
 
 /* ---------------------------------------------------------------- attention
  * Causal multi-head self-attention with in-kernel ALiBi, replacing the mask

@@ -144,21 +144,28 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------ RMSNorm backward
 // dx = dx_add + mask * rstd * (g - xhat * mean(g * xhat)),  g = dy * scale, xhat = x * rstd
 // dscale_partial[block][c] = sum over this block's valid rows of dy * xhat
-template <typename T, int NV>
+// COLS (round 4): dx_colsum_partial[block][c] = sum over this block's rows of the STORED dx (rounded to T first): the
+// layer below needs the column sums of exactly this tensor for its FFN-out bias gradient -- a 33 MB read of its own
+// otherwise (colsum_partials, ~10 us per layer); here it rides on a kernel that is bound by its four row streams.
+template <typename T, int NV, bool COLS>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ rstd, const T* __restrict__ dx_add,
                                                           T* __restrict__ dx, float* __restrict__ dscale_partial,
+                                                          float* __restrict__ dx_colsum_partial,
                                                           int M, int C, const int* __restrict__ lengths, int Tlen) {
   constexpr int N = Vec<T>::N;
   __shared__ float red[4][64 * 8];             // [wave][lane * N + e], N <= 8
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C / N;
-  float ds[NV][8];
+  float ds[NV][8], cs[COLS ? NV : 1][8];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ds[i][e] = 0.f;
+    for (int e = 0; e < 8; ++e) {
+      ds[i][e] = 0.f;
+      if constexpr (COLS) cs[i][e] = 0.f;
+    }
 
   // two frames in flight per wave: the next frame's three row segments are requested (and kept packed) before
   // this frame's reduction
@@ -217,6 +224,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
           for (int e = 0; e < N; ++e) out[e] += r * (g[i][e] - xh[i][e] * dot);
         }
         Vec<T>::store(dx + (long)row * C + c * N, out);
+        if constexpr (COLS) {
+#pragma unroll
+          for (int e = 0; e < N; ++e) cs[i][e] += to_f32<T>(from_f32<T>(out[e]));
+        }
         ra[i] = na[i];
         rb[i] = nb[i];
         ro[i] = no[i];
@@ -239,6 +250,25 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += scratch[(w * 64 + lane) * N + e];
         dscale_partial[(long)blockIdx.x * C + c * N + e] = s;
+      }
+    }
+  }
+  if constexpr (COLS) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < N; ++e) scratch[(wave * 64 + lane) * N + e] = cs[i][e];
+      __syncthreads();
+      const int c = lane + 64 * i;
+      if (wave == 0 && c < nvec) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) t += scratch[(w * 64 + lane) * N + e];
+          dx_colsum_partial[(long)blockIdx.x * C + c * N + e] = t;
+        }
       }
     }
   }
@@ -573,11 +603,17 @@ void run_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, in
 }
 template <typename T>
 void run_rmsnorm_bwd(int nb, const void* dy, const void* x, const float* scale, const float* rstd,
-                     const void* dx_add, void* dx, float* dsp, int M, int C, const int32_t* lengths, int Tn,
+                     const void* dx_add, void* dx, float* dsp, float* csp, int M, int C, const int32_t* lengths, int Tn,
                      hipStream_t stream) {
   const int nv = (C / Vec<T>::N + 63) / 64;
-  auto k = nv <= 1 ? rmsnorm_bwd_kernel<T, 1> : nv <= 2 ? rmsnorm_bwd_kernel<T, 2> : rmsnorm_bwd_kernel<T, MAXV>;
-  k<<<dim3(nb), dim3(256), 0, stream>>>((const T*)dy, (const T*)x, scale, rstd, (const T*)dx_add, (T*)dx, dsp, M, C,
+  if (csp != nullptr && nv <= 2) {      // column sums of dx on the side (the widths of the Transformer stack)
+    auto k = nv <= 1 ? rmsnorm_bwd_kernel<T, 1, true> : rmsnorm_bwd_kernel<T, 2, true>;
+    k<<<dim3(nb), dim3(256), 0, stream>>>((const T*)dy, (const T*)x, scale, rstd, (const T*)dx_add, (T*)dx, dsp, csp, M, C,
+                                          lengths, Tn);
+    return;
+  }
+  auto k = nv <= 1 ? rmsnorm_bwd_kernel<T, 1, false> : nv <= 2 ? rmsnorm_bwd_kernel<T, 2, false> : rmsnorm_bwd_kernel<T, MAXV, false>;
+  k<<<dim3(nb), dim3(256), 0, stream>>>((const T*)dy, (const T*)x, scale, rstd, (const T*)dx_add, (T*)dx, dsp, nullptr, M, C,
                                         lengths, Tn);
 }
 template <typename T>
@@ -616,19 +652,35 @@ extern "C" int vg_rmsnorm_bwd_blocks(int M) {
   return b < 512 ? b : 512;
 }
 
-extern "C" int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rstd,
-                              const void* dx_add, void* dx, float* dscale_partial, int M, int C,
-                              const int32_t* lengths, int T, int dtype, hipStream_t stream) {
-  if (int e = check_row_shape("vg_rmsnorm_bwd", M, C, dtype)) return e;
+static int rmsnorm_bwd_any(const char* who, const void* dy, const void* x, const float* scale, const float* rstd,
+                           const void* dx_add, void* dx, float* dscale_partial, float* dx_colsum_partial, int M, int C,
+                           const int32_t* lengths, int T, int dtype, hipStream_t stream) {
+  if (int e = check_row_shape(who, M, C, dtype)) return e;
   const int nb = vg_rmsnorm_bwd_blocks(M), Tn = T > 0 ? T : 1;
   const double esz = dtype == VG_BF16 ? 2.0 : 4.0;       // read dy, x (+ the residual-path gradient), write dx
   const int tok = vg_host::prof_begin(VG_PROF_RMSNORM_BWD, (double)M * ((dx_add ? 4.0 : 3.0) * C * esz + 4.0), stream);
   if (dtype == VG_BF16)
-    run_rmsnorm_bwd<bf16_t>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, M, C, lengths, Tn, stream);
+    run_rmsnorm_bwd<bf16_t>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, dx_colsum_partial, M, C, lengths, Tn, stream);
   else
-    run_rmsnorm_bwd<float>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, M, C, lengths, Tn, stream);
+    run_rmsnorm_bwd<float>(nb, dy, x, scale, rstd, dx_add, dx, dscale_partial, dx_colsum_partial, M, C, lengths, Tn, stream);
   vg_host::prof_end(tok, stream);
-  return vg_host::check_launch("vg_rmsnorm_bwd");
+  return vg_host::check_launch(who);
+}
+
+extern "C" int vg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rstd,
+                              const void* dx_add, void* dx, float* dscale_partial, int M, int C,
+                              const int32_t* lengths, int T, int dtype, hipStream_t stream) {
+  return rmsnorm_bwd_any("vg_rmsnorm_bwd", dy, x, scale, rstd, dx_add, dx, dscale_partial, nullptr, M, C, lengths, T, dtype,
+                         stream);
+}
+
+extern "C" int vg_rmsnorm_bwd_colsum(const void* dy, const void* x, const float* scale, const float* rstd,
+                                     const void* dx_add, void* dx, float* dscale_partial, float* dx_colsum_partial, int M,
+                                     int C, const int32_t* lengths, int T, int dtype, hipStream_t stream) {
+  VG_REQUIRE(dx_colsum_partial == nullptr || C / (dtype == VG_BF16 ? 8 : 4) <= 128,
+             "vg_rmsnorm_bwd_colsum: the column sums of dx are produced for rows of at most 128 vectors (C=%d)", C);
+  return rmsnorm_bwd_any("vg_rmsnorm_bwd_colsum", dy, x, scale, rstd, dx_add, dx, dscale_partial, dx_colsum_partial, M, C,
+                         lengths, T, dtype, stream);
 }
 
 namespace vg_host {

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vg_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp],
     "vg_rmsnorm_bwd_blocks": [_i],
     "vg_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "vg_rmsnorm_bwd_colsum": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "vg_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "vg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "vg_attn_fwd_varlen": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],

@@ -730,11 +730,8 @@ class RMSNormFn(torch.autograd.Function):
         x, sc, rstd, lengths = ctx.saved_tensors
         M, Cc = x.shape
         dy = _as(dy, x.dtype)
-        dx = torch.empty_like(x)
-        nb = lib().vg_rmsnorm_bwd_blocks(M)
-        part = torch.empty((nb, Cc), dtype=torch.float32, device=x.device)
-        check(lib().vg_rmsnorm_bwd(ptr(dy), ptr(x), ptr(sc), ptr(rstd), None, ptr(dx), ptr(part), M, Cc,
-                                   ptr(lengths), int(ctx.T), dtype_id(x.dtype), stream()), "vg_rmsnorm_bwd")
+        # (the stack's final norm: its dx is the incoming gradient of the top Transformer layer)
+        dx, part = rmsnorm_bwd_raw(dy, x, sc, rstd, None, lengths, int(ctx.T), dx_colsum=True)
         dscale = colsum(part) if ctx.needs_input_grad[1] else None
         return dx, dscale, None, None, None
 
@@ -1185,11 +1182,24 @@ def sink_vector(p: Tensor, value: Tensor) -> None:
     _fire(p)
 
 
-def rmsnorm_bwd_raw(dy, x, sc, rstd, dx_add, lengths, T):
+_DX_COLSUM = _flag("VG_DX_COLSUM", "1")         # rmsnorm_bwd leaves the column sums of its dx for the layer below
+
+
+def rmsnorm_bwd_raw(dy, x, sc, rstd, dx_add, lengths, T, dx_colsum: bool = False):
+    """(dx, per-block partial sums of the scale gradient).  ``dx_colsum``: the launch also leaves per-block column sums of
+    the dx it stores, attached to the returned tensor as ``dx._vg_colparts`` ([nblocks, C] fp32): dx is the incoming
+    gradient of the node below, which can take its bias gradient from there instead of re-reading the tensor."""
     M, Cc = x.shape
     dx = torch.empty_like(x)
     nb = lib().vg_rmsnorm_bwd_blocks(M)
     part = torch.empty((nb, Cc), dtype=torch.float32, device=x.device)
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if dx_colsum and _DX_COLSUM and Cc // vec <= 128:
+        cpart = torch.empty((nb, Cc), dtype=torch.float32, device=x.device)
+        check(lib().vg_rmsnorm_bwd_colsum(ptr(dy), ptr(x), ptr(sc), ptr(rstd), ptr(dx_add), ptr(dx), ptr(part), ptr(cpart), M,
+                                          Cc, ptr(lengths), int(T), dtype_id(x.dtype), stream()), "vg_rmsnorm_bwd_colsum")
+        dx._vg_colparts = cpart
+        return dx, part
     check(lib().vg_rmsnorm_bwd(ptr(dy), ptr(x), ptr(sc), ptr(rstd), ptr(dx_add), ptr(dx), ptr(part), M, Cc,
                                ptr(lengths), int(T), dtype_id(x.dtype), stream()), "vg_rmsnorm_bwd")
     return dx, part
@@ -1310,7 +1320,12 @@ class TransformerLayerFn(torch.autograd.Function):
                 big.append((bias, g_out))
                 return None, None
             return None, vec_grad(bias, g_out)
-        g_w2, g_b2 = wgrad(w2, b2, dy, h)
+        # b2's gradient = column sums of dy.  When dy is the dx of the rmsnorm_bwd launch of the node above (the layer
+        # above's first norm, or the stack's final norm) that launch has left them (`_vg_colparts`): no pass over dy
+        dy_parts = getattr(dy, "_vg_colparts", None)
+        if dy_parts is not None and (dy_parts.shape[1] != D or not _sinkable(b2)):
+            dy_parts = None
+        g_w2, g_b2 = wgrad(w2, None if dy_parts is not None else b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
         small = []                               # (parameter, fp32 partial sums): folded by one launch at the end
         g_b1 = None
@@ -1335,8 +1350,10 @@ class TransformerLayerFn(torch.autograd.Function):
                   "vg_attn_bwd_varlen")
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
         g_wq, g_bq = wgrad(wqkv, bqkv, dqkv, n1)
-        dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T)
+        dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T, dx_colsum=True)
         small.append((n1s, ds1))
+        if dy_parts is not None:
+            small.append((b2, dy_parts))
         if big:                                  # b2 <- dy, bo <- dx1, bqkv <- dqkv (and b1 <- du without colpart)
             parts_big = colsum_partials([g for _, g in big])
             if parts_big is None:
