@@ -98,9 +98,11 @@ int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 int vg_gemm_tile_rows(const vg_gemm_desc* desc);
 /* Several weight-gradient products in ONE launch.  Contract (anything else is refused with a message in
  * vg_last_error and nothing is launched -- run those through vg_gemm): every desc bf16, a_tr = b_tr = 1, fp32 C
- * (out_f32 = 1) in 16-byte aligned rows (N % 8 == 0, ldc % 4 == 0), K a multiple of 64, split_k = 1, accumulate = 1,
+ * (out_f32 = 1) in 16-byte aligned rows (N % 8 == 0, ldc % 4 == 0), K a multiple of 64, split_k = 1,
  * alpha = 1 (C += A^T B: C must hold its initial value; the launch divides the reduction among its blocks itself
- * and combines whole-K segments with plain adds, head / tail pieces with fp32 atomics), no epilogue fields.  Replaces
+ * and combines whole-K segments with plain adds, head / tail pieces with fp32 atomics), no epilogue fields.
+ * accumulate = 0 (round 4) is the caller's statement that C holds ZEROS -- the first contribution since the optimizer
+ * cleared the gradient: whole-K segments then store without reading C; pieces still add atomically.  Replaces
  * the four dW = dY^T X launches of one Transformer layer's backward (the nn.Linear weight gradients autograd computes
  * for modules/transformer/layers.py:52,79,82,151 of the reference) and the two or three of a conv bottleneck block
  * (modules/conv/layers.py): one persistent grid of 256 blocks with equal (tile, K tile) unit counts.  Round 4: up to

@@ -236,3 +236,48 @@ def test_full_config_decode_session_fp32_matches_oracle(full_cfg, fused, monkeyp
     # the layer-0 key cache holds the oracle's keys of all Tp + 1 + n frames
     cache = sess.kc[0][:, : Tp + 1 + n].float().cpu().numpy()
     np.testing.assert_allclose(cache[:, ::7, ::13], past[0][0].numpy()[:, ::7, ::13], atol=2e-5)
+
+
+def test_fresh_pass_stores_and_second_contributions_accumulate(F):
+    """vg_gemm_grouped with accumulate = 0 (hipvg.functional.begin_backward_pass(True): the gradients hold zeros): whole-K
+    tiles are stored without reading C; a second product into the same region in the same pass (a module applied twice)
+    accumulates; a product that took the single-launch route first is seen by the grouped one; a pass that is not fresh
+    adds to what is there.  Exact on small integers."""
+    frames = 4096
+    g = torch.Generator().manual_seed(21)
+    items, weights, refs = _make([(1024, 1024, 0, 1024, 0), (512, 2048, 0, 2048, 1), (2048, 608, 0, 512, 2),
+                                  (2048, 608, 512, 96, 2)], frames, g)
+    prods = {}
+    for (w, dy, x, col0), key in zip(items, [(1024, 1024, 0), (512, 2048, 1), (2048, 608, 2), (2048, 608, 2)]):
+        prods.setdefault(key, torch.zeros_like(weights[key].grad, dtype=torch.float64))[:, col0:col0 + x.shape[1]] += dy.double().T @ x.double()
+    # fresh pass on zeroed gradients: the result is the product itself
+    for w in weights.values():
+        w.grad.zero_()
+    F.begin_backward_pass(True)
+    try:
+        F.sink_wgrad_group(items)
+        for key, w in weights.items():
+            assert torch.equal(w.grad.double(), prods[key]), key
+        F.sink_wgrad_group(items)                       # the same regions again in the same pass: accumulate
+        for key, w in weights.items():
+            assert torch.equal(w.grad.double(), 2 * prods[key]), key
+    finally:
+        F.end_backward_pass()
+    # a product that went through the single-launch route first, then the same region in a grouped launch
+    for w in weights.values():
+        w.grad.zero_()
+    F.begin_backward_pass(True)
+    try:
+        F.sink_wgrad(items[0][0], items[0][1], items[0][2])
+        F.sink_wgrad_group(items)
+    finally:
+        F.end_backward_pass()
+    assert torch.equal(weights[(1024, 1024, 0)].grad.double(), 2 * prods[(1024, 1024, 0)])
+    assert torch.equal(weights[(512, 2048, 1)].grad.double(), prods[(512, 2048, 1)])
+    # not fresh: adds to what is there
+    before = {k: w.grad.double().clone() for k, w in weights.items()}
+    F.begin_backward_pass(False)
+    F.sink_wgrad_group(items)
+    F.end_backward_pass()
+    for key, w in weights.items():
+        assert torch.equal(w.grad.double(), before[key] + prods[key]), key

@@ -507,8 +507,8 @@ extern "C" int vg_gemm_grouped(const vg_gemm_desc* descs, int n, hipStream_t str
                    d->dact == VG_ACT_NONE && !d->colsum_out && !d->colpart,
                "vg_gemm_grouped: problem %d carries an epilogue", i);
     VG_REQUIRE(splits[i] == 1, "vg_gemm_grouped: problem %d: split_k = %d (must be 1: the launch divides the reduction itself)", i, splits[i]);
-    VG_REQUIRE(d->accumulate && d->alpha == 1.0f && d->N % 8 == 0 && d->ldc % 4 == 0 && ((uintptr_t)d->C % 16) == 0,
-               "vg_gemm_grouped: problem %d: C += A^T B into 16-byte aligned fp32 rows only (accumulate = 1, alpha = 1, N %% 8 == 0)", i);
+    VG_REQUIRE(d->alpha == 1.0f && d->N % 8 == 0 && d->ldc % 4 == 0 && ((uintptr_t)d->C % 16) == 0,
+               "vg_gemm_grouped: problem %d: C += A^T B into 16-byte aligned fp32 rows only (alpha = 1, N %% 8 == 0)", i);
     VG_REQUIRE((long)d->K * d->lda * 2 < 0x7ffffff0L && (long)d->K * d->ldb * 2 < 0x7ffffff0L, "vg_gemm_grouped: problem %d is too large", i);
     work += 2.0 * d->M * d->N * d->K;
     bytes += gemm_algorithmic_bytes(ps[i], 2);

@@ -834,12 +834,14 @@ struct GroupPlan {
   int first[9];                     // XCD x owns leftover tiles [first[x], first[x + 1]) of the tile line
   int epi;                          // what one segment's epilogue costs a block, in K tiles (balances heads and tails)
 };
-// One product of the group as the kernel needs it (48 bytes: VG_GROUP_MAX of them fit the 4 KB kernel-argument block,
+// One product of the group as the kernel needs it (56 bytes: VG_GROUP_MAX of them fit the 4 KB kernel-argument block,
 // which a full GemmParams per problem would not)
 struct GroupProb {
   const void* A; const void* B; void* C;
   int M, N, K;
   int lda, ldb, ldc;
+  int accumulate;      // 0: C holds zeros, whole-K tiles may store instead of read-modify-write
+  int pad_;
 };
 struct GroupParams {
   GroupProb q[VG_GROUP_MAX];
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(512) void gemm_ring_group_kernel(GroupParams gp) {
     p.M = q.M; p.N = q.N; p.K = q.K;
     p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
     p.k_per_split = q.K;
+    p.accumulate = q.accumulate;
     TileCtx<A_TR, B_TR> c;
     c.init_range(p, tile, kt * BK, count, gp.plan.lockstep ? 2 : 0, wave, lane);
     f32x4 acc[8][4];
@@ -1025,7 +1028,8 @@ int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_
   for (int i = 0; i < n; ++i) {
     if (splits[i] != 1) return -1;
     if (ps[i].lda > 0x7fffffffL || ps[i].ldb > 0x7fffffffL || ps[i].ldc > 0x7fffffffL) return -1;
-    gp.q[i] = GroupProb{ps[i].A, ps[i].B, ps[i].C, ps[i].M, ps[i].N, ps[i].K, (int)ps[i].lda, (int)ps[i].ldb, (int)ps[i].ldc};
+    gp.q[i] = GroupProb{ps[i].A, ps[i].B, ps[i].C, ps[i].M, ps[i].N, ps[i].K, (int)ps[i].lda, (int)ps[i].ldb, (int)ps[i].ldc,
+                        ps[i].accumulate, 0};
     gp.nkt[i] = ps[i].K / BK;
     gp.unit0[i] = (int)units;
     gp.tile0[i] = (int)tiles;

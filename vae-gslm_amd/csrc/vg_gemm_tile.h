@@ -525,8 +525,8 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
 
 
 // ---- lean epilogue of the weight-gradient products (fp32 C, alpha = 1, C += acc): plain 16-byte read-modify-write
-// when this block holds the tile's whole K range, fp32 atomics (two 128-byte row segments per wave-instruction) when
-// it holds a piece of it.  Same arithmetic as tile_epilogue's two fp32 branches without its other 15,000 instructions.
+// when this block holds the tile's whole K range (a plain store when p.accumulate == 0: C is known to hold zeros),
+// fp32 atomics (two 128-byte row segments per wave-instruction) when it holds a piece of it.  Same arithmetic as tile_epilogue's two fp32 branches without its other 15,000 instructions.
 template <int BM, int BN, int WM, int WN, bool ILV, bool ILVC>
 VG_DEVICE void tile_epilogue_wgrad(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0,
                                    bool atomic) {
@@ -573,8 +573,13 @@ VG_DEVICE void tile_epilogue_wgrad(const GemmParams& p, f32x4 (&acc)[BM / WM / 1
         const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
         if (m >= p.M || n >= p.N) continue;
         f32x4* dst = reinterpret_cast<f32x4*>(c + (long)m * p.ldc + n);
-        dst[0] += lo;
-        dst[1] += hi;
+        if (p.accumulate) {
+          dst[0] += lo;
+          dst[1] += hi;
+        } else {      // the caller vouches that C holds zeros (first contribution since the optimizer cleared it): no read
+          __builtin_nontemporal_store(lo, dst);
+          __builtin_nontemporal_store(hi, dst + 1);
+        }
       }
     }
   }

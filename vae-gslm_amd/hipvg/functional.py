@@ -179,6 +179,29 @@ def wgrad_splits(rows_out: int, cols_out: int, k_red: int, dtype: torch.dtype) -
 
 GROUP_MAX = 48        # VG_GROUP_MAX of include/vaegslm_hip.h: products per vg_gemm_grouped launch
 
+# "Fresh" backward passes (round 4).  The trainer opens every backward pass with begin_backward_pass(fresh): fresh = the
+# gradient buffers hold zeros (first pass since the optimizer / zero_grad cleared them).  In such a pass the FIRST
+# product written into a gradient region by a grouped launch may STORE its whole-K tiles instead of read-modify-write
+# (accumulate = 0 of vg_gemm_grouped: 4 bytes per parameter less traffic).  Every path that writes a weight gradient
+# records its region here, so that a second contribution to the same region in the same pass (a module applied twice, a
+# product that took another route first) accumulates.
+_WPASS = {"fresh": False, "written": set()}
+_WGRAD_STORE = _flag("VG_WGRAD_STORE", "1")
+
+
+def begin_backward_pass(fresh: bool) -> None:
+    _WPASS["fresh"] = bool(fresh) and _WGRAD_STORE
+    _WPASS["written"] = set()
+
+
+def end_backward_pass() -> None:
+    _WPASS["fresh"] = False
+    _WPASS["written"] = set()
+
+
+def _wgrad_region(g: Tensor):
+    return (g.data_ptr(), g.shape[0], g.shape[1])
+
 
 def _wgrad_grad_view(w, x, col0):
     N = w.shape[0]
@@ -209,16 +232,21 @@ def _launch_wgrad_items(items) -> None:
         for w, dy, x, col0 in items:
             N, K, M = w.shape[0], x.shape[1], x.shape[0]
             sp = wgrad_splits(N, K, M, x.dtype)
-            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=_wgrad_grad_view(w, x, col0), split_k=sp, accumulate=(sp == 1))
+            g = _wgrad_grad_view(w, x, col0)
+            _WPASS["written"].add(_wgrad_region(g))
+            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=g, split_k=sp, accumulate=(sp == 1))
         return
     descs = (GemmDesc * len(items))()
     for d, (w, dy, x, col0) in zip(descs, items):
         g = _wgrad_grad_view(w, x, col0)
+        region = _wgrad_region(g)
+        store = _WPASS["fresh"] and region not in _WPASS["written"]       # zeros underneath: whole-K tiles may store
+        _WPASS["written"].add(region)
         d.A, d.B, d.C = ptr(dy), ptr(x), ptr(g)
         d.M, d.N, d.K = w.shape[0], x.shape[1], x.shape[0]
         d.lda, d.ldb, d.ldc = dy.stride(0), x.stride(0), g.stride(0)
         d.a_tr, d.b_tr, d.dtype = 1, 1, dtype_id(torch.bfloat16)
-        d.out_f32, d.accumulate, d.split_k, d.alpha = 1, 1, 1, 1.0
+        d.out_f32, d.accumulate, d.split_k, d.alpha = 1, 0 if store else 1, 1, 1.0
     check(lib().vg_gemm_grouped(descs, len(items), stream()), "vg_gemm_grouped")
 
 
@@ -292,7 +320,9 @@ def sink_wgrad_group(items, fire: bool = True, tag: str = "misc") -> None:
         for w, dy, x, col0 in items:
             N, K, M = w.shape[0], x.shape[1], x.shape[0]
             sp = wgrad_splits(N, K, M, x.dtype)
-            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=_wgrad_grad_view(w, x, col0), split_k=sp, accumulate=(sp == 1))
+            g = _wgrad_grad_view(w, x, col0)
+            _WPASS["written"].add(_wgrad_region(g))
+            gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=g, split_k=sp, accumulate=(sp == 1))
     if fire:
         seen = set()
         for w, _, _, _ in items:
@@ -1115,6 +1145,7 @@ def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor, bias: Optional[Tensor] = None, 
         _wgrad_enqueue([(p, dy, x, 0)], fire, "misc")      # leaves with the other products of this backward piece
         return
     g = _grad_buffer(p).view(N, K)
+    _WPASS["written"].add(_wgrad_region(g))
     s = wgrad_splits(N, K, M, x.dtype)
     bg = None if bias is None else _grad_buffer(bias).view(-1)
     gemm(dy, x, N, K, M, a_tr=True, b_tr=True, out=g, split_k=s, accumulate=(s == 1), colsum_out=bg)
@@ -1477,6 +1508,7 @@ class ConvBlockFn(torch.autograd.Function):
             return the dense gradient."""
             if _sinkable(p):
                 g = _grad_buffer(p).view(rows, -1)[:, col0:col0 + cols]
+                _WPASS["written"].add(_wgrad_region(g))
                 s = wgrad_splits(rows, cols, M, dt)
                 bg = None
                 if _FUSE_BIAS_GRAD and bias is not None and _sinkable(bias):

@@ -215,11 +215,15 @@ class LVTRTrainer(BaseTrainer):
             for p, _ in fold:
                 p.grad = None
         from hipvg import functional as HF
+        # first backward pass since the gradients were cleared: grouped weight-gradient launches may store their whole
+        # tiles instead of adding to the zeros underneath (hipvg.functional.begin_backward_pass)
+        HF.begin_backward_pass(getattr(self, "_wgrad_fresh", False))
         HF.defer_vec_grads(self._defer_colsums())
         try:
             loss.backward()
         except BaseException:
             HF.reset_vec_grads()
+            HF.end_backward_pass()
             raise
         if backward_tail:
             # the pieces below the model's own cuts (the posterior encoder sits below the reparameterised sample) belong
@@ -306,16 +310,25 @@ class LVTRTrainer(BaseTrainer):
             batch, self._held = self._concat_batches(self._held), []
         if self.reducer is not None:
             self.reducer.sync_now = last
-        if self.use_graph and noise is None:
-            try:
-                out = self._graphed_micro_step(batch, batch_idx, last)
-            finally:
-                # the row count chosen for this capture / replay must not outlive it: a later direct call of the model
-                # (likelihood(), a user's forward) would pack a different batch into it
-                self._clear_pack_rows()
-        else:
-            self._choose_pack_rows(batch, eager=True)
-            out = self._training_loop(batch, batch_idx, noise)
+        # the gradient buffers hold zeros when this pass starts: one pass per optimizer step (no accumulation, or the
+        # window coalesced into this call), else the window's first micro-batch (every optimizer step ends by clearing them)
+        coalesced_pass = self.coalesce and noise is None and self.gradient_update_step > 1
+        self._wgrad_fresh = bool(coalesced_pass or self.gradient_update_step == 1 or batch_idx % self.gradient_update_step == 0)
+        from hipvg import functional as _HF
+        try:
+            if self.use_graph and noise is None:
+                try:
+                    out = self._graphed_micro_step(batch, batch_idx, last)
+                finally:
+                    # the row count chosen for this capture / replay must not outlive it: a later direct call of the model
+                    # (likelihood(), a user's forward) would pack a different batch into it
+                    self._clear_pack_rows()
+            else:
+                self._choose_pack_rows(batch, eager=True)
+                out = self._training_loop(batch, batch_idx, noise)
+        finally:
+            self._wgrad_fresh = False
+            _HF.end_backward_pass()                # a backward outside the trainer never inherits "gradients are zero"
         if last:
             clip = self.hp.training.get("gradient_clip_val", None)
             pipelined = (clip is None and self.reducer is not None and self.reducer.world > 1
@@ -421,7 +434,7 @@ class LVTRTrainer(BaseTrainer):
         # packed rows: the number of packed rows is part of the graph's shape.  It is chosen here, on the host, from
         # the batch's valid-frame count (one small device -> host read per micro-step) and rounded up to the granule,
         # so a ragged data stream needs one graph per (padded length, bucket) and not one per batch.
-        key = key + (self._choose_pack_rows(batch),)
+        key = key + (self._choose_pack_rows(batch), bool(getattr(self, "_wgrad_fresh", False)))
         dev = batch["mel"].value.device
         if self._kw_dev is None:
             self._kw_dev = torch.zeros((), dtype=torch.float32, device=dev)
