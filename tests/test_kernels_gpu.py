@@ -1042,3 +1042,39 @@ def test_kernels_without_atomics_are_bitwise_repeatable(F):
             assert torch.equal(a[k][valid], b[k][valid]), k
         else:
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("variant", list(LEAN_VARIANTS))
+@pytest.mark.parametrize("mode", ["nt", "nn"])
+def test_lean_epilogues_bitwise_on_launches_of_more_than_one_round(F, variant, mode):
+    """The same comparison on launches of more than one round of tiles (289 tiles of 256 rows, 374 of 192: every CU gets
+    a second block), ragged in both directions, with a row mask of 100 random lengths whose sequences (T = 41) end
+    inside 16-row bands: every lean variant bitwise equal to the all-options epilogue of tile_cfg 3."""
+    kw = LEAN_VARIANTS[variant]
+    M, N, K, T = 4100, 4104, 192, 41
+    A = rnd(M, K, dtype=torch.bfloat16)
+    B = rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=1)
+    if mode == "nn":
+        B = B.T.contiguous()
+    bias, res, der = rnd(N, seed=2), rnd(M, N, dtype=torch.bfloat16, seed=3), rnd(M, N, dtype=torch.bfloat16, seed=4)
+    lens = torch.randint(0, T + 1, (M // T,), generator=torch.Generator().manual_seed(5)).to(torch.int32).to(dev())
+    outs = {}
+    for cfg in (3, 13, 15):
+        args = dict(tile_cfg=cfg, b_tr=(mode == "nn"), lengths=lens, T=T)
+        if kw.get("bias"): args["bias"] = bias
+        if kw.get("residual"): args["residual"] = res
+        if "act" in kw: args["act"] = kw["act"]
+        if "dact" in kw: args.update(dact=kw["dact"], aux_in=der)
+        if kw.get("pre_add"): args["pre_add"] = res
+        aux = torch.zeros(M, N, device=dev(), dtype=torch.bfloat16) if kw.get("aux") else None
+        if aux is not None: args["aux_out"] = aux
+        part = [] if kw.get("colpart") else None
+        if part is not None: args["colpart"] = part
+        out = F.gemm(A, B, M, N, K, **args)
+        outs[cfg] = (out, aux, part[0] if part else None)
+    for cfg in (13, 15):
+        assert torch.equal(outs[3][0], outs[cfg][0]), cfg
+        if outs[3][1] is not None:
+            assert torch.equal(outs[3][1], outs[cfg][1]), cfg
+    if outs[3][2] is not None:
+        torch.testing.assert_close(outs[3][2].sum(0), outs[13][2].sum(0), atol=5e-2, rtol=1e-3)

@@ -579,7 +579,18 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
   // out of step and their epilogues no longer meet at the HBM -- with the removed work paid back by extra blocks, so that
   // the makespan in tile units stays the same -- made the FFN-in products 15-19 % SLOWER, 134.7 -> 160.3 us plain and
   // 183.5 -> 218.6 us with GELU + stored derivative at M = 16384: the blocks of an XCD read the same K slice of a few
-  // operand panels at the same time, and that lockstep is what keeps the panels L2 hits.)
+  // operand panels at the same time, and that lockstep is what keeps the panels L2 hits.  De-phasing whole XCDs instead
+  // (the first-round blocks of XCDs 4..7 started 5 / 10 / 15 us late, lockstep inside each XCD intact) gained nothing
+  // either: plain 127 -> 130 / 134 / 144 us, GELU + stored derivative 165 -> 176 us.
+  // Also measured and rejected: a PERSISTENT form of this kernel for launches of several rounds (one block per CU walks
+  // its tiles, requests the next tile's first eight images right after the barrier that ends the main loop -- before
+  // it writes the finished tile out -- and transposes through swizzled 32 KB strips in ring slots 8 and 9; bitwise
+  // equal results).  In-kernel stamps had priced a tile of the K = 1024 products at 2.2 us from block entry to a running
+  // pipeline + 16 x 1.3 us of K tiles + 4.3 us of epilogue + 0.5-1.5 us until the CU's next block enters (5 us after the
+  // GELU epilogue), but hiding the first and the last of those changed nothing: FFN-in forward 127-129 -> 123-126 us on
+  // cold operands, GELU 167-168 -> 166, QKV 94 -> 93-96, the training step 543-547 k -> 544-545 k tokens/s.  The
+  // dispatcher already starts a CU's next block while the last one's stores drain, and the counted waits of the new
+  // tile's prologue sit behind the finished tile's stores (vector-memory operations retire in order).)
   f32x4 acc[BM / 32][4];           // [a * 4 + i][b * 2 + j]; SCHED 2: [a * (BM / 64) + i][j]
   zero_acc(acc);
   if constexpr (SCHED == 1) ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);

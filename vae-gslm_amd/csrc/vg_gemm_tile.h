@@ -347,6 +347,16 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
 //   EPI_GELU_SAVE  C = mask(GELU(acc + bias)), aux_out = GELU'(acc + bias) (act = GELU | SAVE_DERIV)
 //   EPI_SILU_SAVE  the same with SiLU, and an optional pre_add operand     (act = SILU | SAVE_DERIV: the conv blocks)
 //   EPI_DACT       C = mask((acc + bias) * aux_in)                         (dact = STORED; dact = RELU: aux_in > 0 ? . : 0)
+// Round 4, measured and rejected: a register-only form (MFMAs with swapped operands, so that a lane holds four consecutive
+// columns of a row, one v_permlane16_swap per register to make them eight, 16-byte stores straight from registers: no
+// LDS strip, no barrier, ~480 executed vector instructions per wave and tile instead of ~1,200, results bitwise equal).
+// Its store instruction covers 16 rows x 64 bytes instead of 8 rows x 128 bytes, and the epilogue is no longer bound by
+// instruction issue since the stores went non-temporal: in-kernel stamps 4.2-4.8 us per plain tile for THIS epilogue
+// (256 CUs x 128 KB in that time is ~7.4 TB/s: the memory side's rate for a burst in which every CU stores at once)
+// against 5.0-6.4 us for the register-only one; x stored derivative 8.0 -> 10.0 us; GELU + stored derivative
+// 11.8 -> 10.3 us in the stamps build but no gain in the regular one (166 us per launch either way); training step
+// 535-540 k -> 512-514 k tokens/s with all variants switched, 532-538 k with the GELU variant only.  Half-line stores
+// cost more than the instructions saved.
 // Host-side preconditions (gemm_ph_launch): bf16 C, alpha = 1, one K slice, no pre_add / accumulate / colsum_out,
 // N % 8 == 0, T >= 16 when lengths are given.  colpart is supported (the dgrad that also reduces the bias gradient).
 enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3, EPI_SILU_SAVE = 4 };
