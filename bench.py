@@ -163,6 +163,10 @@ def main():
     ap.add_argument("--decode-batch", type=int, default=8)
     ap.add_argument("--prompt-frames", type=int, default=150)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--single-rank-rccl", action="store_true",
+                    help="N = 1 only: run the whole data-parallel step (segmented graphs, bucket all-reduces on the "
+                         "communication stream, per-bucket optimizer launches) on a ONE-rank RCCL communicator -- "
+                         "the machinery's cost without the wire, and a functional check of the RCCL path on one GPU")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,6 +213,16 @@ def main():
     dev_index = 0 if one_dev else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dp = world > 1 or args.single_rank_rccl        # collectives run
+    if args.single_rank_rccl:
+        assert world == 1 and args.gpus == 1, "--single-rank-rccl is the one-GPU exercise of the N > 1 path"
+        os.environ["VG_DP_SINGLE_RANK"] = "1"
+        if not dist.is_initialized():
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_dev:
@@ -249,8 +263,8 @@ def main():
     ranks = reducer.communicator_ranks()
     if ranks != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the gradient communicator has {ranks} rank(s) "
-                         f"(comm={args.comm}, backend={dist.get_backend() if world > 1 else 'none'})")
-    reducer.time_collectives = world > 1
+                         f"(comm={args.comm}, backend={dist.get_backend() if dist.is_initialized() else 'none'})")
+    reducer.time_collectives = dp
     trainer.global_step = hp.training.scheduler.warmup_kld      # past the KL warm-up
     # event pairs captured into the graph do not report on replay (and cost graph nodes): off unless asked for
     trainer.profile_in_graph = bool(args.graph) and os.environ.get("VG_PROF_IN_GRAPH", "0") == "1"
@@ -296,6 +310,8 @@ def main():
         for j in range(args.steps * accum):
             trainer.training_step(batches[lo + j], lo + j)
     sync()
+    if dp:
+        reducer.comm_stats()               # drop the warm-up's collectives from the record
     if not args.graph:
         hipvg.prof_enable(True)
     t0 = time.perf_counter()
@@ -308,9 +324,9 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    comm = reducer.comm_stats() if world > 1 else None
+    comm = reducer.comm_stats() if dp else None
     comm_exposed_ms = None
-    if world > 1:
+    if dp:
         # the same steps without their collectives: the difference is the part of the exchange nothing hides
         reducer.time_collectives, reducer.stub_collectives = False, True
         n_stub = min(args.steps, 3)
@@ -430,7 +446,7 @@ def main():
                          "step_model_frac": value / world * flop_per_token / PEAK_BF16,
                          "kernels": kinds},
         }
-        if world > 1:
+        if dp:
             nb = len(reducer.buckets)
             line["comm"] = {"rccl_ranks": ranks, "mode": args.comm,
                             "backend": dist.get_backend(), "buckets": nb,
@@ -447,9 +463,20 @@ def main():
                                     "ms_per_step minus the same steps with the collectives skipped"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which (block-buffered
+    # on a pipe) would otherwise surface after it, when the processes exit.  Every rank empties its C buffers, the
+    # ranks meet, the communicator goes, and only then does rank 0 write the line.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

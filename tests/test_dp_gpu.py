@@ -226,3 +226,60 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(full_cfg):
     # almost everywhere (bf16 kernels, atomics and Adam's eps leave a tail on near-zero gradients)
     close = ((single - dp).abs() <= 1e-4).float().mean().item()
     assert close > 0.97, close
+
+
+def _single_rank_worker(rank, port, cfg, comm, exchange, out):
+    """One process, one GPU: the data-parallel step on a one-rank communicator (real RCCL) or the plain step."""
+    if exchange:
+        os.environ["VG_DP_SINGLE_RANK"] = "1"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    if exchange and comm == "torch":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    from hparams.hp import Hparams
+    from trainers.speech.lvtr import LVTRTrainer
+    from training_lib.synthetic import make_batch
+    import hipvg
+    cfg = copy.deepcopy(cfg)
+    cfg.setdefault("hip", {})
+    cfg["hip"].update(precision="bf16", graph=True, bucket_mb=4, graph_bucket_mb=4, comm=comm)
+    torch.manual_seed(11)
+    tr = LVTRTrainer(Hparams.from_dict(cfg)).to(dev)
+    tr.configure_optimizers()
+    tr.attach_reducer()
+    tr.global_step = cfg["training"]["scheduler"]["warmup_kld"]
+    batches = [make_batch(2, 64, dev, seed=500 + i) for i in range(2)]
+    for it in range(6):
+        outp = tr.training_step(batches[it % 2], it)
+    torch.cuda.synchronize()
+    out["params"] = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()]).cpu()
+    out["loss"] = float(outp["loss"])
+    out["ranks"] = tr.reducer.communicator_ranks()
+    out["exchange"] = bool(tr.reducer.exchange)
+    out["segmented"] = bool(getattr(tr, "_segmented", False))
+    out["abi_world"] = int(hipvg.lib().vg_comm_world())
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm", ["torch", "abi"])
+def test_single_rank_rccl_step_ends_where_the_plain_step_ends(full_cfg, comm):
+    """REAL RCCL in the loop on one GPU (VG_DP_SINGLE_RANK=1): the segmented hipGraph step with every gradient bucket
+    all-reduced (AVG) on a one-rank communicator -- through torch.distributed's nccl backend or through
+    vg_comm_init / vg_allreduce_bucket (librccl loaded by the library itself) -- on the communication stream, with the
+    per-bucket optimizer waits.  The average over one rank is the identity: three optimizer steps must end where the
+    plain single-GPU step ends."""
+    from oracle.lvtr_oracle import small_config
+    cfg = copy.deepcopy(full_cfg)
+    cfg["model"] = small_config(full_cfg["model"])
+    res = {}
+    for exchange in (False, True):
+        mgr = mp.get_context("spawn").Manager()
+        out = mgr.dict()
+        mp.spawn(_single_rank_worker, args=(_free_port(), cfg, comm, exchange, out), nprocs=1, join=True)
+        res[exchange] = dict(out)
+    assert res[True]["exchange"] and res[True]["ranks"] == 1 and res[True]["segmented"]
+    assert res[True]["abi_world"] == (1 if comm == "abi" else 0)
+    assert not res[False]["exchange"]
+    torch.testing.assert_close(res[True]["params"], res[False]["params"], rtol=0.0, atol=4e-3)
+    assert abs(res[True]["loss"] - res[False]["loss"]) <= 2e-2 * abs(res[False]["loss"])

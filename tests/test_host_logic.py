@@ -278,3 +278,35 @@ def test_flat_adamw_bind_keeps_loaded_state():
         assert float(opt.state[p]["step"]) == 2.0
         assert opt.state[p]["exp_avg"].untyped_storage().data_ptr() in {f["M"].untyped_storage().data_ptr()
                                                                         for f in opt._flat}
+
+
+def test_full_config_bucket_plan_lets_the_segmented_replay_run(full_cfg, monkeypatch):
+    """The data-parallel step replays the micro-step as several hipGraphs and sends a bucket as soon as the graph that
+    finishes its gradients has been launched.  That needs buckets that ARE final after each graph: at the full
+    configuration the registration order once put the stack's input projection (final last) into the top layers' bucket,
+    no bucket qualified after the first graph and the segmented replay silently switched itself off (round 4, found
+    with the one-rank RCCL run).  The plan is host logic: build it on the CPU and check it."""
+    from trainers.speech.lvtr import LVTRTrainer
+    monkeypatch.setenv("VG_GRAPH_SEGMENTS", "force")
+    cfg = copy.deepcopy(full_cfg)
+    tr = LVTRTrainer(Hparams.from_dict(cfg))
+    tr.use_graph = True                                     # the plan does not depend on the device
+    tr.configure_optimizers()
+    red = tr.attach_reducer()
+    assert tr._segmented and tr.graph_cuts == [12, 8, 4]
+    names = {id(p): n for n, p in tr.model.named_parameters()}
+    in_bucket = [id(p) for b in red.buckets for p in b["params"]]
+    assert sorted(in_bucket) == sorted(names)               # every parameter in exactly one bucket
+    early = tr._early_buckets
+    assert len(early) == 4 and all(early) and all(set(a) <= set(b) for a, b in zip(early, early[1:]))
+    stack = tr.model.transformer[0]
+    # after the first graph: everything above the stack and layers 12..15; nothing of a lower layer, nothing of the input side
+    first = {names[id(p)] for i in early[0] for p in red.buckets[i]["params"]}
+    assert any(n.startswith("transformer.0.layers.15.") for n in first) and any(n.startswith("decoder.") for n in first)
+    assert not any(n.startswith(f"transformer.0.layers.{k}.") for k in range(12) for n in first)
+    assert not any(n.startswith(("encoder.", "token_embedding.", "token_fuser.", "transformer.0.linear.")) for n in first)
+    # after the last Transformer piece every layer is out, the input side is the one bucket left for the end
+    done = {names[id(p)] for i in early[-1] for p in red.buckets[i]["params"]}
+    assert all(any(n.startswith(f"transformer.0.layers.{k}.") for n in done) for k in range(len(stack.layers)))
+    left = [i for i in range(len(red.buckets)) if i not in early[-1]]
+    assert len(left) == 1 and red.buckets[left[0]]["flat"].numel() * 4 < 64 << 20

@@ -110,30 +110,55 @@ class LVTRTrainer(BaseTrainer):
                                              reverse=True)
         cuts = [c for c in cuts if 0 < c < nl]
         seg_env = os.environ.get("VG_GRAPH_SEGMENTS", "2")       # "1": one graph; "force": segmented on one rank too
-        self._segmented = bool(self.use_graph and (world > 1 or seg_env == "force") and cuts and seg_env != "1")
-        self.graph_cuts = list(cuts) if self._segmented else []      # reported by bench.py's comm block
+        single_rank = os.environ.get("VG_DP_SINGLE_RANK", "0") == "1"      # one-rank communicator, whole DP step (dp.py)
+        self._segmented = bool(self.use_graph and (world > 1 or single_rank or seg_env == "force") and cuts and seg_env != "1")
         boundaries = ()
-        if self._segmented:     # a bucket ends at every cut
+        params = list(self.model.parameters())
+        m = self.model
+        above = [p for mod in (m.decoder, m.utterance_encoder, m.transformer_flow, m.transformer[1],
+                               stack.final_norm, getattr(stack, "out", None), m.q_spliter, m.token_spliter,
+                               m.token_predictor) if mod is not None for p in mod.parameters()]
+        if self._segmented:
+            # Buckets are filled walking the parameter list backwards, so the list is put in the order in which backward
+            # FINISHES gradients, reversed: [input side: encoder, embeddings, the stack's own input projection]
+            # [layer 0] .. [layer L-1] [everything above the stack].  Registration order alone put the stack's input
+            # projection (registered after its layers, final only when backward has walked the whole stack) into the
+            # bucket of the top layers -- no bucket was final after the first graph and the segmented replay switched
+            # itself off at the full configuration (round 4: every collective ran after the last backward kernel).
+            # A bucket ends at every cut, where the layers begin and where they end.
+            seen = set()
+            above = [p for p in above if not (id(p) in seen or seen.add(id(p)))]
+            layer_params = [p for layer in stack.layers for p in layer.parameters()]
+            taken = {id(p) for p in above} | {id(p) for p in layer_params}
+            late = [p for p in params if id(p) not in taken]
+            params = late + layer_params + above
             boundaries = tuple(list(stack.layers[c - 1].parameters())[-1] for c in cuts)
-        self.reducer = GradReducer(self.model.parameters(), bucket_mb=bucket, overlap=overlap, group=group, comm=comm,
+            boundaries += (list(stack.layers[nl - 1].parameters())[-1],)
+            if late:
+                boundaries += (late[-1],)
+        self.reducer = GradReducer(params, bucket_mb=bucket, overlap=overlap, group=group, comm=comm,
                                    boundaries=boundaries)
         self._cut_layers, self._early_buckets = [], []
         if self._segmented:
-            m = self.model
-            above = [p for mod in (m.decoder, m.utterance_encoder, m.transformer_flow, m.transformer[1],
-                                   stack.final_norm, getattr(stack, "out", None), m.q_spliter, m.token_spliter,
-                                   m.token_predictor) if mod is not None for p in mod.parameters()]
             top = nl
             for c in cuts:          # after graph k the parameters above cut k are final
                 for layer in stack.layers[c:top]:
                     above += list(layer.parameters())
                 top = c
                 self._early_buckets.append(self.reducer.buckets_within(above))
+            # one more piece: the cuts near the input (fused token / z input, reparameterised sample) are a graph of
+            # their own, so that the bottom layers' bucket goes on the wire under the posterior encoder's backward
+            for layer in stack.layers[0:top]:
+                above += list(layer.parameters())
+            self._early_buckets.append(self.reducer.buckets_within(above))
             self._cut_layers = cuts
             if self._early_buckets[0]:
                 self.model.grad_cut_layer = tuple(cuts)
             else:
+                import warnings
+                warnings.warn("segmented hipGraph replay is off: no gradient bucket is final after the first graph")
                 self._segmented = False
+        self.graph_cuts = list(cuts) if self._segmented else []      # reported by bench.py's comm block
         bind = getattr(self.optimizer, "bind", None)
         if callable(bind) and next(self.model.parameters()).is_cuda:
             bind(self.reducer)                 # AdamW + bf16 weight refresh + gradient clear: one launch per bucket
@@ -154,12 +179,12 @@ class LVTRTrainer(BaseTrainer):
     def _backward_tail(self, segment: Optional[int] = None) -> None:
         """Backward of the parts below the model's backward cuts (none unless ``model.grad_cut_layer`` is set): the
         gradient left in each cut's leaves is fed into the tape below it, deepest cut last.  ``segment`` k runs only
-        the piece that belongs to graph k + 2 of a segmented replay: the k-th Transformer cut from the top, and with
-        the last one the cuts near the input."""
+        the piece that belongs to graph k + 2 of a segmented replay: the k-th Transformer cut from the top; the piece
+        after the last of them holds the cuts near the input."""
         cuts = list(reversed(getattr(self.model, "grad_cuts", [])))      # top Transformer cut first ... z last
         if segment is not None:
             n = len(self._cut_layers)
-            cuts = cuts[segment:segment + 1] if segment < n - 1 else cuts[n - 1:]
+            cuts = cuts[segment:segment + 1] if segment < n else cuts[n:]
         from hipvg import functional as HF
         HF.defer_vec_grads(self._defer_colsums())
         try:
@@ -176,7 +201,7 @@ class LVTRTrainer(BaseTrainer):
         """The finishing launches of the bias / scale column sums may wait for the end of a backward piece wherever
         nothing acts on "gradient ready" inside it: one rank, a non-final micro-step, or a captured segment (its
         buckets are reduced after the replay)."""
-        return (self.reducer is None or self.reducer.world == 1 or not self.reducer.sync_now
+        return (self.reducer is None or not self.reducer.exchange or not self.reducer.sync_now
                 or getattr(self, "_segmented", False))
 
     def _training_loop(self, batch: Mapping, batch_idx: int, noise: Optional[Mapping] = None,
@@ -210,7 +235,7 @@ class LVTRTrainer(BaseTrainer):
         # nothing acts on "gradient ready" before the pass ends (one rank, or a captured / non-final micro-step).
         fold = None
         if (self._owned is not None and self.reducer is not None and backward_tail and not getattr(self, "_segmented", False)
-                and (self.reducer.world == 1 or not self.reducer.sync_now) and self._fold_accum):
+                and (not self.reducer.exchange or not self.reducer.sync_now) and self._fold_accum):
             fold = [(p, p.grad) for p in self._owned if p.grad is not None]
             for p, _ in fold:
                 p.grad = None
@@ -331,7 +356,7 @@ class LVTRTrainer(BaseTrainer):
             _HF.end_backward_pass()                # a backward outside the trainer never inherits "gradients are zero"
         if last:
             clip = self.hp.training.get("gradient_clip_val", None)
-            pipelined = (clip is None and self.reducer is not None and self.reducer.world > 1
+            pipelined = (clip is None and self.reducer is not None and self.reducer.exchange
                          and getattr(self.optimizer, "clears_gradients", False))
             if self.reducer is not None and not pipelined:
                 self.reducer.finish()
@@ -483,7 +508,9 @@ class LVTRTrainer(BaseTrainer):
                     with torch.cuda.graph(graph, pool=self._graph_pool):
                         out = self._training_loop(static, batch_idx, kld_weight=self._kw_dev, backward_tail=False)
                     graph2 = []
-                    for k in range(len(self._cut_layers)):
+                    n_cut = len(self._cut_layers)
+                    # the Transformer cuts, then (if the model placed them) the cuts near the input as a last piece
+                    for k in range(n_cut + (1 if len(getattr(self.model, "grad_cuts", [])) > n_cut else 0)):
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, pool=self._graph_pool):
                             self._backward_tail(k)
@@ -510,7 +537,7 @@ class LVTRTrainer(BaseTrainer):
             if static[k].mask is not v.mask and not getattr(static[k].mask, "_vg_full", False):
                 static[k].mask.copy_(v.mask, non_blocking=True)     # lengths are recomputed inside the graph
         graph.replay()
-        reduce_now = last and self.reducer is not None and self.reducer.world > 1
+        reduce_now = last and self.reducer is not None and self.reducer.exchange
         if graph2 is not None:
             for k, g in enumerate(graph2):
                 if reduce_now:     # final already: on the wire under the next graph

@@ -23,6 +23,8 @@ in the CPU tests).  With ``world_size == 1`` it degenerates to the bucket views.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Iterable, List, Optional
 
 import torch
@@ -41,9 +43,18 @@ class GradReducer:
         if comm not in ("torch", "abi"):
             raise ValueError(f"hip.comm must be 'torch' or 'abi', got {comm!r}")
         self.comm = comm
-        if comm == "abi" and self.world > 1:
+        # Collectives run when there is more than one rank -- or, VG_DP_SINGLE_RANK=1, on a ONE-rank communicator: the
+        # whole data-parallel step (segmented hipGraph replay, bucket launches on the communication stream, per-bucket
+        # optimizer waits) through real RCCL on a one-GPU box.  The average over one rank is the identity, so the run
+        # must end where the plain single-GPU step ends (tests/test_dp_gpu.py), and its timing is the step's cost of
+        # the machinery without the wire (bench.py --single-rank-rccl).
+        self.exchange = self.world > 1 or os.environ.get("VG_DP_SINGLE_RANK", "0") == "1"
+        if self.exchange and self.world == 1 and comm == "torch" and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("VG_DP_SINGLE_RANK=1 with hip.comm=torch needs an initialised one-rank process group")
+        if comm == "abi" and self.exchange:
             from hipvg import comm as vg_comm
-            vg_comm.init(dist.get_rank(group), self.world, group)
+            rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+            vg_comm.init(rank, self.world, group)
         self.overlap = overlap
         self.sync_now = True           # set False on non-final micro-batches
         self._epoch = 0                # backward passes announced through new_backward()
@@ -150,7 +161,7 @@ class GradReducer:
                 return
             rem = self._remaining.get(key, 0)
             if rem <= 0:
-                if self.sync_now and self.world > 1:
+                if self.sync_now and self.exchange:
                     self._surprise = tuple(param.shape)
                 return
             self._remaining[key] = rem - 1
@@ -168,7 +179,7 @@ class GradReducer:
         for the step's signature (a counting rank launches nothing before ``flush()``, which also walks the buckets
         in index order) -- so ranks that disagree about the calibration state still issue the same sequence of
         collectives."""
-        if not (self.sync_now and self.world > 1):
+        if not (self.sync_now and self.exchange):
             return
         while self._next < len(self.buckets):
             b = self.buckets[self._next]
@@ -205,7 +216,7 @@ class GradReducer:
 
     def communicator_ranks(self) -> int:
         """Size of the communicator the collectives actually run on (not the launcher's environment)."""
-        if self.world == 1:
+        if not self.exchange:
             return 1
         if self.comm == "abi":
             import hipvg
@@ -225,7 +236,7 @@ class GradReducer:
     def wait_bucket(self, i: int) -> None:
         """Make the current stream wait for bucket ``i``'s all-reduce only (the optimizer can then update that
         bucket while later buckets are still on the wire)."""
-        if self.world == 1:
+        if not self.exchange:
             return
         b = self.buckets[i]
         if not b.get("launched", False):
@@ -251,7 +262,7 @@ class GradReducer:
 
     def reduce_all(self) -> None:
         """Launch the all-reduce of every bucket not yet on the wire (used when backward ran inside a hipGraph)."""
-        if self.world > 1:
+        if self.exchange:
             for b in self.buckets:
                 if not b.get("launched", False):
                     self._launch(b)
@@ -259,7 +270,7 @@ class GradReducer:
     def reduce_buckets(self, indices) -> None:
         """Launch the all-reduce of the given buckets only (their gradients are final although backward is not:
         segmented hipGraph replay)."""
-        if self.world > 1:
+        if self.exchange:
             for i in indices:
                 if not self.buckets[i].get("launched", False):
                     self._launch(self.buckets[i])
@@ -273,7 +284,7 @@ class GradReducer:
         """End of the window's last backward: every bucket not yet on the wire is launched now (the counting pass of
         a new signature, buckets whose parameters received no gradient, hipGraph replays)."""
         self._end_pass()
-        if self.sync_now and self.world > 1:
+        if self.sync_now and self.exchange:
             self.reduce_all()
 
     def finish(self) -> None:
@@ -287,7 +298,7 @@ class GradReducer:
             b["handle"], b["launched"], b["ready"] = None, False, False
             b["pending"] = b["need"]
         self._next = 0
-        if self.comm_stream is not None and self.overlap and self.world > 1:
+        if self.comm_stream is not None and self.overlap and self.exchange:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def zero_grad(self) -> None:
