@@ -466,6 +466,9 @@ VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR, 64 * NTA>& c, f32x4 (&acc)[2 * 
   auto mfmas = [&](auto halfc) {
     constexpr int A0 = decltype(halfc)::value * NTA;
     __builtin_amdgcn_s_setprio(1);
+    // (round 4, timing-only lab: the phase's 32 MFMAs 16x16x32 issued as 16 MFMAs 32x32x16 on the same fragment registers --
+    // half the matrix instructions for the same bytes read -- ran the K = 4096 / N = 1024 product's loop in 91.6-92.8 us
+    // against 85.3-86.9, NN 95.3-95.4 against 93.6-94.6: the shorter instruction is the better fit for this schedule)
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
