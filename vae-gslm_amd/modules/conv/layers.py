@@ -181,21 +181,11 @@ class BottleNeckResNet(nn.Module):
         if (len(timed) > 1 and len({type(self.layers[i].act) for i in timed}) == 1
                 and os.environ.get("VG_BATCH_TEMB", "1") != "0"):
             a = self.layers[timed[0]].act(temb)
+            W = torch.cat([self.layers[i].time_emb.weight for i in timed], 0)
+            bvec = torch.cat([self.layers[i].time_emb.bias for i in timed], 0)
             sizes = [self.layers[i].time_emb.out_features for i in timed]
-            if (len(set(sizes)) == 1 and all(self.layers[i].time_emb.bias is not None for i in timed)
-                    and os.environ.get("VG_STOCK_TEMB", "0") != "1"):
-                # one product for all blocks (weight gradients sunk per block), then ONE copy that makes every block's
-                # [B, C] piece contiguous -- the row kernel reads it without a stride
-                full = HF.stacked_linear(a.to(dt).contiguous(), [self.layers[i].time_emb.weight for i in timed],
-                                         [self.layers[i].time_emb.bias for i in timed], out_f32=True)
-                pieces = full.view(full.shape[0], len(timed), sizes[0]).transpose(0, 1).contiguous()
-                for j, i in enumerate(timed):
-                    tes[i] = pieces[j]
-            else:
-                W = torch.cat([self.layers[i].time_emb.weight for i in timed], 0)
-                bvec = torch.cat([self.layers[i].time_emb.bias for i in timed], 0)
-                for i, piece in zip(timed, F.linear(a, W, bvec).split(sizes, dim=1)):
-                    tes[i] = piece
+            for i, piece in zip(timed, F.linear(a, W, bvec).split(sizes, dim=1)):
+                tes[i] = piece
         for i, block in enumerate(self.layers):
             h = block.forward_rows(h, T, cond2 if self.conditional[i] else None,
                                    temb if self.time_dim is not None else None, tes.get(i))

@@ -3,8 +3,6 @@ modules/diffusion/unet.py:10-27,67-93): sinusoidal time embedding -> 2-layer
 MLP, a Linear that squeezes the frame condition, and the conditional
 bottleneck ResNet.  Runs on stock PyTorch-ROCm ops (not part of the HIP list).
 """
-import os
-
 import torch
 from torch import nn
 
@@ -27,15 +25,7 @@ class TimeEmbedding(nn.Module):
         self.embedding = SinCos(hp.dim, maxpos=hp.maxpos)
 
     def forward(self, t: torch.Tensor) -> torch.Tensor:
-        emb = self.embedding.get(t)
-        if emb.is_cuda and emb.dim() == 2 and os.environ.get("VG_STOCK_TEMB", "0") != "1":
-            # the two Linears through the HIP GEMM (bf16 copies kept current by the flat optimizer, weight gradients
-            # sunk with the step's other products): under autocast each stock Linear is three cast launches + addmm
-            # forward and six launches backward for 16 rows of work
-            from modules.linear.layers import dense_2d
-            return dense_2d(self.act(dense_2d(emb, self.lin1.weight, self.lin1.bias, out_f32=True)),
-                            self.lin2.weight, self.lin2.bias, out_f32=True)
-        return self.lin2(self.act(self.lin1(emb)))
+        return self.lin2(self.act(self.lin1(self.embedding.get(t))))
 
 
 class ConditionalBottleNeckUNet(nn.Module):
