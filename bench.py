@@ -345,12 +345,26 @@ def main():
         tokens = world * sum(sum(l) for l in all_lens[args.warmup * accum:])
     value = tokens / elapsed
     if args.graph:
-        # kernels inside a replayed hipGraph cannot be bracketed by host-recorded events: measure the
-        # per-kernel durations on ONE extra optimizer step of the same workload launched eagerly
-        trainer.use_graph = False
-        hipvg.prof_enable(True)
-        for j in range(accum):
-            trainer.training_step(batches[it - accum + j], it - accum + j)
+        # Kernels inside a replayed hipGraph cannot be bracketed by host-recorded events: the per-kernel durations are
+        # measured on ONE extra optimizer step of the same workload launched eagerly -- BEHIND queued graph replays, so
+        # that the host has enqueued the step before the GPU reaches it and its kernels run back to back, as they do in
+        # the timed replays.  (Launched into an idle queue, as rounds 1-3 did, every kernel starts on a GPU that has been
+        # waiting for the host: rocprofv3 shows the same kernels 8-9 % longer there than in the replayed graph --
+        # grouped weight gradients 1,202 against 1,100 us -- and the event pairs add the dispatch latency on top.  Behind
+        # the replays the step's GPU span is 31.6-32.1 ms against 29.6 ms replayed, with 361 event pairs in it: the
+        # durations reported here still carry a few microseconds of marker time per launch, i.e. they err on the slow side.)
+        # A first eager step behind its own replays takes the allocator's and the lazy initialisations' host time.
+        def eager_step_behind_replays(profiled):
+            trainer.use_graph = True
+            for r in range(3):
+                for j in range(accum):
+                    trainer.training_step(batches[it - accum + j], it - accum + j)
+            trainer.use_graph = False
+            hipvg.prof_enable(profiled)
+            for j in range(accum):
+                trainer.training_step(batches[it - accum + j], it - accum + j)
+        eager_step_behind_replays(False)
+        eager_step_behind_replays(True)
         sync()
 
     if rank == 0:
@@ -440,8 +454,9 @@ def main():
                          "attn_ffn_path_tflops": layer_tflops, "attn_ffn_path_frac": layer_tflops / (PEAK_BF16 / 1e12),
                          "attn_ffn_path_ms": l_ms + a_ms,
                          "hbm_kernels": hbm_kernels,
-                         "measured_on": ("one eager optimizer step right after the timed hipGraph replays"
-                                         if args.graph else "the timed region"),
+                         "measured_on": ("one optimizer step launched eagerly (HIP event pair around every launch) behind "
+                                         "queued hipGraph replays right after the timed region: its kernels run back to "
+                                         "back, as in the replays" if args.graph else "the timed region"),
                          "step_model_tflops": value / world * flop_per_token / 1e12,
                          "step_model_frac": value / world * flop_per_token / PEAK_BF16,
                          "kernels": kinds},
