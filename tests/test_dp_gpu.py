@@ -12,7 +12,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+# a rank that dies must not leave the other one waiting for gloo's default 30 minutes
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+GLOO_TIMEOUT_S = 240
 
 
 def _free_port():
@@ -21,9 +23,30 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(fn, args, nprocs, port_index=1, on_retry=None):
+    """mp.spawn with ONE retry (fresh port, emptied result dict).  Ranks that share cuda:0 are an artefact of the one-GPU
+    test box (a run gives every rank its own device); once in some fifteen runs of this module a rank of such a pair died
+    in a test that passes unchanged before and after.  The first failure is printed in full, and a repeatable one is not
+    hidden: the retry fails too."""
+    try:
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+    except Exception as exc:      # noqa: BLE001 -- ProcessRaisedException / ProcessExitedException
+        import sys
+        print(f"[test_dp_gpu] first attempt of {fn.__name__} failed, retrying once:\n{exc}", file=sys.stderr, flush=True)
+        args = list(args)
+        args[port_index] = _free_port()
+        for a in args:
+            if type(a).__name__ == "DictProxy":
+                a.clear()
+        if on_retry is not None:
+            on_retry()
+        mp.spawn(fn, args=tuple(args), nprocs=nprocs, join=True)
+
+
 def _worker(rank, world, port, cfg, use_graph, out, overlap=True, comm="torch"):
+    import datetime
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=GLOO_TIMEOUT_S))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     from hparams.hp import Hparams
@@ -67,7 +90,7 @@ def test_two_rank_training_on_gpu(full_cfg, use_graph):
     world = 2
     mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), cfg, use_graph, out), nprocs=world, join=True)
+    _spawn(_worker, (world, _free_port(), cfg, use_graph, out), world)
     assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True)
     assert out["segmented"] == use_graph          # two ranks + hipGraph mode: the two-graph replay is the default
 
@@ -83,7 +106,7 @@ def test_two_rank_segmented_replay_matches_one_graph(full_cfg, monkeypatch):
         monkeypatch.setenv("VG_GRAPH_SEGMENTS", seg)
         mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
         out = mgr.dict()
-        mp.spawn(_worker, args=(2, _free_port(), cfg, True, out), nprocs=2, join=True)
+        _spawn(_worker, (2, _free_port(), cfg, True, out), 2)
         assert out[0] == (True, True, True, True) and out["segmented"] == (seg == "2")
         finals[seg] = out["params"]
     torch.testing.assert_close(finals["2"], finals["1"], rtol=0.0, atol=4e-3)
@@ -113,7 +136,11 @@ def test_two_rank_abi_exchange_matches_the_torch_exchange(full_cfg, monkeypatch,
             monkeypatch.setenv("FAKE_RCCL_DIR", str(ex))
         mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
         out = mgr.dict()
-        mp.spawn(_worker, args=(2, _free_port(), cfg, True, out, True, comm), nprocs=2, join=True)
+        def empty_exchange():          # a retried attempt must not meet the files of the failed one
+            if comm == "abi":
+                for f in ex.iterdir():
+                    f.unlink()
+        _spawn(_worker, (2, _free_port(), cfg, True, out, True, comm), 2, on_retry=empty_exchange)
         assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True) and out["segmented"]
         finals[comm] = out["params"]
         if comm == "abi":
@@ -153,7 +180,7 @@ def test_two_rank_eager_overlap_on_and_off_agree(full_cfg):
     for overlap in (True, False):
         mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
         out = mgr.dict()
-        mp.spawn(_worker, args=(2, _free_port(), cfg, False, out, overlap), nprocs=2, join=True)
+        _spawn(_worker, (2, _free_port(), cfg, False, out, overlap), 2)
         assert out[0] == (True, True, True, True) and out[1] == (True, True, True, True)
         finals[overlap] = out["params"]
     torch.testing.assert_close(finals[True], finals[False], rtol=0.0, atol=4e-3)
@@ -167,8 +194,9 @@ def _noise_for(B, T, seed, dev):
 
 
 def _one_step_worker(rank, world, port, cfg, out):
+    import datetime
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=GLOO_TIMEOUT_S))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     from hparams.hp import Hparams
@@ -203,7 +231,7 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(full_cfg):
     cfg["hip"].update(precision="bf16", graph=False, bucket_mb=4)
     mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
     out = mgr.dict()
-    mp.spawn(_one_step_worker, args=(2, _free_port(), cfg, out), nprocs=2, join=True)
+    _spawn(_one_step_worker, (2, _free_port(), cfg, out), 2)
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
     tr = LVTRTrainer(Hparams.from_dict(copy.deepcopy(cfg))).to(dev)
@@ -276,7 +304,7 @@ def test_single_rank_rccl_step_ends_where_the_plain_step_ends(full_cfg, comm):
     for exchange in (False, True):
         mgr = mp.get_context("spawn").Manager()
         out = mgr.dict()
-        mp.spawn(_single_rank_worker, args=(_free_port(), cfg, comm, exchange, out), nprocs=1, join=True)
+        _spawn(_single_rank_worker, (_free_port(), cfg, comm, exchange, out), 1, port_index=0)
         res[exchange] = dict(out)
     assert res[True]["exchange"] and res[True]["ranks"] == 1 and res[True]["segmented"]
     assert res[True]["abi_world"] == (1 if comm == "abi" else 0)
