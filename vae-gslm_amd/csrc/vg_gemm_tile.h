@@ -14,7 +14,10 @@ constexpr int BK = 64;
 // Results and epilogue operands are streamed once: non-temporal stores / loads keep them from evicting the operand panels
 // the other blocks of the XCD are still reading out of L2 (round 4, measured in one call on cold operands: QKV forward
 // 105-110 -> 97-101 us, N = K = 1024 34.4 -> 31.4 (NN 41 -> 34.5), N = 2048 / K = 512 45 -> 39, FFN-in 138-142 -> 134-137; in the
-// training step 485.6 -> 497.7 k tokens/s).  -DVG_EPI_TEMPORAL restores the plain forms for A/B builds.
+// training step 485.6 -> 497.7 k tokens/s).  -DVG_EPI_TEMPORAL restores the plain forms for A/B builds.  Per operand
+// (one call, two runs each): the GELU launch's result, which the next GEMM reads as its A operand, with the default
+// policy and its stored derivative streamed: 29.01-29.17 against 29.04-29.11 ms per step (no difference); the plain
+// launches' results with the default policy: 29.48-29.52 ms (worse).  Everything streamed stays.
 #ifndef VG_EPI_TEMPORAL
 #define VG_EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #define VG_EPI_LOAD(ptr) __builtin_nontemporal_load(ptr)
