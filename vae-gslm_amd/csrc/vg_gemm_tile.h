@@ -485,7 +485,11 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
       } else {
         // ReLU as a max against a wave-uniform floor (0 or -inf): one v_max per value whether the launch asks for it or
         // not -- the per-value select the compiler made of `if (act == RELU)` cost two more instructions per value in
-        // every plain launch (436 of the epilogue's 1465 vector instructions)
+        // every plain launch (436 of the epilogue's 1465 vector instructions).  NaN note (accepted): v_max
+        // returns the non-NaN operand, so a NaN accumulator leaves a NON-ReLU launch as -inf here where tile_epilogue
+        // passes the NaN through: still non-finite (a diverged run stays visible: tests/test_kernels_gpu.py,
+        // test_nan_stays_non_finite_through_lean_epilogues), but the "bitwise equal to the generic epilogue" statement
+        // holds for non-NaN accumulators only.  A NaN-propagating select costs a second instruction per value.
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], relu_floor);
         if (res != nullptr) {

@@ -185,18 +185,36 @@ GROUP_MAX = 48        # VG_GROUP_MAX of include/vaegslm_hip.h: products per vg_g
 # (accumulate = 0 of vg_gemm_grouped: 4 bytes per parameter less traffic).  Every path that writes a weight gradient
 # records its region here, so that a second contribution to the same region in the same pass (a module applied twice, a
 # product that took another route first) accumulates.
-_WPASS = {"fresh": False, "written": set()}
+_WPASS = {"fresh": False, "written": set(), "auto": set(), "epoch": 0}
 _WGRAD_STORE = _flag("VG_WGRAD_STORE", "1")
 
 
 def begin_backward_pass(fresh: bool) -> None:
     _WPASS["fresh"] = bool(fresh) and _WGRAD_STORE
     _WPASS["written"] = set()
+    _WPASS["auto"] = set()
+    _WPASS["epoch"] += 1
 
 
 def end_backward_pass() -> None:
     _WPASS["fresh"] = False
     _WPASS["written"] = set()
+    _WPASS["auto"] = set()
+
+
+def write_epoch() -> int:
+    """Counts everything that may have written a gradient through this library (every backward pass opened, every
+    "gradient ready" report of the sink, every dense autograd gradient that reached a watched parameter).  Whoever
+    clears the gradient buffers remembers the value; the buffers still hold zeros only while it has not moved.  This is
+    how the trainer decides `fresh` -- from the state of the buffers, not from a batch index."""
+    return _WPASS["epoch"]
+
+
+def note_autograd_write(p) -> None:
+    """post-accumulate-grad hook of a parameter the sink may also write: a dense autograd gradient has been ADDED to
+    ``p.grad``, so a grouped launch that lands later in this pass must accumulate, not store."""
+    _WPASS["auto"].add(id(p))
+    _WPASS["epoch"] += 1
 
 
 def _wgrad_region(g: Tensor):
@@ -240,7 +258,8 @@ def _launch_wgrad_items(items) -> None:
     for d, (w, dy, x, col0) in zip(descs, items):
         g = _wgrad_grad_view(w, x, col0)
         region = _wgrad_region(g)
-        store = _WPASS["fresh"] and region not in _WPASS["written"]       # zeros underneath: whole-K tiles may store
+        # zeros underneath (nothing of this pass -- library or autograd -- has written there): whole-K tiles may store
+        store = _WPASS["fresh"] and region not in _WPASS["written"] and id(w) not in _WPASS["auto"]
         _WPASS["written"].add(region)
         d.A, d.B, d.C = ptr(dy), ptr(x), ptr(g)
         d.M, d.N, d.K = w.shape[0], x.shape[1], x.shape[0]
@@ -262,6 +281,16 @@ def _launch_wgrad_items(items) -> None:
 _WDEFER = {"on": False, "q": {}, "keys": {}, "fire": []}
 
 
+_CUS = []
+
+
+def _cu_count() -> int:
+    if not _CUS:
+        _CUS.append(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+                    if torch.cuda.is_available() else 256)
+    return _CUS[0]
+
+
 def _wgrad_enqueue(items, fire: bool, tag: str) -> None:
     q = _WDEFER["q"].setdefault(tag, [])
     keys = _WDEFER["keys"].setdefault(tag, set())
@@ -279,7 +308,11 @@ def _wgrad_enqueue(items, fire: bool, tag: str) -> None:
                 seen.add(id(w))
                 _WDEFER["fire"].append(w)
     tiles = sum(_wgrad_tiles(w, x) for w, _, x, _ in q)
-    if tiles >= 512 and tiles % 256 == 0:
+    cus = _cu_count()
+    # whole rounds (>= 2) leave at once; a queue whose tile count never lands on a round (e.g. 108 tiles per layer at
+    # d = 768) leaves at six rounds anyway, so the queued operands of every layer do not stay alive for the whole
+    # backward piece
+    if (tiles >= 2 * cus and tiles % cus == 0) or tiles >= 6 * cus:
         flush_wgrads(tag)
 
 
@@ -1129,6 +1162,7 @@ def _grad_buffer(p: Tensor) -> Tensor:
 
 def _fire(p: Tensor) -> None:
     p._vg_sunk = True            # this parameter's gradient is written by the library, not by AccumulateGrad
+    _WPASS["epoch"] += 1         # (a library write outside any trainer pass also ends "the buffers hold zeros")
     for h in getattr(p, "_vg_grad_hooks", ()):
         h(p)
 
@@ -1177,7 +1211,9 @@ class WgradStream:
 
     def wgrad(self, weight, bias, g_out: Tensor, inp: Tensor):
         """Same contract as :func:`wgrad_pair`; the weight-gradient GEMM goes to the side stream when it is sunk."""
-        if not (self.enabled and _sinkable(weight) and weight.is_contiguous()):
+        # inside a deferral bracket the product is only QUEUED: the queue owns the "gradient ready" report (it fires
+        # when the launch exists), so the side stream and its early join-time report are bypassed (ADVICE r04)
+        if not (self.enabled and _sinkable(weight) and weight.is_contiguous()) or _WDEFER["on"]:
             return wgrad_pair(weight, bias, g_out, inp)
         self.side.wait_stream(self.main)             # g_out / inp were produced on the main stream
         with torch.cuda.stream(self.side):
@@ -1230,6 +1266,10 @@ def rmsnorm_bwd_raw(dy, x, sc, rstd, dx_add, lengths, T, dx_colsum: bool = False
         check(lib().vg_rmsnorm_bwd_colsum(ptr(dy), ptr(x), ptr(sc), ptr(rstd), ptr(dx_add), ptr(dx), ptr(part), ptr(cpart), M,
                                           Cc, ptr(lengths), int(T), dtype_id(x.dtype), stream()), "vg_rmsnorm_bwd_colsum")
         dx._vg_colparts = cpart
+        # the sums describe THESE bytes: if autograd later adds a second consumer's gradient into the tensor in place
+        # (InputBuffer / AccumulateGrad keep the Python object), version or address no longer match and the consumer
+        # falls back to its own column sums
+        dx._vg_colparts_of = (dx.data_ptr(), dx._version)
         return dx, part
     check(lib().vg_rmsnorm_bwd(ptr(dy), ptr(x), ptr(sc), ptr(rstd), ptr(dx_add), ptr(dx), ptr(part), M, Cc,
                                ptr(lengths), int(T), dtype_id(x.dtype), stream()), "vg_rmsnorm_bwd")
@@ -1354,7 +1394,8 @@ class TransformerLayerFn(torch.autograd.Function):
         # b2's gradient = column sums of dy.  When dy is the dx of the rmsnorm_bwd launch of the node above (the layer
         # above's first norm, or the stack's final norm) that launch has left them (`_vg_colparts`): no pass over dy
         dy_parts = getattr(dy, "_vg_colparts", None)
-        if dy_parts is not None and (dy_parts.shape[1] != D or not _sinkable(b2)):
+        if dy_parts is not None and (dy_parts.shape[1] != D or not _sinkable(b2)
+                                     or getattr(dy, "_vg_colparts_of", None) != (dy.data_ptr(), dy._version)):
             dy_parts = None
         g_w2, g_b2 = wgrad(w2, None if dy_parts is not None else b2, dy, h)
         dn3 = gemm(du, s1, M, D, F_, b_tr=True)
@@ -1548,14 +1589,18 @@ class ConvBlockFn(torch.autograd.Function):
             else:
                 gc = wgrad_into(c2w, Hd, Cc, Kc, dpre, cond)
         if group:
-            sink_wgrad_group(group, fire=False)          # fired below, once per weight
+            # one "gradient ready" report per weight, issued by sink_wgrad_group itself: at once when it launches, from
+            # the deferral queue (after the launch exists) when it only queues -- never before the dW launch
+            sink_wgrad_group(group, fire=True)
         if _sinkable(c2w):
-            _fire(c2w)
+            if not group:
+                _fire(c2w)
             g_c2 = None
         else:
             g_c2 = (ga if gc is None else torch.cat([ga, gc], 1)).view_as(c2w)
         if _sinkable(c3w):
-            _fire(c3w)
+            if not group:
+                _fire(c3w)
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
         dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)

@@ -72,6 +72,24 @@ class LVTRTrainer(BaseTrainer):
         self.packed_rows = bool(hip.get("packed_rows", False)) if hip is not None else False
         self.packed_granule = int(hip.get("packed_rows_granule", 1024)) if hip is not None else 1024
         self._held = []
+        self._clean_epoch = None       # hipvg.functional.write_epoch() at the moment the gradients were last cleared
+        self._watched = False
+
+    def _watch_autograd_writes(self) -> None:
+        """A parameter the gradient sink writes may ALSO receive a dense autograd gradient in the same pass (a module
+        of the library and a stock op sharing a weight): the sink has to know, or a deferred grouped launch would store
+        over it.  One post-accumulate hook per fp32 parameter; it runs for the ~50 parameters autograd owns."""
+        if self._watched:
+            return
+        self._watched = True
+        from hipvg import functional as HF
+        fresh_start = all(p.grad is None or not bool(p.grad.any()) for p in self.model.parameters()) \
+            if next(self.model.parameters()).is_cuda else False
+        for p in self.model.parameters():
+            if p.requires_grad and p.dtype == torch.float32:
+                p.register_post_accumulate_grad_hook(HF.note_autograd_write)
+        if fresh_start:
+            self._clean_epoch = HF.write_epoch()
 
     # ------------------------------------------------------------ optimisation plumbing
     def configure_optimizers(self):
@@ -337,11 +355,13 @@ class LVTRTrainer(BaseTrainer):
             batch, self._held = self._concat_batches(self._held), []
         if self.reducer is not None:
             self.reducer.sync_now = last
-        # the gradient buffers hold zeros when this pass starts: one pass per optimizer step (no accumulation, or the
-        # window coalesced into this call), else the window's first micro-batch (every optimizer step ends by clearing them)
-        coalesced_pass = self.coalesce and noise is None and self.gradient_update_step > 1
-        self._wgrad_fresh = bool(coalesced_pass or self.gradient_update_step == 1 or batch_idx % self.gradient_update_step == 0)
+        # "Fresh" = the gradient buffers hold zeros when this pass starts.  Taken from their real state, not from
+        # batch_idx (per-epoch batch indices, or a backward outside training_step, would leave accumulated
+        # gradients under a grouped launch that STORES): whoever cleared them recorded the library's write epoch, and
+        # nothing has written a gradient since (hipvg.functional.write_epoch).
         from hipvg import functional as _HF
+        self._watch_autograd_writes()
+        self._wgrad_fresh = self._clean_epoch is not None and self._clean_epoch == _HF.write_epoch()
         try:
             if self.use_graph and noise is None:
                 try:
@@ -355,6 +375,7 @@ class LVTRTrainer(BaseTrainer):
                 out = self._training_loop(batch, batch_idx, noise)
         finally:
             self._wgrad_fresh = False
+            self._clean_epoch = None               # a pass ran (eagerly, captured or replayed): the buffers hold gradients
             _HF.end_backward_pass()                # a backward outside the trainer never inherits "gradients are zero"
         if last:
             clip = self.hp.training.get("gradient_clip_val", None)
@@ -376,6 +397,7 @@ class LVTRTrainer(BaseTrainer):
                 self.reducer.zero_grad()
             else:
                 self.optimizer.zero_grad(set_to_none=True)
+            self._clean_epoch = _HF.write_epoch()      # zeros underneath until the library's write epoch moves
             if self.use_graph and not getattr(self.optimizer, "clears_gradients", False):
                 from hipvg import functional as HF
                 HF.refresh_shadows(self.model.parameters())   # captured GEMMs read the bf16 copies by address
