@@ -158,6 +158,21 @@ int vg_attn_fwd_varlen(const void* qkv, void* out, float* lse, const float* slop
 int vg_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
                        void* dqkv, float* delta, int B, int Tmax, int H, const int32_t* lengths,
                        const int32_t* cu_rows, int rows, int dtype, vg_stream_t stream);
+/* The same calls with the ALiBi window of the backward pass (round 5).  `stats`: fp32 workspace of
+ * vg_attn_stats_floats(B, T, H) floats per call pair, written by the bf16 forward (per (batch, head): max |k|^2, and per
+ * 64 queries max |q|^2 and max -logsumexp; plain stores, no initialisation needed) and read by the backward, which then
+ * does not stream key / query tiles whose every probability is provably below 2^-20 of its row (the same threshold the
+ * kernels already drop products at; fp32 launches ignore it and keep every tile, as does VG_ATTN_WINDOW=0).  The
+ * reference (modules/attention/attention.py:60-77) computes the dense masked softmax; under ALiBi
+ * (modules/position/alibi.py:9-33) those entries are exactly the ones that underflow bf16.  cu_rows = NULL (and
+ * rows = 0): padded layout as vg_attn_fwd; otherwise packed rows as vg_attn_fwd_varlen.  stats = NULL: no window. */
+int vg_attn_stats_floats(int B, int T, int H);
+int vg_attn_fwd_stats(const void* qkv, void* out, float* lse, const float* slopes, int B, int T, int H,
+                      const int32_t* lengths, const int32_t* cu_rows, int rows, float* stats, int dtype,
+                      vg_stream_t stream);
+int vg_attn_bwd_stats(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
+                      void* dqkv, float* delta, int B, int T, int H, const int32_t* lengths, const int32_t* cu_rows,
+                      int rows, const float* stats, int dtype, vg_stream_t stream);
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for rows of row_bytes (a multiple of 16) bytes: packing the valid frames of a
  * padded batch, un-packing them, and each other's backward. */
 int vg_gather_rows(const void* src, const int32_t* map, void* dst, int n_dst, int row_bytes, vg_stream_t stream);

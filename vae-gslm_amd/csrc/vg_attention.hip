@@ -31,12 +31,22 @@ constexpr int TB = 64;       // time rows staged per LDS tile
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.69314718055994530942f;
 constexpr float SCALE = 0.125f;   // 1 / sqrt(64)
-// resident blocks per CU the bf16 kernels are register-budgeted for (measured: forward 3, backward 2)
+// resident blocks per CU the bf16 kernels are register-budgeted for (measured: 128-query forward 3; backward 2 until
+// round 5, 3 since: dQ 75.9 -> 71.7 us, dK/dV 93.9 -> 86.6 us at B = 16, T = 1000; 4 spills)
+#ifndef VG_ATTN_PAIR
+#define VG_ATTN_PAIR 1     // forward: a wave owns the 32-query groups w and 7 - w of its block (0: 2w and 2w + 1, lab only)
+#endif
+#ifndef VG_ATTN_TILESKIP
+#define VG_ATTN_TILESKIP 1  // backward: per-32x32-block test that drops negligible blocks inside the window (0: lab, branch-free tile body)
+#endif
+#ifndef VG_ATTN_HEADMIX
+#define VG_ATTN_HEADMIX 1   // heads x and 15 - x share an XCD (0: x and x + 8, lab)
+#endif
 #ifndef VG_ATTN_OCC_FWD
 #define VG_ATTN_OCC_FWD 3
 #endif
 #ifndef VG_ATTN_OCC
-#define VG_ATTN_OCC 2
+#define VG_ATTN_OCC 3     // round 5: with the transposed images gone from the bf16 stages three blocks fit a CU (168 VGPRs, no spill)
 #endif
 
 // Block index -> ((batch, head) pair, rank of the tile inside the pair: 0 = longest sweep).
@@ -60,6 +70,18 @@ VG_DEVICE void pair_and_rank(int bid, int ntiles, int npairs, int sched, int& hb
     hb = bid % npairs;
     rank = bid / npairs;
   }
+}
+
+// Which head a block of pair slot `hb` works on.  Blocks are dealt round-robin over the 8 XCDs (blocks i and i + 8 share
+// one) and H * B is a multiple of 8, so with h = hb % H an XCD would work on heads x and x + 8 of every 16 only -- and
+// under ALiBi the cost of a head grows with its index (the steep heads' far tiles are dropped / outside the window):
+// XCD 7 (heads 7, 15) carried half as much again as XCD 0 (heads 0, 8) and the launch ended on it.  Slots 8..15 of
+// every 16 take the heads in descending order, so that an XCD gets heads x and 15 - x (round 5).
+VG_DEVICE int head_of_slot(int hb, int H) {
+  const int j = hb % H;
+  if ((H & 15) != 0 || !VG_ATTN_HEADMIX) return j;
+  const int j16 = j & 15;
+  return (j & ~15) | (j16 < 8 ? j16 : 23 - j16);
 }
 
 template <typename T> struct NVec { static constexpr int v = TB * DH / Traits<T>::VEC / 256; };  // 2 bf16 / 4 f32
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
   const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt;
   int hb, rank;
   pair_and_rank(blockIdx.x, nqt, HB, sched, hb, rank);
-  const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
+  const int qt = nqt - 1 - rank, h = head_of_slot(hb, H), b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
@@ -403,16 +425,45 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
 //   * O leaves through LDS as whole 128-byte rows (16-byte stores) instead of 8-byte pieces at a row stride.
 // Two blocks (8 waves) per CU: <= 256 VGPRs.
 // =====================================================================================
-constexpr int QW2 = 64;             // queries per wave
+constexpr int QW2 = 64;             // queries per wave (two 32-query groups)
 constexpr int QB2 = 4 * QW2;        // queries per block
 constexpr int STAGE2 = 2 * TB * 128;   // K row image + V transposed-read image of one 64-key tile
 constexpr int NSTAGE2 = 3;
 
-template <bool DESC>
+// ---- per-(batch, head) statistics the bf16 forward leaves for the backward's ALiBi window (round 5).
+// stats: fp32 [B*H][attn_stats_floats(Tn)]: [0] = max |k_j|^2 over the sequence's keys, written by the one wave that sees
+// every K tile of the pair; [1 + 4 qt + w] = max |q_i|^2 and [1 + 4 nqt + 4 qt + w] = max -L_i (L_i: the row's
+// log-sum-exp in the log2 domain) over the valid queries of wave w of 256-query block qt.  Plain stores, one writer per
+// entry: no initialisation, no atomics, bitwise repeatable.  With p_ij = 2^(s_ij - L_i) and
+// s_ij <= c2 |q_i| |k_j| - slope2 (i - j), every probability further than
+//     W = (c2 max|q| max|k| + max(-L) + thr) / slope2
+// from the diagonal is below 2^-thr: the backward kernels do not even STREAM those tiles (the per-tile test they had
+// dropped the products but still paid DMA + barrier + the S product of every tile; at T = 1000 the steep half of the
+// 16 ALiBi heads needs 1-4 of its up to 16 tiles).
+VG_DEVICE int attn_stats_floats(int Tn) { return 4 + 8 * ((Tn + QB2 - 1) / QB2); }      // [0] max |k|^2, [1..3] pad (the arrays stay 16-byte aligned)
+// The window in frames from the statistics of a pair.  Every address is wave-uniform and the buffer is read-only in the
+// backward kernels, so these are SCALAR loads (s_load_dwordx4) and a few v_max on uniform values: the first version --
+// one entry per lane, two DPP wave maxima -- cost 1.4 us per block, which at four rounds of blocks per launch ate what the
+// window saved on the steep heads.  q-side entries [e0, e0 + n) of both arrays, n a multiple of 4.
+VG_DEVICE float attn_window(const float* __restrict__ st, int nqt, int e0, int n, float slope2, float c2, float thr) {
+  float q2 = 0.f, nl = -INFINITY;
+  const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(st + 4 + e0);
+  const f32x4* __restrict__ n4 = reinterpret_cast<const f32x4*>(st + 4 + 4 * nqt + e0);
+  for (int i = 0; i < n / 4; ++i) {
+    const f32x4 a = q4[i], c = n4[i];
+    q2 = fmaxf(fmaxf(q2, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+    nl = fmaxf(fmaxf(nl, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
+  }
+  const float bound = c2 * sqrtf(q2 * st[0]) * 1.01f + nl + thr;          // log2 units; 1 % for the rounding of the norms
+  const float w = bound * __builtin_amdgcn_rcpf(slope2) * 1.0001f;        // (approximate reciprocal: rounded up)
+  return w >= 0.f ? w : (w < 0.f ? 0.f : INFINITY);                       // NaN (inf - inf, 0 * inf) -> no window
+}
+
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, const float* __restrict__ slopes,
                                                            int Tn, int H, const int* __restrict__ lengths, float skip_thr,
-                                                           int sched, const int* __restrict__ cu, int Mtot) {
+                                                           int sched, const int* __restrict__ cu, int Mtot,
+                                                           float* __restrict__ stats) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,32 +471,48 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   const int nqt = (Tn + QB2 - 1) / QB2, HB = gridDim.x / nqt;
   int hb, rank;
   pair_and_rank(blockIdx.x, nqt, HB, sched, hb, rank);
-  const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
+  const int qt = nqt - 1 - rank, h = head_of_slot(hb, H), b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
   const int Tr = cu ? cu[b + 1] - soff : Tn;            // rows the sequence owns (packed layout: its own length)
   const int len = lengths ? min(lengths[b], Tr) : Tr;
   const int q0 = qt * QB2;
-  const int qw0 = q0 + wave * QW2;
+  // Causal balance (round 5): a wave owns the 32-query groups w and 7 - w of the block's eight, not two neighbours.  Of
+  // the block's four diagonal tiles group g needs g / 2 + 1, so every wave computes 5 of the 8 (group, tile) pairs there
+  // (neighbouring groups: 2, 4, 6 and 8 of them -- the block ran at the pace of its last wave: 15 % of the wave-time).
+#if VG_ATTN_PAIR
+  const int qg0[2] = {q0 + 32 * wave, q0 + 32 * (7 - wave)};          // first query of the wave's two groups
+#else
+  const int qg0[2] = {q0 + 64 * wave, q0 + 64 * wave + 32};           // (lab build: neighbouring groups, the round-4 map)
+#endif
   const T* __restrict__ base = qkv + (long)soff * rs + h * DH;
   T* __restrict__ obase = out + (long)soff * D + h * DH;
+  float* __restrict__ st_pair = stats ? stats + (long)(b * H + h) * attn_stats_floats(Tn) : nullptr;
 
   if (q0 >= len) {   // fully padded tile: zero rows (attention.py:80 re-mask)
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int row = qw0 + it * 8 + (lane >> 3);
+      const int r64 = it * 8 + (lane >> 3);
+      const int row = qg0[r64 >> 5] + (r64 & 31);
       if (row < Tr) *reinterpret_cast<uint4*>(obase + (long)row * D + (lane & 7) * 8) = make_uint4(0, 0, 0, 0);
+    }
+    if (st_pair && lane == 0) {
+      st_pair[4 + 4 * qt + wave] = 0.f;
+      st_pair[4 + 4 * nqt + 4 * qt + wave] = -INFINITY;
     }
     return;
   }
   const int qend = min(q0 + QB2, len);
   const int nkt = (qend + TB - 1) / TB;
+  // a group's diagonal tile = the first it computes (a group of padding past the sequence's end starts with the block:
+  // its rows are computed like the others and zeroed at the end)
+  const int kd[2] = {min((qg0[0] + 31) / TB, nkt - 1), min((qg0[1] + 31) / TB, nkt - 1)};
 
   // Q fragments, pre-scaled by log2(e) / sqrt(d): the S products come out in the log2 domain
   RowRegs<T> qf[2];
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs) qf[qs].load(base + (long)min(qw0 + qs * 32 + (lane & 31), Tr - 1) * rs, lane);
+  for (int qs = 0; qs < 2; ++qs) qf[qs].load(base + (long)min(qg0[qs] + (lane & 31), Tr - 1) * rs, lane);
   const float slope = slopes[h];
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   f32x16 o[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
@@ -470,9 +537,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
     kext[0] = (bf16_t)1.0f; kext[1] = (bf16_t)1.0f; kext[2] = rhi; kext[3] = rlo;
   }
   const bool lowhalf = lane < 32;
+  const bool vq[2] = {qg0[0] + (lane & 31) < len, qg0[1] + (lane & 31) < len};     // this lane's two queries are real rows
 
-  // ---- addressing, hoisted: inside the loop every LDS read is a loop-invariant per-lane base + an immediate (the
-  // stage of a tile is a compile-time constant: the loop body is instantiated once per ring stage) and every DMA
+  // ---- addressing, hoisted: every LDS read is a loop-invariant per-lane base + the stage offset and every DMA
   // request is a loop-invariant per-lane source offset + the tile's byte offset.  Left to the per-tile helpers this
   // was ~70 address instructions per tile in a loop that is bound by VALU issue.
   int kbase[4];             // K fragment (kb, k-step s): stage + kb * 4096 + kbase[s]               (RowTile::frag)
@@ -505,39 +572,63 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
     }
   };
   // Key tiles are swept from the block's last tile DOWN to tile 0: under ALiBi the nearest keys carry the largest
-  // bias, so the first tile a wave computes (its diagonal tile) fixes the reference and later tiles almost never
-  // raise it, and a tile all of whose scores lie more than `skip_thr` below the reference of every query of the wave
-  // (every probability < 2^-skip_thr of a row sum that is >= 1) is dropped after its S products: no exp2, no PV.
-  // Tile kt sits in ring stage (nkt - 1 - kt) % 3.  DESC = false sweeps upward instead (tile kt in stage kt % 3, the
-  // reference is raised as the bias grows, nothing can be skipped): the blocks of a pair then start on the same tile.
-  issue(DESC ? nkt - 1 : 0, 0);
-  if (nkt > 1) issue(DESC ? nkt - 2 : 1, 1);
+  // bias, so the first tile a group computes (its diagonal tile) fixes the reference and later tiles almost never
+  // raise it, and a tile all of whose scores lie more than `skip_thr` below the reference of every query of a group
+  // (every probability < 2^-skip_thr of a row sum that is >= 1) is dropped for that group after its S products: no
+  // exp2, no PV.  Tile kt sits in ring stage (nkt - 1 - kt) % 3.
+  const int t0 = q0 / TB;                       // ring slot of tile kt: (t0 - kt) mod 3 -- the block's first diagonal tile in slot 0
+  auto slot_of = [&](int kt) { return (t0 + 3 - kt) % 3; };
+  issue(nkt - 1, slot_of(nkt - 1));
+  if (nkt > 1) issue(nkt - 2, slot_of(nkt - 2));
   // The Q fragments are ordinary loads the compiler counts: left alone, it waits for them at their first use INSIDE
   // the loop with vmcnt(8..1), which on every later iteration drains the (uncounted) DMA ring.  Retire them here.
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0].f[0]), "+v"(qf[0].f[1]), "+v"(qf[0].f[2]), "+v"(qf[0].f[3]),
                "+v"(qf[1].f[0]), "+v"(qf[1].f[1]), "+v"(qf[1].f[2]), "+v"(qf[1].f[3]) :: "memory");
+  // statistics for the backward's window: max |q|^2 over this wave's valid queries (before the pre-scaling)
+  float qmax2 = 0.f;
+  if (st_pair) {
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      float part = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const bf16x2 v = {qf[qs].f[st][j], qf[qs].f[st][j + 1]};
+          part = __builtin_amdgcn_fdot2_f32_bf16(v, v, part, false);
+        }
+      const float whole = xhalf_sum(part);
+      qmax2 = fmaxf(qmax2, qg0[qs] + (lane & 31) < len ? whole : 0.f);
+    }
+  }
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[qs].f[st][j] = (bf16_t)((float)qf[qs].f[st][j] * c2);
+  // the wave that holds the sequence's last valid query computes every K tile of the pair: it takes max |k|^2 along
+  const int g_last = (len - 1 - q0) >> 5;
+#if VG_ATTN_PAIR
+  const bool kstat = st_pair != nullptr && len - 1 < q0 + QB2 && wave == (g_last < 4 ? g_last : 7 - g_last);
+#else
+  const bool kstat = st_pair != nullptr && len - 1 < q0 + QB2 && wave == (g_last >> 1);
+#endif
+  float kmax2 = 0.f;
 
-  const int kt_diag = qw0 / TB;            // the wave's first computed tile (qw0 is a multiple of 64)
-  auto tile = [&](auto jc, const int kt) {
-    constexpr int J = decltype(jc)::value;
+  // One tile of the sweep: MASK = which of the wave's two groups take part (3: both; 2: the upper group alone, between
+  // the two diagonals), J = ring slot -- a compile-time constant in the hot loop, which is unrolled over the ring so that
+  // every LDS address of a body is a per-lane base + an immediate; a register in the few tiles of the upper group alone.
+  // (Both kinds of body inside ONE loop cost 60 spilled registers, reloaded in the middle of the tile behind counted
+  // waits that drain the DMA ring: they live in loops of their own.)
+  auto body = [&](auto mc, auto jc, const int kt) __attribute__((always_inline)) {
+    constexpr int MASK = decltype(mc)::value;
+    const int J = jc;
     const int kv0 = kt * TB;
-    // tile kt has landed (this wave's four pieces; the barrier adds everyone else's) while the next one stays in flight
-    if (DESC ? kt > 0 : kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(VG_LAB_ATTN & 4)) __builtin_amdgcn_s_barrier();
-    // the tile after next, into the stage of the previous tile, which every wave has finished reading
-    if (!(VG_LAB_ATTN & 8) && (DESC ? kt >= 2 : kt + 2 < nkt)) issue(DESC ? kt - 2 : kt + 2, (J + 2) % NSTAGE2);
-    if (kv0 > qw0) return;                 // all of this wave's queries precede the tile (causal)
     if (VG_LAB_ATTN & 64) return;
-    const bool first = DESC ? kt == kt_diag : kt == 0;
     const char* k_row = smem + J * STAGE2;
     const char* v_tr = k_row + TB * 128;
+    constexpr int Q0 = MASK == 3 ? 0 : 1;         // first group of the loops below
 
     bf16x8 kf[2][4];
 #pragma unroll
@@ -546,8 +637,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
       for (int st = 0; st < 4; ++st) kf[kb][st] = *reinterpret_cast<const bf16x8*>(k_row + kb * 4096 + kbase[st]);
     f32x16 s[2][2];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      const float cb = slope2 * (float)(kv0 - qw0 - qs * 32) - r[qs];
+    for (int qs = Q0; qs < 2; ++qs) {
+      const float cb = slope2 * (float)(kv0 - qg0[qs]) - r[qs];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const float cst = cb + (float)(kb * 32) * slope2;
@@ -570,22 +661,41 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
         s[qs][kb] = a;
       }
     }
-    if (kv0 == qw0) {                      // diagonal tile: mask key > query (tile start == wave's first query)
+    if (kstat) {
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs)
+      for (int kb = 0; kb < 2; ++kb) {
+        float part = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const int lim = qs * 32 + (lane & 31) - kb * 32;
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) s[qs][kb][i] = acc_row(i, lane) <= lim ? s[qs][kb][i] : -INFINITY;
-        }
+          for (int j = 0; j < 8; j += 2) {
+            const bf16x2 v = {kf[kb][st][j], kf[kb][st][j + 1]};
+            part = __builtin_amdgcn_fdot2_f32_bf16(v, v, part, false);
+          }
+        kmax2 = fmaxf(kmax2, xhalf_sum(part));
+      }
+    }
+    // a group's diagonal tile (the first it computes): mask key > query.  Only the first group of the body can be on
+    // its diagonal: the upper group's lies above the lower group's
+    const bool first = kt == kd[Q0];
+    if (first) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        // acc_row(i, lane) <= query - key block start, with the lane's part of acc_row moved to the right-hand side
+        // (one per-lane value compared against 16 immediates, not 16 hoisted per-lane values)
+        const int lim = qg0[Q0] + (lane & 31) - kv0 - kb * 32 - 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[Q0][kb][i] = ((i & 3) + 8 * (i >> 2)) <= lim ? s[Q0][kb][i] : -INFINITY;
+      }
     }
     // tile maxima relative to the references
-    float mx[2];
+    float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs)
+    for (int qs = Q0; qs < 2; ++qs)
       mx[qs] = (VG_LAB_ATTN & 32) ? s[qs][0][0] : xhalf_max(fmaxf(max16(s[qs][0]), max16(s[qs][1])));
-    if (DESC && !first && !__any(fmaxf(mx[0], mx[1]) > -skip_thr)) return;      // negligible for all 64 queries
+    // negligible for every VALID query of the wave (padding rows hold other bytes in the packed layout than in the padded
+    // one: left in, they made the decision -- hence the valid rows' last bits -- depend on the layout)
+    if (!first && !__any((vq[0] && mx[0] > -skip_thr) || (vq[1] && mx[1] > -skip_thr))) return;
     bf16x8 vf[2][2][2];      // [kb][k-step of 16 keys][d block]
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -599,12 +709,13 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
           vf[kb][st][db] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = Q0; qs < 2; ++qs) {
+      const bool fst = kt == kd[qs];          // (two groups of padding past the sequence's end share a first tile)
       // the first tile sets the reference, later ones raise it rarely
-      if (first || __any(mx[qs] > RESCALE_THR)) {
-        const float delta = (first || mx[qs] > RESCALE_THR) ? mx[qs] : 0.f;
+      if (fst || __any(mx[qs] > RESCALE_THR)) {
+        const float delta = (fst || mx[qs] > RESCALE_THR) ? mx[qs] : 0.f;
         // first tile: O and the row sum are still zero and the maximum may be far below zero (2^-delta overflows)
-        const float sc = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        const float sc = fst ? 1.0f : __builtin_amdgcn_exp2f(-delta);
         r[qs] += delta;
         lp[qs] *= sc;
 #pragma unroll
@@ -642,33 +753,50 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
         }
     }
   };
-  if constexpr (DESC) {
-    for (int kt = nkt - 1;;) {
-      tile(std::integral_constant<int, 0>{}, kt);
+  // tile kt has landed (this wave's four pieces; the barrier adds everyone else's) while the next one stays in flight;
+  // then the tile after next is requested into the stage of the previous tile, which every wave has finished reading
+  // tile kt has landed (this wave's four pieces; the barrier adds everyone else's) while the next one stays in flight;
+  // then the tile after next is requested into the slot of the previous tile, which every wave has finished reading
+  auto arrive = [&](const int J, const int kt) __attribute__((always_inline)) {
+    if (kt > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(VG_LAB_ATTN & 4)) __builtin_amdgcn_s_barrier();
+    if (!(VG_LAB_ATTN & 8) && kt >= 2) issue(kt - 2, J >= 1 ? J - 1 : 2);
+  };
+  // (1) above the lower group's diagonal: nothing, or the upper group alone; (2) the hot loop over both groups starts
+  // in slot 0 (waves 0, 1: the block's first diagonal tile) or slot 2 (waves 2, 3: one tile higher; a peeled copy)
+  int kt = nkt - 1;
+  for (int Jr = slot_of(kt); kt > kd[0]; --kt, Jr = Jr == 2 ? 0 : Jr + 1) {
+    arrive(Jr, kt);
+    if (kt <= kd[1]) body(std::integral_constant<int, 2>{}, Jr, kt);
+  }
+  if (slot_of(kt) == 2) {
+    arrive(2, kt);
+    body(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, kt);
+    --kt;
+  }
+  if (kt >= 0) {
+    for (;;) {
+      arrive(0, kt);
+      body(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, kt);
       if (--kt < 0) break;
-      tile(std::integral_constant<int, 1>{}, kt);
+      arrive(1, kt);
+      body(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, kt);
       if (--kt < 0) break;
-      tile(std::integral_constant<int, 2>{}, kt);
+      arrive(2, kt);
+      body(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, kt);
       if (--kt < 0) break;
-    }
-  } else {
-    for (int kt = 0;;) {
-      tile(std::integral_constant<int, 0>{}, kt);
-      if (++kt >= nkt) break;
-      tile(std::integral_constant<int, 1>{}, kt);
-      if (++kt >= nkt) break;
-      tile(std::integral_constant<int, 2>{}, kt);
-      if (++kt >= nkt) break;
     }
   }
 
   // ---- epilogue: O^T -> rows through LDS.  The last tile (tile 0) sits in stage (nkt - 1) % 3; the other two stages
   // hold no tile any wave still reads and nothing is in flight: 2 x 16 KB = 8 KB per wave.
-  char* ow = smem + ((nkt + (wave >> 1)) % NSTAGE2) * STAGE2 + (wave & 1) * 8192;
+  char* ow = smem + ((t0 + 1 + (wave >> 1)) % NSTAGE2) * STAGE2 + (wave & 1) * 8192;
+  float nlmax = -INFINITY;
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
     const float l = xhalf_sum(lp[qs]);
-    const int query = qw0 + qs * 32 + (lane & 31);
+    const int query = qg0[qs] + (lane & 31);
     const float mul = query < len ? 1.f / l : 0.f;
     const int row = qs * 32 + (lane & 31);
 #pragma unroll
@@ -676,12 +804,27 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = db * 32 + 8 * g + 4 * (lane >> 5);
-        const bf16x4 v = {(bf16_t)(o[qs][db][4 * g] * mul), (bf16_t)(o[qs][db][4 * g + 1] * mul),
-                          (bf16_t)(o[qs][db][4 * g + 2] * mul), (bf16_t)(o[qs][db][4 * g + 3] * mul)};
+        bf16x4 v = {(bf16_t)(o[qs][db][4 * g] * mul), (bf16_t)(o[qs][db][4 * g + 1] * mul),
+                    (bf16_t)(o[qs][db][4 * g + 2] * mul), (bf16_t)(o[qs][db][4 * g + 3] * mul)};
+        if (query >= len) v = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};   // (a padded row may hold inf * 0)
         *reinterpret_cast<bf16x4*>(ow + row * 128 + ((((d0 >> 3) ^ (row & 7))) << 4) + (d0 & 7) * 2) = v;
       }
-    if (query < len && lane < 32)
-      lse[(long)h * Mtot + soff + query] = (r[qs] + log2f(l) - slope2 * (float)(lane & 31)) * LN2;
+    const float L2 = r[qs] + log2f(l) - slope2 * (float)(lane & 31);        // log-sum-exp of the row, log2 domain
+    if (query < len) {
+      if (lane < 32) lse[(long)h * Mtot + soff + query] = L2 * LN2;
+      nlmax = fmaxf(nlmax, -L2);
+    }
+  }
+  if (st_pair) {
+    const float qm = wave_max(qmax2), nl = wave_max(nlmax);
+    if (lane == 0) {
+      st_pair[4 + 4 * qt + wave] = qm;
+      st_pair[4 + 4 * nqt + 4 * qt + wave] = nl;
+    }
+    if (kstat) {
+      const float km = wave_max(kmax2);
+      if (lane == 0) st_pair[0] = km;
+    }
   }
   // the rows of a wave are written and read by that wave only: no block barrier (LDS accesses of one wave stay in order)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -689,7 +832,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   for (int it = 0; it < 8; ++it) {
     const int row = it * 8 + (lane >> 3), c16 = lane & 7;
     const uint4 v = *reinterpret_cast<const uint4*>(ow + row * 128 + ((c16 ^ (row & 7)) << 4));
-    if (qw0 + row < Tr) *reinterpret_cast<uint4*>(obase + (long)(qw0 + row) * D + c16 * 8) = v;
+    const int query = qg0[row >> 5] + (row & 31);
+    if (query < Tr) *reinterpret_cast<uint4*>(obase + (long)query * D + c16 * 8) = v;
   }
 }
 
@@ -727,7 +871,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
                                                           float* __restrict__ delta, const T* __restrict__ out_o,
                                                           const float* __restrict__ slopes, T* __restrict__ dqkv,
                                                           int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched,
-                                                          const int* __restrict__ cu, int Mtot) {
+                                                          const int* __restrict__ cu, int Mtot, const float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_row = smem;
   char* v_row = smem + LdsPlan<T>::ROW_BYTES;
@@ -738,7 +882,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt;
   int hb, rank;
   pair_and_rank(blockIdx.x, nqt, HB, sched, hb, rank);
-  const int qt = nqt - 1 - rank, h = hb % H, b = hb / H;
+  const int qt = nqt - 1 - rank, h = head_of_slot(hb, H), b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
@@ -757,20 +901,48 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const int nkt = (qend + TB - 1) / TB;
   const bool qvalid = query < len;
   const int qc = min(query, Tr - 1);
-  RowRegs<T> qf, dof;
+  constexpr bool DMA = sizeof(T) == 2;
+  constexpr int STAGE = 2 * LdsPlan<T>::ROW_BYTES + (DMA ? 0 : LdsPlan<T>::TR_BYTES);   // bf16: K^T fragments come out of the K row image
+  uint4 rk[DMA ? 1 : NVec<T>::v], rv[DMA ? 1 : NVec<T>::v];
+  __amdgpu_buffer_rsrc_t rsk, rsv;
+  auto issue = [&](int t0, char* st) {
+    slab_dma<false>(rsk, st, rs, t0, wave, lane);
+    slab_dma<false>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);      // (K^T fragments come out of the K row image)
+  };
+  // Round 5: key tiles are swept from the block's diagonal DOWN, and the first tile is requested before anything else is
+  // loaded: the row fragments, the statistics of the window and the first K / V tile share ONE memory round trip per
+  // block (they were three in a row: delta's operands, then the window's statistics, then the first tile).
+  if constexpr (DMA) {
+    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tr);
+    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tr);
+    issue((nkt - 1) * TB, smem + ((nkt - 1) & 1) * STAGE);
+  } else {
+    slab_load<T>(rk, base + D, rs, (nkt - 1) * TB, Tr, tid);
+    slab_load<T>(rv, base + 2 * D, rs, (nkt - 1) * TB, Tr, tid);
+  }
+  // every load of the prologue is requested before the first value is used (one round trip: the lse value used to be
+  // waited for -- with everything in front of it -- before the O rows were even requested)
+  RowRegs<T> qf, dof, of;
   qf.load(base + (long)qc * rs, lane);
   dof.load(dout + ((long)soff + qc) * D + h * DH, lane);
+  of.load(out_o + ((long)soff + qc) * D + h * DH, lane);
+  const float lse_raw = lse[(long)h * Mtot + soff + qc];
+  // ALiBi window (round 5, see attn_stats_floats): keys further than W frames below the block's first query carry
+  // probabilities < 2^-skip_thr for every query of the block -- their tiles are not streamed at all
   const float slope = slopes[h];
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
-  // +inf for padded queries -> p = exp2(-inf) = 0 without a compare
-  const float Lq = qvalid ? lse[(long)h * Mtot + soff + query] * LOG2E + slope2 * (float)(query - qw0) : INFINITY;
+  int kt_lo = 0;
+  if (DMA && stats != nullptr && skip_thr < INFINITY) {
+    const int nqt2 = (Tn + QB2 - 1) / QB2;
+    const float W = attn_window(stats + (long)(b * H + h) * attn_stats_floats(Tn), nqt2, 4 * (q0 / QB2), 4, slope2, c2, skip_thr);
+    const float lo = (float)q0 - W;
+    if (lo > 0.f) kt_lo = min((int)(lo * (1.0f / TB)), q0 / TB);
+  }
   // delta = rowsum(dO * O) of this wave's 32 queries, from the dO row fragments it holds anyway and the matching O row
   // fragments (round 4: the stand-alone delta kernel -- a 15 us launch per layer that re-read O and dO -- is gone);
   // written out for the dK/dV pass, which runs after this launch.  Lanes l and l + 32 hold the two halves of a row.
   float dl;
   {
-    RowRegs<T> of;
-    of.load(out_o + ((long)soff + qc) * D + h * DH, lane);
     float part = 0.f;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -785,6 +957,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     dl = qvalid ? whole : 0.f;
     if (query < Tr && lane < 32) delta[(long)h * Mtot + soff + query] = dl;
   }
+  // +inf for padded queries -> p = exp2(-inf) = 0 without a compare
+  const float Lq = qvalid ? lse_raw * LOG2E + slope2 * (float)(query - qw0) : INFINITY;
   f32x16 kinit, dinit;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -793,27 +967,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   }
 
   f32x16 dq[2] = {zero16(), zero16()};
-  constexpr bool DMA = sizeof(T) == 2;
-  constexpr int STAGE = 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
-  uint4 rk[DMA ? 1 : NVec<T>::v], rv[DMA ? 1 : NVec<T>::v];
-  __amdgpu_buffer_rsrc_t rsk, rsv;
-  auto issue = [&](int t0, char* st) {
-    slab_dma<false>(rsk, st, rs, t0, wave, lane);
-    slab_dma<false>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);      // (K^T fragments come out of the K row image)
-  };
-  if constexpr (DMA) {
-    rsk = slab_rsrc(reinterpret_cast<const bf16_t*>(base + D), rs, Tr);
-    rsv = slab_rsrc(reinterpret_cast<const bf16_t*>(base + 2 * D), rs, Tr);
-    issue(0, smem);
-  } else {
-    slab_load<T>(rk, base + D, rs, 0, Tr, tid);
-    slab_load<T>(rv, base + 2 * D, rs, 0, Tr, tid);
-  }
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = nkt - 1; kt >= kt_lo; --kt) {
     const int kv0 = kt * TB;
     if constexpr (DMA) {
       dma_wait_and_publish();
-      if (!(VG_LAB_ATTN & 512) && kt + 1 < nkt) issue(kv0 + TB, smem + ((kt + 1) & 1) * STAGE);
+      if (!(VG_LAB_ATTN & 512) && kt > kt_lo) issue(kv0 - TB, smem + ((kt - 1) & 1) * STAGE);
       k_row = smem + (kt & 1) * STAGE;
       v_row = k_row + LdsPlan<T>::ROW_BYTES;
       k_tr = k_row + 2 * LdsPlan<T>::ROW_BYTES;
@@ -822,9 +980,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       slab_store<T, true, true>(rk, k_row, k_tr, tid);
       slab_store<T, true, false>(rv, v_row, nullptr, tid);
       __syncthreads();
-      if (kt + 1 < nkt) {
-        slab_load<T>(rk, base + D, rs, kv0 + TB, Tr, tid);
-        slab_load<T>(rv, base + 2 * D, rs, kv0 + TB, Tr, tid);
+      if (kt > kt_lo) {
+        slab_load<T>(rk, base + D, rs, kv0 - TB, Tr, tid);
+        slab_load<T>(rv, base + 2 * D, rs, kv0 - TB, Tr, tid);
       }
     }
     if (qw0 + 31 < kv0) continue;
@@ -841,7 +999,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       const float off = slope2 * (float)(kv0 + kb * 32 - qw0) - Lq;
       // every probability of this 32-key block below 2^-skip_thr (of a row that sums to 1) for all 32 queries of the
       // wave: its dS is dropped -- no dP product, no exp2, no dQ product (ALiBi: the far keys of the steep heads)
-      if (!__any(fmaf(max16(s), c2, off) > -skip_thr)) continue;
+      if (VG_ATTN_TILESKIP && !__any(fmaf(max16(s), c2, off) > -skip_thr)) continue;
       f32x16 dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, dinit);
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(fmaf(s[i], c2, off)) * dp[i];
@@ -867,7 +1025,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ slopes, T* __restrict__ dqkv,
                                                            int Tn, int H, const int* __restrict__ lengths, float skip_thr, int sched,
-                                                           const int* __restrict__ cu, int Mtot) {
+                                                           const int* __restrict__ cu, int Mtot, const float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_row = smem;
   char* do_row = smem + LdsPlan<T>::ROW_BYTES;
@@ -878,7 +1036,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const int nkb = (Tn + QB - 1) / QB, HB = gridDim.x / nkb;   // low key tiles sweep the most query tiles: first
   int hb, ktile;
   pair_and_rank(blockIdx.x, nkb, HB, sched, hb, ktile);
-  const int h = hb % H, b = hb / H;
+  const int h = head_of_slot(hb, H), b = hb / H;
   const int D = H * DH;
   const long rs = 3L * D;
   const int soff = cu ? cu[b] : b * Tn;                 // first row of the sequence in the [rows][...] tensors
@@ -898,21 +1056,15 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     return;
   }
   const int kc = min(key, Tr - 1);
-  RowRegs<T> kf, vf;
-  kf.load(base + D + (long)kc * rs, lane);
-  vf.load(base + 2 * D + (long)kc * rs, lane);
-  const float slope = slopes[h];
-  const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
-  const float kl = slope2 * (float)(key - k0);
   const float* __restrict__ lse_bh = lse + (long)h * Mtot + soff;
   const float* __restrict__ dl_bh = delta + (long)h * Mtot + soff;
-
-  // query tiles are swept from the sequence's LAST tile down to the block's diagonal: the key blocks of a (batch, head)
-  // pair then start on the same tile (see pair_and_rank)
+  // Round 5: query tiles are swept from the block's diagonal UP (they were swept down from the sequence's last tile so
+  // that the key blocks of a pair started on one tile -- L2 hits that never bounded these kernels), so that the first
+  // tile is known before the window is: it is requested first, and the K / V row fragments, the first two tiles'
+  // lse / delta and the window's statistics all share its round trip (they were three in a row).
   const int qt_beg = k0 / TB, qt_end = (len + TB - 1) / TB;
-  const int nq = qt_end - qt_beg, qt_first = qt_end - 1;
   constexpr bool DMA = sizeof(T) == 2;
-  constexpr int IMG = 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES;
+  constexpr int IMG = 2 * LdsPlan<T>::ROW_BYTES + (DMA ? 0 : 2 * LdsPlan<T>::TR_BYTES);   // bf16: Q^T / dO^T fragments come out of the row images
   constexpr int STAGE = IMG + 2 * 64 * (int)sizeof(float);     // + the per-query constants of the tile
   uint4 rq[DMA ? 1 : NVec<T>::v], rd[DMA ? 1 : NVec<T>::v];
   __amdgpu_buffer_rsrc_t rsq, rsd;
@@ -920,6 +1072,21 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     slab_dma<false>(rsq, sg, rs, t0, wave, lane);
     slab_dma<false>(rsd, sg + LdsPlan<T>::ROW_BYTES, D, t0, wave, lane);       // (Q^T / dO^T fragments come out of the row images)
   };
+  if constexpr (DMA) {
+    rsq = slab_rsrc(reinterpret_cast<const bf16_t*>(base), rs, Tr);
+    rsd = slab_rsrc(reinterpret_cast<const bf16_t*>(dobase), D, Tr);
+    issue(qt_beg * TB, smem);
+  } else {
+    slab_load<T>(rq, base, rs, qt_beg * TB, Tr, tid);
+    slab_load<T>(rd, dobase, D, qt_beg * TB, Tr, tid);
+  }
+  RowRegs<T> kf, vf;
+  kf.load(base + D + (long)kc * rs, lane);
+  vf.load(base + 2 * D + (long)kc * rs, lane);
+  const float slope = slopes[h];
+  const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
+  const float kl = slope2 * (float)(key - k0);
+
   // per-query constants of a tile: S init = -(lse2 + slope2 (q - k0)) / c2 (-inf for padded queries), dP init = -delta
   auto st_values = [&](int qs, float& a, float& d) {
     const int qq = qs + tid;
@@ -943,25 +1110,30 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     dst[64 + tid] = ok ? -d_raw : 0.f;
   };
   float st_a = 0.f, st_d = 0.f;    // wave 0: raw lse / delta of the NEXT tile, fetched one iteration ahead
+  float st_a0 = 0.f, st_d0 = 0.f;  // ... and of the first tile
+  if (DMA && tid < 64) {
+    st_raw(qt_beg * TB, st_a0, st_d0);
+    st_raw((qt_beg + 1) * TB, st_a, st_d);          // (clamped to the sequence's rows: harmless when there is no second tile)
+  }
+  // ALiBi window (round 5, see attn_stats_floats): queries further than W frames above the block's last key see its
+  // keys with probabilities < 2^-skip_thr -- their tiles are not streamed at all
+  int qt_first = qt_end - 1;         // the LAST tile of the upward sweep
+  if (DMA && stats != nullptr && skip_thr < INFINITY) {
+    const int nqt2 = (Tn + QB2 - 1) / QB2;
+    const float W = attn_window(stats + (long)(b * H + h) * attn_stats_floats(Tn), nqt2, 0, 4 * nqt2, slope2, c2, skip_thr);
+    const float hi = (float)(k0 + QB - 1) + W;
+    if (hi < (float)(qt_end * TB)) qt_first = min(qt_first, (int)(hi * (1.0f / TB)));
+  }
   if constexpr (DMA) {
-    rsq = slab_rsrc(reinterpret_cast<const bf16_t*>(base), rs, Tr);
-    rsd = slab_rsrc(reinterpret_cast<const bf16_t*>(dobase), D, Tr);
-    if (tid < 64) {
-      st_raw(qt_first * TB, st_a, st_d);
-      st_store(qt_first * TB, st_a, st_d, reinterpret_cast<float*>(smem + IMG));
-      if (nq > 1) st_raw((qt_first - 1) * TB, st_a, st_d);
-    }
-    issue(qt_first * TB, smem);
     // retire the counted prologue loads (K / V fragments, the first constants) here: left to the compiler, their
     // waits land at the first use inside the loop as vmcnt(7..0) and drain the uncounted DMA ring on every iteration
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf.f[0]), "+v"(kf.f[1]), "+v"(kf.f[2]), "+v"(kf.f[3]), "+v"(vf.f[0]),
-                 "+v"(vf.f[1]), "+v"(vf.f[2]), "+v"(vf.f[3]), "+v"(st_a), "+v"(st_d) :: "memory");
-  } else {
-    slab_load<T>(rq, base, rs, qt_first * TB, Tr, tid);
-    slab_load<T>(rd, dobase, D, qt_first * TB, Tr, tid);
+                 "+v"(vf.f[1]), "+v"(vf.f[2]), "+v"(vf.f[3]), "+v"(st_a), "+v"(st_d), "+v"(st_a0), "+v"(st_d0) :: "memory");
+    if (tid < 64) st_store(qt_beg * TB, st_a0, st_d0, reinterpret_cast<float*>(smem + IMG));
   }
+  const int nq = qt_first - qt_beg + 1;
   for (int it = 0; it < nq; ++it) {
-    const int qt = qt_first - it;
+    const int qt = qt_beg + it;
     const int qs0 = qt * TB;
     if constexpr (DMA) {
       dma_wait_and_publish();
@@ -969,14 +1141,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       if (it + 1 < nq) {
         char* nx = smem + (sl ^ 1) * STAGE;
         if (tid < 64)                // registers were filled one iteration ago: no wait behind the DMA below
-          st_store(qs0 - TB, st_a, st_d, reinterpret_cast<float*>(nx + IMG));
-        if (!(VG_LAB_ATTN & 512)) issue(qs0 - TB, nx);
-        if (tid < 64 && it + 2 < nq) st_raw(qs0 - 2 * TB, st_a, st_d);
+          st_store(qs0 + TB, st_a, st_d, reinterpret_cast<float*>(nx + IMG));
+        if (!(VG_LAB_ATTN & 512)) issue(qs0 + TB, nx);
+        if (tid < 64 && it + 2 < nq) st_raw(qs0 + 2 * TB, st_a, st_d);
       }
       q_row = smem + sl * STAGE;
       do_row = q_row + LdsPlan<T>::ROW_BYTES;
-      q_tr = q_row + 2 * LdsPlan<T>::ROW_BYTES;
-      do_tr = q_tr + LdsPlan<T>::TR_BYTES;
       st = reinterpret_cast<float*>(q_row + IMG);
     } else {
       __syncthreads();
@@ -985,8 +1155,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       if (tid < 64) st_values(qs0, st[tid], st[64 + tid]);
       __syncthreads();
       if (it + 1 < nq) {
-        slab_load<T>(rq, base, rs, qs0 - TB, Tr, tid);
-        slab_load<T>(rd, dobase, D, qs0 - TB, Tr, tid);
+        slab_load<T>(rq, base, rs, qs0 + TB, Tr, tid);
+        slab_load<T>(rd, dobase, D, qs0 + TB, Tr, tid);
       }
     }
 #pragma unroll
@@ -1001,7 +1171,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
         for (int i = 0; i < 16; ++i) s[i] = acc_row(i, lane) >= lim ? s[i] : -INFINITY;
       }
       // all 32 x 32 probabilities of this block below 2^-skip_thr: no dP product, no exp2, no dV / dK products
-      if (!__any(fmaf(max16(s), c2, kl) > -skip_thr)) continue;
+      if (VG_ATTN_TILESKIP && !__any(fmaf(max16(s), c2, kl) > -skip_thr)) continue;
       f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, rows16(st + 64, qb * 32, lane));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1101,25 +1271,26 @@ static float attn_skip_thr() {
 
 // `cu` (packed rows, vg_attn_*_varlen): cu[b] = first row of sequence b in the [rows][...] tensors, cu[B] = their total;
 // Mtot = rows of those tensors (= B * Tn in the padded layout); lse / delta are [H][Mtot].
+// host-side mirror of attn_stats_floats (the public vg_attn_stats_floats)
+static int stats_floats_host(int Tn) { return 4 + 8 * ((Tn + QB2 - 1) / QB2); }
+
 template <typename T>
 int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tn, int H,
-               const int32_t* lengths, const int32_t* cu, int Mtot, hipStream_t stream) {
+               const int32_t* lengths, const int32_t* cu, int Mtot, float* stats, hipStream_t stream) {
   // algorithmic work: causal-exact QK^T + PV, 2*2*64 FLOP per (query, key <= query) pair
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_FWD, 256.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
   const int sched = attn_env("VG_ATTN_SCHED", 0);
   if constexpr (sizeof(T) == 2) {
     if (!attn_v1(Tn, (long)B * H)) {
       dim3 grid2(((Tn + QB2 - 1) / QB2) * H * B);
-      if (attn_env("VG_ATTN_FWD_DESC", 1))
-        hipLaunchKernelGGL(attn2_fwd_kernel<true>, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
-                           lse, slopes, Tn, H, lengths, attn_skip_thr(), sched, cu, Mtot);
-      else
-        hipLaunchKernelGGL(attn2_fwd_kernel<false>, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
-                           lse, slopes, Tn, H, lengths, attn_skip_thr(), sched, cu, Mtot);
+      hipLaunchKernelGGL(attn2_fwd_kernel, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
+                         lse, slopes, Tn, H, lengths, attn_skip_thr(), sched, cu, Mtot, stats);
       vg_host::prof_end(tok, stream);
       return vg_host::check_launch("vg_attn_fwd");
     }
   }
+  // the 128-query kernels leave no statistics: every entry "huge" (0x7f7f7f7f = 3.4e38) = no window in the backward
+  if (stats != nullptr) (void)hipMemsetAsync(stats, 0x7f, sizeof(float) * (size_t)B * H * stats_floats_host(Tn), stream);
   const size_t lds = (sizeof(T) == 2 ? 2 : 1) * (LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
@@ -1131,19 +1302,20 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
 template <typename T>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* slopes,
                void* dqkv, float* delta, int B, int Tn, int H, const int32_t* lengths, const int32_t* cu, int Mtot,
-               hipStream_t stream) {
-  const long nthreads = (long)Mtot * H * 8;
+               const float* stats, hipStream_t stream) {
   // algorithmic work of the backward: 2 x forward (training = 3 x forward, no credit for the scores the
   // backward recomputes; the kernels execute 5 products -- S, dP, dV, dK, dQ -- i.e. 2.5 x)
   const int tok = vg_host::prof_begin(VG_PROF_ATTN_BWD, 512.0 * B * H * (0.5 * Tn * (Tn + 1.0)), stream);
-  (void)nthreads;      // (the stand-alone attn_delta_kernel is no longer launched: the dQ pass computes and stores delta)
+  // (the stand-alone attn_delta_kernel is no longer launched: the dQ pass computes and stores delta)
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   const int sched = attn_env("VG_ATTN_SCHED", 0);
-  const size_t lds_q = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
+  if (attn_env("VG_ATTN_WINDOW", 1) == 0) stats = nullptr;      // A/B switch: the round-4 sweep over every tile
+  const size_t lds_q = sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES) : 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
   const float skip = sizeof(T) == 2 ? attn_skip_thr() : INFINITY;     // the fp32 parity path keeps every tile
   hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
-                     delta, (const T*)out, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot);
-  const size_t lds_k = (sizeof(T) == 2 ? 2 : 1) * (2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float));
+                     delta, (const T*)out, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot, stats);
+  const size_t lds_k = sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES + 2 * 64 * sizeof(float))
+                                      : 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float);
   static bool attr[2] = {false, false};
   if (!attr[sizeof(T) == 2]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>),
@@ -1151,52 +1323,63 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     attr[sizeof(T) == 2] = true;
   }
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, dim3(256), lds_k, stream, (const T*)qkv, (const T*)dout, lse,
-                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot);
+                     delta, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot, stats);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_bwd");
 }
 
 }  // namespace
 
-extern "C" int vg_attn_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int T, int H,
-                           const int32_t* lengths, int dtype, hipStream_t stream) {
+extern "C" int vg_attn_stats_floats(int B, int T, int H) { return B * H * stats_floats_host(T); }
+
+extern "C" int vg_attn_fwd_stats(const void* qkv, void* out, float* lse, const float* slopes, int B, int T, int H,
+                                 const int32_t* lengths, const int32_t* cu_rows, int rows, float* stats, int dtype,
+                                 hipStream_t stream) {
   VG_REQUIRE(B > 0 && T > 0 && H > 0, "vg_attn_fwd: empty problem");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_fwd: bad dtype %d", dtype);
   VG_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "vg_attn_fwd: unaligned");
-  VG_REQUIRE((long)B * T < 0x7fffffffL / 4, "vg_attn_fwd: too many rows");
-  if (dtype == VG_BF16) return launch_fwd<bf16_t>(qkv, out, lse, slopes, B, T, H, lengths, nullptr, B * T, stream);
-  return launch_fwd<float>(qkv, out, lse, slopes, B, T, H, lengths, nullptr, B * T, stream);
+  VG_REQUIRE(cu_rows == nullptr || (lengths != nullptr && rows > 0), "vg_attn_fwd: packed rows need lengths[B], cu_rows[B + 1] and rows");
+  const int Mtot = cu_rows ? rows : B * T;
+  VG_REQUIRE((long)Mtot < 0x7fffffffL / 4, "vg_attn_fwd: too many rows");
+  if (dtype == VG_BF16) return launch_fwd<bf16_t>(qkv, out, lse, slopes, B, T, H, lengths, cu_rows, Mtot, stats, stream);
+  return launch_fwd<float>(qkv, out, lse, slopes, B, T, H, lengths, cu_rows, Mtot, nullptr, stream);
+}
+
+extern "C" int vg_attn_bwd_stats(const void* qkv, const void* out, const void* dout, const float* lse,
+                                 const float* slopes, void* dqkv, float* delta, int B, int T, int H,
+                                 const int32_t* lengths, const int32_t* cu_rows, int rows, const float* stats, int dtype,
+                                 hipStream_t stream) {
+  VG_REQUIRE(B > 0 && T > 0 && H > 0, "vg_attn_bwd: empty problem");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_bwd: bad dtype %d", dtype);
+  VG_REQUIRE(cu_rows == nullptr || (lengths != nullptr && rows > 0), "vg_attn_bwd: packed rows need lengths[B], cu_rows[B + 1] and rows");
+  const int Mtot = cu_rows ? rows : B * T;
+  if (dtype == VG_BF16)
+    return launch_bwd<bf16_t>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, cu_rows, Mtot, stats, stream);
+  return launch_bwd<float>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, cu_rows, Mtot, nullptr, stream);
+}
+
+extern "C" int vg_attn_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int T, int H,
+                           const int32_t* lengths, int dtype, hipStream_t stream) {
+  return vg_attn_fwd_stats(qkv, out, lse, slopes, B, T, H, lengths, nullptr, 0, nullptr, dtype, stream);
 }
 
 extern "C" int vg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                            const float* slopes, void* dqkv, float* delta, int B, int T, int H,
                            const int32_t* lengths, int dtype, hipStream_t stream) {
-  VG_REQUIRE(B > 0 && T > 0 && H > 0, "vg_attn_bwd: empty problem");
-  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_bwd: bad dtype %d", dtype);
-  if (dtype == VG_BF16)
-    return launch_bwd<bf16_t>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, nullptr, B * T, stream);
-  return launch_bwd<float>(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, nullptr, B * T, stream);
+  return vg_attn_bwd_stats(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths, nullptr, 0, nullptr, dtype, stream);
 }
 
 extern "C" int vg_attn_fwd_varlen(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tmax, int H,
                                   const int32_t* lengths, const int32_t* cu_rows, int rows, int dtype, hipStream_t stream) {
-  VG_REQUIRE(B > 0 && Tmax > 0 && H > 0 && rows > 0, "vg_attn_fwd_varlen: empty problem");
-  VG_REQUIRE(lengths != nullptr && cu_rows != nullptr, "vg_attn_fwd_varlen: lengths[B] and cu_rows[B + 1] are required");
-  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_fwd_varlen: bad dtype %d", dtype);
-  VG_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "vg_attn_fwd_varlen: unaligned");
-  if (dtype == VG_BF16) return launch_fwd<bf16_t>(qkv, out, lse, slopes, B, Tmax, H, lengths, cu_rows, rows, stream);
-  return launch_fwd<float>(qkv, out, lse, slopes, B, Tmax, H, lengths, cu_rows, rows, stream);
+  VG_REQUIRE(lengths != nullptr && cu_rows != nullptr && rows > 0, "vg_attn_fwd_varlen: lengths[B], cu_rows[B + 1] and rows are required");
+  return vg_attn_fwd_stats(qkv, out, lse, slopes, B, Tmax, H, lengths, cu_rows, rows, nullptr, dtype, stream);
 }
 
 extern "C" int vg_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse,
                                   const float* slopes, void* dqkv, float* delta, int B, int Tmax, int H,
                                   const int32_t* lengths, const int32_t* cu_rows, int rows, int dtype, hipStream_t stream) {
-  VG_REQUIRE(B > 0 && Tmax > 0 && H > 0 && rows > 0, "vg_attn_bwd_varlen: empty problem");
-  VG_REQUIRE(lengths != nullptr && cu_rows != nullptr, "vg_attn_bwd_varlen: lengths[B] and cu_rows[B + 1] are required");
-  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_attn_bwd_varlen: bad dtype %d", dtype);
-  if (dtype == VG_BF16)
-    return launch_bwd<bf16_t>(qkv, out, dout, lse, slopes, dqkv, delta, B, Tmax, H, lengths, cu_rows, rows, stream);
-  return launch_bwd<float>(qkv, out, dout, lse, slopes, dqkv, delta, B, Tmax, H, lengths, cu_rows, rows, stream);
+  VG_REQUIRE(lengths != nullptr && cu_rows != nullptr && rows > 0, "vg_attn_bwd_varlen: lengths[B], cu_rows[B + 1] and rows are required");
+  return vg_attn_bwd_stats(qkv, out, dout, lse, slopes, dqkv, delta, B, Tmax, H, lengths, cu_rows, rows, nullptr, dtype, stream);
 }
 
 extern "C" int vg_attn_decode(const void* q, const void* kcache, const void* vcache, void* out,

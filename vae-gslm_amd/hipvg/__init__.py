@@ -66,6 +66,9 @@ SIGNATURES = {
     "vg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "vg_attn_fwd_varlen": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "vg_attn_bwd_varlen": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
+    "vg_attn_stats_floats": [_i, _i, _i],
+    "vg_attn_fwd_stats": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp],
+    "vg_attn_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp],
     "vg_gather_rows": [_vp, _vp, _vp, _i, _i, _vp],
     "vg_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vg_ce_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _i, _i, _vp],

@@ -815,6 +815,25 @@ def alibi_slopes(nheads: int):
     return pow2(c) + alibi_slopes(2 * c)[0::2][:nheads - c]
 
 
+def attn_workspace(B: int, T: int, H: int, rows: int, device) -> Tensor:
+    """fp32 [H * rows + vg_attn_stats_floats]: the log-sum-exp rows the backward needs, followed by the per-(batch, head)
+    statistics of its ALiBi window (include/vaegslm_hip.h, vg_attn_fwd_stats) -- one allocation, one saved tensor."""
+    return torch.empty(H * rows + lib().vg_attn_stats_floats(B, T, H), dtype=torch.float32, device=device)
+
+
+def attn_fwd_raw(qkv, out, ws, slopes, B, T, H, lengths, cu=None, rows=0) -> None:
+    M = rows if cu is not None else B * T
+    check(lib().vg_attn_fwd_stats(ptr(qkv), ptr(out), ptr(ws), ptr(slopes), B, T, H, ptr(lengths), ptr(cu), int(rows),
+                                  ws.data_ptr() + 4 * H * M, dtype_id(qkv.dtype), stream()), "vg_attn_fwd")
+
+
+def attn_bwd_raw(qkv, out, dout, ws, slopes, dqkv, delta, B, T, H, lengths, cu=None, rows=0) -> None:
+    M = rows if cu is not None else B * T
+    check(lib().vg_attn_bwd_stats(ptr(qkv), ptr(out), ptr(dout), ptr(ws), ptr(slopes), ptr(dqkv), ptr(delta), B, T, H,
+                                  ptr(lengths), ptr(cu), int(rows), ws.data_ptr() + 4 * H * M, dtype_id(qkv.dtype),
+                                  stream()), "vg_attn_bwd")
+
+
 class AttentionFn(torch.autograd.Function):
     """Causal ALiBi attention over the packed in_proj output
     (modules/attention/attention.py:52-78)."""
@@ -824,9 +843,8 @@ class AttentionFn(torch.autograd.Function):
         D = H * 64
         assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
         out = torch.empty((B * T, D), dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty((H, B * T), dtype=torch.float32, device=qkv.device)
-        check(lib().vg_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(slopes), B, T, H, ptr(lengths),
-                                dtype_id(qkv.dtype), stream()), "vg_attn_fwd")
+        lse = attn_workspace(B, T, H, B * T, qkv.device)
+        attn_fwd_raw(qkv, out, lse, slopes, B, T, H, lengths)
         ctx.save_for_backward(qkv, out, lse, slopes, lengths)
         ctx.dims = (B, T, H)
         return out
@@ -838,8 +856,7 @@ class AttentionFn(torch.autograd.Function):
         dout = _as(dout, qkv.dtype)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((H, B * T), dtype=torch.float32, device=qkv.device)
-        check(lib().vg_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
-                                B, T, H, ptr(lengths), dtype_id(qkv.dtype), stream()), "vg_attn_bwd")
+        attn_bwd_raw(qkv, out, dout, lse, slopes, dqkv, delta, B, T, H, lengths)
         return dqkv, None, None, None, None, None
 
 
@@ -1329,13 +1346,12 @@ class TransformerLayerFn(torch.autograd.Function):
         n1, rstd1 = rmsnorm_fwd_raw(x, sc1, eps, lengths, T)
         qkv = gemm(n1, sq, M, 3 * D, D, bias=f32(bqkv))
         att = torch.empty((M, D), dtype=dt, device=x.device)
-        lse = torch.empty((H, M), dtype=torch.float32, device=x.device)
         if pack is None:
-            check(lib().vg_attn_fwd(ptr(qkv), ptr(att), ptr(lse), ptr(slopes), B, T, H, ptr(lengths), dtype_id(dt),
-                                    stream()), "vg_attn_fwd")
+            lse = attn_workspace(B, T, H, M, x.device)
+            attn_fwd_raw(qkv, att, lse, slopes, B, T, H, lengths)
         else:
-            check(lib().vg_attn_fwd_varlen(ptr(qkv), ptr(att), ptr(lse), ptr(slopes), pack.nseq, T, H, ptr(pack.lengths),
-                                           ptr(pack.cu), M, dtype_id(dt), stream()), "vg_attn_fwd_varlen")
+            lse = attn_workspace(pack.nseq, T, H, M, x.device)
+            attn_fwd_raw(qkv, att, lse, slopes, pack.nseq, T, H, pack.lengths, pack.cu, M)
         x1 = gemm(att, so, M, D, D, bias=f32(bo), residual=x, lengths=lengths, T=T)
         n3, rstd3 = rmsnorm_fwd_raw(x1, sc3, eps, lengths, T)
         u = torch.empty((M, F_), dtype=dt, device=x.device)
@@ -1414,12 +1430,9 @@ class TransformerLayerFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((H, M), dtype=torch.float32, device=x.device)
         if pack is None:
-            check(lib().vg_attn_bwd(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
-                                    B, T, H, ptr(lengths), dtype_id(dt), stream()), "vg_attn_bwd")
+            attn_bwd_raw(qkv, att, datt, lse, slopes, dqkv, delta, B, T, H, lengths)
         else:
-            check(lib().vg_attn_bwd_varlen(ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(slopes), ptr(dqkv), ptr(delta),
-                                           pack.nseq, T, H, ptr(pack.lengths), ptr(pack.cu), M, dtype_id(dt), stream()),
-                  "vg_attn_bwd_varlen")
+            attn_bwd_raw(qkv, att, datt, lse, slopes, dqkv, delta, pack.nseq, T, H, pack.lengths, pack.cu, M)
         dn1 = gemm(dqkv, sq, M, D, 3 * D, b_tr=True)
         g_wq, g_bq = wgrad(wqkv, bqkv, dqkv, n1)
         dx, ds1 = rmsnorm_bwd_raw(dn1, x, sc1, rstd1, dx1, lengths, T, dx_colsum=True)
