@@ -214,8 +214,12 @@ def _one_step_worker(rank, world, port, cfg, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_the_concatenated_batch(full_cfg):
-    """SURVEY section 4 'DP=k with global batch N == one GPU with batch N': two ranks with two sequences each
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_equal_one_process_on_the_concatenated_batch(full_cfg, graph):
+    """(graph = True, ADVICE r04: hipGraph mode + injected noise = an EAGER pass of a trainer whose segmented replay is
+    on, i.e. deferred weight-gradient launches with the reducer's hooks live: a "gradient ready" report ahead of its
+    launch would let a bucket travel before the deferred conv-block weight gradients landed.)
+    SURVEY section 4 'DP=k with global batch N == one GPU with batch N': two ranks with two sequences each
     (gradients averaged as DDP does) against one process on the four sequences, same injected noise, one AdamW step
     from the same initial weights.  The single-process gradient is the sum instead of the mean -- a factor of 2 that
     Adam's normalisation removes -- so the updated parameters must agree closely."""
@@ -228,7 +232,7 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(full_cfg):
     cfg["model"] = small_config(full_cfg["model"])
     cfg["training"]["gradient_accumulation"] = 1
     cfg.setdefault("hip", {})
-    cfg["hip"].update(precision="bf16", graph=False, bucket_mb=4)
+    cfg["hip"].update(precision="bf16", graph=graph, bucket_mb=4, graph_bucket_mb=4)
     mgr = mp.get_context("spawn").Manager()      # never fork a process that has touched the GPU
     out = mgr.dict()
     _spawn(_one_step_worker, (2, _free_port(), cfg, out), 2)
@@ -311,3 +315,105 @@ def test_single_rank_rccl_step_ends_where_the_plain_step_ends(full_cfg, comm):
     assert not res[False]["exchange"]
     torch.testing.assert_close(res[True]["params"], res[False]["params"], rtol=0.0, atol=4e-3)
     assert abs(res[True]["loss"] - res[False]["loss"]) <= 2e-2 * abs(res[False]["loss"])
+
+
+def _full_size_single_rank_worker(rank, port, cfg, out):
+    """One process, one GPU, the FULL configuration: the segmented hipGraph step on a one-rank RCCL communicator."""
+    os.environ["VG_DP_SINGLE_RANK"] = "1"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    from hparams.hp import Hparams
+    from trainers.speech.lvtr import LVTRTrainer
+    from training_lib.synthetic import make_batch
+    cfg = copy.deepcopy(cfg)
+    cfg.setdefault("hip", {})
+    cfg["hip"].update(precision="bf16", graph=True, comm="torch", coalesce_accumulation=True)
+    cfg["training"]["gradient_accumulation"] = 1
+    torch.manual_seed(11)
+    tr = LVTRTrainer(Hparams.from_dict(cfg)).to(dev)
+    tr.configure_optimizers()
+    tr.attach_reducer()
+    tr.global_step = cfg["training"]["scheduler"]["warmup_kld"]
+    batch = make_batch(4, 512, dev, seed=77)
+    for it in range(3):
+        outp = tr.training_step(batch, it)
+    torch.cuda.synchronize()
+    out["log"] = list(tr.reducer.last_launch_log)
+    out["nbuckets"] = len(tr.reducer.buckets)
+    out["pieces"] = 1 + (len(tr._cut_layers) + 1 if getattr(tr, "_segmented", False) else 0)
+    out["segmented"] = bool(getattr(tr, "_segmented", False))
+    out["early"] = [list(v) for v in getattr(tr, "_early_buckets", [])]
+    out["finite"] = bool(torch.isfinite(outp["loss"]))
+    dist.destroy_process_group()
+
+
+def test_full_size_segmented_replay_puts_buckets_on_the_wire_before_backward_ends(full_cfg):
+    """VERDICT r04 item 6b.  The full configuration (16 layers, 227 M parameters) in hipGraph mode on a one-rank REAL
+    RCCL communicator: the reducer's own launch log must show that most gradient buckets were on the wire BEFORE the
+    last piece of backward was queued -- the property the round-4 bucket-order bug broke (every collective ran after
+    the last backward kernel) and that no test below full size can see, because only at full size do the bucket
+    boundaries fall between the graph cuts."""
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    _spawn(_full_size_single_rank_worker, (_free_port(), copy.deepcopy(full_cfg), out), 1, port_index=0)
+    assert out["finite"] and out["segmented"], dict(out)
+    log, nb, pieces = out["log"], out["nbuckets"], out["pieces"]
+    assert len(log) == nb and sorted(i for i, _ in log) == list(range(nb)), log      # every bucket exactly once
+    assert [i for i, _ in log] == sorted(i for i, _ in log), log                      # in bucket-index order
+    last_piece = pieces - 1                                # phase of the launches that came after the last graph was queued
+    early = sum(1 for _, ph in log if ph < last_piece)
+    assert nb >= 5 and early >= 4, (log, pieces)
+    assert early >= (2 * nb) // 3, (log, pieces)
+    # and the plan says so too: the pieces' early-bucket lists grow
+    assert all(len(a) <= len(b) for a, b in zip(out["early"], out["early"][1:])), out["early"]
+
+
+def _world8_worker(rank, world, port, cfg, out):
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=GLOO_TIMEOUT_S))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from hparams.hp import Hparams
+    from trainers.speech.lvtr import LVTRTrainer
+    from training_lib.synthetic import make_batch
+    cfg = copy.deepcopy(cfg)
+    cfg.setdefault("hip", {})
+    cfg["hip"].update(precision="bf16", graph=True, bucket_mb=4, graph_bucket_mb=4, comm="torch")
+    torch.manual_seed(11)
+    tr = LVTRTrainer(Hparams.from_dict(cfg)).to(dev)
+    for p in tr.model.parameters():
+        dist.broadcast(p.data, 0)
+    tr.configure_optimizers()
+    tr.attach_reducer()
+    tr.global_step = cfg["training"]["scheduler"]["warmup_kld"]
+    batches = [make_batch(2, 64, dev, seed=500 + 10 * rank + i) for i in range(2)]
+    for it in range(4):                        # 2 optimizer steps (accumulation 2)
+        outp = tr.training_step(batches[it % 2], it)
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    out[rank] = (all(bool(torch.equal(gathered[0], g)) for g in gathered[1:]), bool(torch.isfinite(flat).all()),
+                 tr.reducer.world, [i for i, _ in tr.reducer.last_launch_log], bool(getattr(tr, "_segmented", False)))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_on_one_device(full_cfg):
+    """the small model over EIGHT ranks (gloo exchange, all on one device) in hipGraph mode: the
+    rank count the target names -- bucket plan, the 1/8 scale of the average, the launch order on every rank and the
+    segmented replay -- ends with identical weights on all eight."""
+    from oracle.lvtr_oracle import small_config
+    cfg = copy.deepcopy(full_cfg)
+    cfg["model"] = small_config(full_cfg["model"])
+    world = 8
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    _spawn(_world8_worker, (world, _free_port(), cfg, out), world)
+    orders = set()
+    for r in range(world):
+        same, finite, w, order, seg = out[r]
+        assert same and finite and w == world and seg, (r, out[r])
+        orders.add(tuple(order))
+    assert len(orders) == 1 and list(orders)[0] == tuple(sorted(list(orders)[0]))    # one launch order, bucket-index order

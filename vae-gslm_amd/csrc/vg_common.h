@@ -240,7 +240,29 @@ VG_DEVICE float gelu_erf_grad(float x) {
 // exp(-x^2/2) is shared with the density, the sign is put back with one v_bfi (no compare / select pair), no division.
 // The fp32 parity path (vg_gemm.hip) keeps erff.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#ifndef VG_LAB_GELU_R4
+#define VG_LAB_GELU_R4 0      // 1: the round-4 form (degree-8 erfcx in z = |x| / sqrt(2) on [0, 4.3], compare + select), A/B only
+#endif
 VG_DEVICE void gelu_parts_pk(f32x2_t x, f32x2_t& cdf, f32x2_t& pdf_x) {
+#if VG_LAB_GELU_R4
+  const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+  f32x2_t z = ax * 0.70710678118654752440f;
+  z = f32x2_t{fminf(z[0], 4.3f), fminf(z[1], 4.3f)};
+  const f32x2_t t = z * (2.0f / 4.3f) - 1.0f;
+  f32x2_t P = t * 5.537286610e-01f + 1.473028107e+00f;
+  P = P * t + 1.759649855e+00f;
+  P = P * t + 8.490489436e-01f;
+  P = P * t + 2.434840076e-01f;
+  P = P * t + -1.777284163e-01f;
+  P = P * t + 1.400074079e-01f;
+  P = P * t + -2.071878611e-01f;
+  P = P * t + 2.402888274e-01f;
+  const f32x2_t xx = x * x * -0.72134752044448170368f;
+  const f32x2_t e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  const f32x2_t half = e * P * 0.5f;
+  cdf = f32x2_t{x[0] >= 0.f ? 1.0f - half[0] : half[0], x[1] >= 0.f ? 1.0f - half[1] : half[1]};
+  pdf_x = x * e * 0.39894228040143267794f;
+#else
   const f32x2_t a = {fminf(fabsf(x[0]), 6.0f), fminf(fabsf(x[1]), 6.0f)};
   f32x2_t P = a * 2.8386106714606285e-04f + -4.2407736182212830e-03f;
   P = P * a + 2.6878884062170982e-02f;
@@ -253,6 +275,7 @@ VG_DEVICE void gelu_parts_pk(f32x2_t x, f32x2_t& cdf, f32x2_t& pdf_x) {
   const f32x2_t t = 0.5f - e * P;                                   // 1/2 - Phi(-|x|) >= 0
   cdf = f32x2_t{__builtin_copysignf(t[0], x[0]), __builtin_copysignf(t[1], x[1])} + 0.5f;
   pdf_x = x * e * 0.39894228040143267794f;
+#endif
 }
 VG_DEVICE void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
   f32x2_t c, d;

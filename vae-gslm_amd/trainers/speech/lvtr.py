@@ -560,14 +560,18 @@ class LVTRTrainer(BaseTrainer):
             static[k].value.copy_(v.value, non_blocking=True)
             if static[k].mask is not v.mask and not getattr(static[k].mask, "_vg_full", False):
                 static[k].mask.copy_(v.mask, non_blocking=True)     # lengths are recomputed inside the graph
+        if self.reducer is not None:
+            self.reducer.phase = 0
         graph.replay()
         reduce_now = last and self.reducer is not None and self.reducer.exchange
         if graph2 is not None:
             for k, g in enumerate(graph2):
                 if reduce_now:     # final already: on the wire under the next graph
                     self.reducer.reduce_buckets(self._early_buckets[k])
+                self.reducer.phase = k + 1         # launches logged from here on came after piece k + 1 was queued
                 g.replay()
         if reduce_now:
+            self.reducer.phase = (len(graph2) if graph2 is not None else 0) + 1      # after the last backward kernel
             self.reducer.reduce_all()
         res = dict(out)
         res["kld_weight"] = self.current_kld_weight()

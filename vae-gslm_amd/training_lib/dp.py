@@ -67,6 +67,13 @@ class GradReducer:
         self.time_collectives = False
         self.stub_collectives = False
         self._comm_events = []
+        # launch log (tests, bench): one (bucket index, phase) per collective put on the wire since the last finish();
+        # `phase` is whatever the caller set before it launched more work -- the trainer's segmented hipGraph replay
+        # sets it to the index of the graph piece about to be replayed, so the log shows WHICH buckets were already
+        # travelling when the last piece of backward started (the property a bucket-order bug silently breaks)
+        self.phase = 0
+        self.launch_log = []
+        self.last_launch_log = []
         dev = self.params[0].device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         limit = int(bucket_mb * (1 << 20) / 4)
@@ -231,6 +238,7 @@ class GradReducer:
         else:
             h = self._timed_allreduce(b["flat"])
         b["handle"], b["launched"] = h, True
+        self.launch_log.append((next(i for i, x in enumerate(self.buckets) if x is b), self.phase))
         self._handles.append(h)
 
     def wait_bucket(self, i: int) -> None:
@@ -294,6 +302,7 @@ class GradReducer:
             if h is not None:
                 h.wait()
         self._handles.clear()
+        self.last_launch_log, self.launch_log, self.phase = self.launch_log, [], 0
         for b in self.buckets:
             b["handle"], b["launched"], b["ready"] = None, False, False
             b["pending"] = b["need"]
