@@ -661,8 +661,10 @@ def test_gemm_rows(F, dtype, shape):
     g = 1 + 0.1 * rnd(K, seed=5)
     xn = x.double() * torch.rsqrt(x.double().square().mean(-1, keepdim=True) + 1e-6) * g.double()
     y = F.rows_linear(x, w, bias, out_f32=True, norm_scale=g, norm_eps=1e-6)
+    # (bf16, more than 16 rows: the matrix-core kernel rounds the scaled inputs x * g to bf16 -- what the training path
+    # does when it stores the normed activations -- where the 8-row kernel multiplies in fp32)
     torch.testing.assert_close(y.double(), xn @ w.double().T + bias.double(),
-                               atol=5e-5 if dtype == torch.float32 else 5e-3, rtol=2e-4)
+                               atol=5e-5 if dtype == torch.float32 else (5e-3 if M <= 16 else 2e-2), rtol=2e-4)
 
 
 def test_decode_noise(F):

@@ -307,3 +307,87 @@ def test_fresh_follows_the_buffers_not_the_batch_index(full_cfg):
     assert bool(torch.isfinite(gd).all()) and bool(torch.isfinite(ge).all()) and float(gd.norm()) > 0
     rel = float((gd - ge).norm() / gd.norm())
     assert rel < 1e-3, f"the pass after a backward outside training_step stored over it (rel {rel:.3e})"
+
+
+# ---------------------------------------------------------------- decode at the reference's inference batch (64)
+def _oracle_decode(cfg, sd, x, init, Tp, n):
+    """oracle.lvtr_oracle with its own KV cache: prefill (init state pushed in front) + n single-frame steps."""
+    from oracle import lvtr_oracle as O
+    B = x.shape[0]
+    tr = cfg["transformer"]
+    past, want = None, dict(lat=[], mean=[], logstd=[], logits=[])
+    with torch.no_grad():
+        for i in range(n + 1):
+            xi = x[:, :Tp] if i == 0 else x[:, Tp + i - 1: Tp + i]
+            tok = sd["token_embedding.weight"][xi[..., 0].long()]
+            fused_in = tok + torch.relu(O.dense(sd, "token_fuser.linear", xi[..., 1:]))
+            if i == 0:
+                fused_in = torch.cat([init, fused_in], 1)
+            m = torch.ones(B, fused_in.shape[1], dtype=torch.bool)
+            hT, past, _ = O.transformer_stack(sd, "transformer.0", fused_in, m, tr, past)
+            c = torch.relu(O.dense(sd, "q_spliter.linear", hT))
+            want["lat"].append(hT[:, -1])
+            want["mean"].append(O.dense(sd, "transformer.1.mean", c)[:, -1])
+            want["logstd"].append(O.dense(sd, "transformer.1.logstd", c)[:, -1])
+            want["logits"].append(O.dense(sd, "token_predictor.linear",
+                                          torch.relu(O.dense(sd, "token_spliter.linear", hT)))[:, -1])
+    return {k: torch.stack(v, 1) for k, v in want.items()}
+
+
+def _session_decode(cfg, sd, x, init, Tp, n, precision):
+    import hipvg
+    from hparams.hp import Hparams
+    from inference.speech.session import DecodeSession
+    from models.speech.lvtr import LVTR
+    B = x.shape[0]
+    hipvg.set_precision(precision)
+    model = LVTR(Hparams.from_dict(copy.deepcopy(cfg)), input_dim=80)
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda().eval()
+    xd, zeros = x.to(dev()), torch.zeros(B, 4, device=dev())
+    sess = DecodeSession(model, B, Tp + n + 2, use_graph=False, keep_latent=True)
+    sess.prefill(xd[:, :Tp], init_state=init.to(dev()), noise=torch.zeros(B, Tp + 1, 4, device=dev()))
+    got = dict(lat=[sess._last["transformer_latent"][:, -1].float()], mean=[sess._last["prior"].mean.value[:, -1].float()],
+               logstd=[sess._last["prior"].logstd.value[:, -1].float()], logits=[sess._last["logits"][:, -1].float()])
+    for i in range(1, n + 1):
+        sess.force_frame(xd[:, Tp + i - 1: Tp + i])
+        sess.step(noise=zeros)
+        got["lat"].append(sess._last["transformer_latent"][:, 0].float())
+        got["mean"].append(sess._last["mu_ls"][:, 0, :4])
+        got["logstd"].append(sess._last["mu_ls"][:, 0, 4:])
+        got["logits"].append(sess._last["logits"][:, 0])
+    return {k: torch.stack(v, 1).cpu() for k, v in got.items()}, sess
+
+
+def test_full_config_decode_session_at_batch_64(full_cfg):
+    """``DecodeSession`` at the batch the reference's inference config decodes
+    (configs/infer/speech/vae-gslm.yaml:27: 64 sequences): the FULL model, a 24-frame prompt and 6 teacher-forced steps,
+    against the oracle's own KV-cache decode (reference: models/speech/lvtr.py:227-286, trainers/speech/sampler.py:50-62).
+    fp32 (exact dot-product rows kernel in groups of 8) with the tolerances of the B = 4 test; bf16 on the round-5
+    matrix-core rows kernel (weights streamed once for all 64 rows) within bf16 drift of the oracle, token arg-max
+    exact where the oracle's margin is clear.  (The kernel itself against float64: test_kernels_gpu.py::test_gemm_rows,
+    whose 17..64-row bf16 cases run on it.)"""
+    import numpy as np
+    from oracle import lvtr_oracle as O
+    from oracle.weights import fill_like
+    cfg = full_cfg["model"]
+    rng = np.random.default_rng(64)
+    B, Tp, n = 64, 24, 6
+    x = torch.cat([torch.from_numpy(rng.integers(0, 200, (B, Tp + n, 1))).float(),
+                   torch.from_numpy(rng.standard_normal((B, Tp + n, 4)).astype(np.float32))], -1)
+    init = torch.from_numpy(rng.random((B, 1, 64)).astype(np.float32)) * 2 - 1
+    sd = {k: torch.from_numpy(v) for k, v in fill_like(O.param_shapes(cfg), 20250620).items()}
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 32))
+    want = _oracle_decode(cfg, sd, x, init, Tp, n)
+    got32, sess = _session_decode(cfg, sd, x, init, Tp, n, "fp32")
+    assert not sess._fused                                     # 64 sequences: five launches per layer
+    for key, tol in (("lat", 1e-4), ("mean", 1e-4), ("logstd", 1e-4), ("logits", 5e-4)):
+        np.testing.assert_allclose(got32[key].numpy(), want[key].numpy(), atol=tol, rtol=2e-4, err_msg=key)
+    got16, _ = _session_decode(cfg, sd, x, init, Tp, n, "bf16")          # matrix-core rows kernel
+    for key, tol in (("lat", 0.12), ("mean", 0.05), ("logstd", 0.05), ("logits", 0.25)):
+        err = (got16[key] - want[key]).abs().max().item()
+        assert err <= tol, f"bf16 decode at B = 64 drifts from the oracle: {key} {err:.3f}"
+    # arg-max of the token logits where the oracle's margin is clear
+    top2 = want["logits"].topk(2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 0.3
+    assert bool((got16["logits"].argmax(-1) == want["logits"].argmax(-1))[clear].all())

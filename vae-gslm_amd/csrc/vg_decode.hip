@@ -12,6 +12,7 @@
 //    and attends over the pos[b]+1 cached frames (replaces the per-step torch.cat and mask rebuild of
 //    modules/attention/attention.py:56-73).
 //  * vg_advance: pos[b] += 1 (device-side step counter, so a captured hipGraph can be replayed).
+#include <type_traits>
 #include "vg_common.h"
 #include "../../include/vaegslm_hip.h"
 
@@ -235,6 +236,158 @@ __global__ __launch_bounds__(RMAXW * 64) void gemm_rows_kernel(const TX* __restr
         else reinterpret_cast<T*>(y)[(long)m * ldy + n] = from_f32<T>(r);
       }
     }
+  }
+}
+
+// ---- more than 16 rows (round 5): the same product on the matrix cores.  The 8-row kernel above serves M rows as
+// ceil(M / 8) groups along grid.y, i.e. it streams the weights once per group: at the reference's inference batch (64
+// sequences, configs/infer/speech/vae-gslm.yaml:27) that is eight passes over the 403 MB of a frame's weights, all but
+// the first from L2, and 8 x the VALU work of the dot products.  Here a block owns 16 output columns (16 weight rows)
+// and ALL rows: W is read once, straight from HBM into registers as v_mfma_f32_16x16x32_bf16 A fragments (a lane loads
+// the 16 bytes k0 + 8 (lane >> 4) .. + 7 of weight row n0 + (lane & 15): four lanes cover 64 contiguous bytes of a
+// row), the input rows are the B fragments (bf16 as loaded; fp32 rows of the fused path are rounded to bf16 -- the
+// weights are bf16 anyway), one 16 x 16 accumulator per 16 rows.  The block's waves split K (interleaved 32-deep
+// steps, four of them in flight per wave), meet in LDS, and the whole block runs the epilogue.  The RMSNorm prologue
+// multiplies the input fragments by the norm's scale on the fly and accumulates sum(x^2) from the same registers.
+// fp32 weights (the parity path) and M <= 16 stay on the exact-fp32 kernel above.
+template <typename TX> struct Frag8;       // 8 consecutive input elements -> (bf16x8 operand, their fp32 values on request)
+template <> struct Frag8<bf16_t> {
+  bf16x8 v;
+  VG_DEVICE void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  VG_DEVICE float sumsq() const {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x2_t t = {v[2 * i], v[2 * i + 1]};
+      a = __builtin_amdgcn_fdot2_f32_bf16(t, t, a, false);
+    }
+    return a;
+  }
+  VG_DEVICE bf16x8 operand(const float* g) const {
+    if (g == nullptr) return v;
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)((float)v[i] * g[i]);
+    return r;
+  }
+};
+template <> struct Frag8<float> {
+  f32x4 lo, hi;
+  VG_DEVICE void load(const float* p) {
+    lo = *reinterpret_cast<const f32x4*>(p);
+    hi = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  VG_DEVICE float sumsq() const {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a = fmaf(lo[i], lo[i], fmaf(hi[i], hi[i], a));
+    return a;
+  }
+  VG_DEVICE bf16x8 operand(const float* g) const {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[i] = (bf16_t)(g ? lo[i] * g[i] : lo[i]);
+      r[4 + i] = (bf16_t)(g ? hi[i] * g[4 + i] : hi[i]);
+    }
+    return r;
+  }
+};
+
+constexpr int MFW = 8;          // waves per block of the MFMA rows kernel (K split 8 ways inside the block)
+constexpr int MFU = 4;          // 32-deep k-steps in flight per wave
+
+template <typename TX>
+__global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __restrict__ x, long ldx,
+                                                                  const bf16_t* __restrict__ w, long ldw,
+                                                                  const float* __restrict__ bias,
+                                                                  const TX* __restrict__ residual, long ldr,
+                                                                  void* __restrict__ y, long ldy, int M, int N, int K,
+                                                                  int act, int out_f32,
+                                                                  const float* __restrict__ norm_scale, float norm_eps,
+                                                                  float* __restrict__ zero_ptr, int zero_n) {
+  __shared__ float red[MFW][16][64 + 1];
+  __shared__ float ssq[MFW][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  if (zero_ptr)
+    for (int i = blockIdx.x * blockDim.x + tid; i < zero_n; i += gridDim.x * blockDim.x) zero_ptr[i] = 0.f;
+  const int mt = (M + 15) >> 4;                        // 16-row input tiles (wave-uniform)
+  const int kq = (lane >> 4) * 8;
+  const bf16_t* __restrict__ wp = w + (long)min(n0 + (lane & 15), N - 1) * ldw + kq;
+  const TX* xp[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) xp[t] = x + (long)min(16 * t + (lane & 15), M - 1) * ldx + kq;
+  f32x4 acc[4];
+  float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // k-steps of 32, dealt round-robin to the waves: step j of the block belongs to wave j % MFW
+  const int nsteps = K >> 5;
+  for (int j0 = wave; j0 < nsteps; j0 += MFW * MFU) {
+    bf16x8 wf[MFU];
+    Frag8<TX> xf[MFU][4];
+    float g[MFU][8];
+    // every load of the MFU steps is requested before the first product
+#pragma unroll
+    for (int u = 0; u < MFU; ++u) {
+      const int j = min(j0 + u * MFW, nsteps - 1);      // (past the end: a valid address, the product is dropped below)
+      wf[u] = *reinterpret_cast<const bf16x8*>(wp + 32 * j);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < mt) xf[u][t].load(xp[t] + 32 * j);
+      if (norm_scale) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(norm_scale + 32 * j + kq);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(norm_scale + 32 * j + kq + 4);
+        g[u][0] = a[0]; g[u][1] = a[1]; g[u][2] = a[2]; g[u][3] = a[3];
+        g[u][4] = c[0]; g[u][5] = c[1]; g[u][6] = c[2]; g[u][7] = c[3];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MFU; ++u) {
+      if (j0 + u * MFW >= nsteps) break;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t >= mt) break;
+        if (norm_scale) sq[t] += xf[u][t].sumsq();
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][t].operand(norm_scale ? g[u] : nullptr), acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // accumulator tile t: value (n = 4 (lane >> 4) + i, m = 16 t + (lane & 15)) in acc[t][i]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][4 * (lane >> 4) + i][16 * t + (lane & 15)] = t < mt ? acc[t][i] : 0.f;
+  if (norm_scale) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = sq[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) ssq[wave][16 * t + lane] = v;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 16 * 64; idx += MFW * 64) {
+    const int nn = idx & 15, m = idx >> 4, n = n0 + nn;
+    if (m >= M || n >= N) continue;
+    float r = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < MFW; ++ww) r += red[ww][nn][m];
+    if (norm_scale) {
+      float ss = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < MFW; ++ww) ss += ssq[ww][m];
+      r *= rsqrtf(ss / (float)K + norm_eps);
+    }
+    if (bias) r += bias[n];
+    if (act == VG_ACT_RELU) r = fmaxf(r, 0.f);
+    else if (act == VG_ACT_GELU) r = gelu_erf(r);
+    else if (act == VG_ACT_SILU) r = silu(r);
+    if (residual) r += to_f32<TX>(residual[(long)m * ldr + n]);
+    if (out_f32) reinterpret_cast<float*>(y)[(long)m * ldy + n] = r;
+    else reinterpret_cast<bf16_t*>(y)[(long)m * ldy + n] = (bf16_t)r;
   }
 }
 
@@ -752,6 +905,17 @@ template <typename TX, typename T>
 int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* bias, const void* res, long ldr, void* y,
                 long ldy, int M, int N, int K, int act, int out_f32, const float* norm_scale, float norm_eps,
                 float* zero_ptr, int zero_n, hipStream_t stream) {
+  // more than 16 rows of bf16 weights: the matrix-core kernel (weights streamed once).  VG_ROWS_MFMA=<M> moves the
+  // threshold (rows from which it is used; 0 = never), for A/B runs
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    static const int from = [] { const char* e = getenv("VG_ROWS_MFMA"); return e ? atoi(e) : 17; }();
+    if (from > 0 && M >= from && K % 32 == 0 && ((uintptr_t)x % 16) == 0 && (norm_scale == nullptr || ((uintptr_t)norm_scale % 16) == 0)) {
+      dim3 grid((N + 15) / 16), block(MFW * 64);
+      gemm_rows_mfma_kernel<TX><<<grid, block, 0, stream>>>((const TX*)x, ldx, (const bf16_t*)w, ldw, bias, (const TX*)res, ldr,
+                                                            y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps, zero_ptr, zero_n);
+      return vg_host::check_launch("vg_gemm_rows");
+    }
+  }
   int nwaves = (K + RCHUNK - 1) / RCHUNK;
   if (nwaves > RMAXW) nwaves = RMAXW;
   // more than 8 rows run as groups of up to 8 (grid.y) on the 8-row kernel: its 16-row instance keeps one input row

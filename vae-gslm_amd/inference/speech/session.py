@@ -10,8 +10,10 @@ This session produces the same frames from a different machine model:
 * the prompt is consumed by ONE pass of the training-path kernels (flash attention over the whole prompt),
   whose per-layer key/value projections are copied into the caches;
 * every Linear of the step is ``vg_gemm_rows`` (HBM-bound: the step streams the 403 MB of bf16 weights
-  once; more than 8 sequences run as groups of 8 rows), norms / flow reverse are the row kernels of the training path;
-  from 4 sequences up the attention sub-layer of a layer is ONE launch on an fp32 residual stream
+  once: up to 16 sequences as groups of 8 rows on the exact-fp32 dot-product kernel, 17 to 64 -- the reference's
+  inference batch, configs/infer/speech/vae-gslm.yaml:27 -- on the matrix-core rows kernel), norms / flow reverse
+  are the row kernels of the training path;
+  from 4 to 16 sequences the attention sub-layer of a layer is ONE launch on an fp32 residual stream
   (``vg_attn_layer_decode``: RMSNorm, QKV rows of a head, cache append, attention, out-projection band);
 * the step's random draws (Gaussian latent noise, the uniform number of the token draw) come from one launch of a
   counter-based generator keyed by (session seed, sequence, device-side frame counter) (``vg_decode_noise``);
@@ -88,7 +90,10 @@ class DecodeSession:
         # B = 1 0.675 / 0.663 ms, 4 0.663 / 0.673, 8 0.663 / 0.684, 16 0.93 / 1.16).  VG_DECODE_FUSED=1 / 0 forces it.
         mode = os.environ.get("VG_DECODE_FUSED", "auto")
         fits = self.D % 256 == 0 and self.D <= 1024 and self.D == 64 * self.H
-        self._fused = fits and (mode == "1" or (mode != "0" and self.B >= 4))
+        # ... and up to 16: the fused launch re-reads a head's weights once per SEQUENCE (one block per (head, sequence)),
+        # which is what the batch of the reference's inference config (64) cannot afford; from 17 sequences on every
+        # Linear is one launch of the matrix-core rows kernel (weights streamed once) around the cache attention
+        self._fused = fits and (mode == "1" or (mode != "0" and 4 <= self.B <= 16))
         # seed of this session's draws (vg_decode_noise), taken from torch's CPU generator: torch.manual_seed reproduces a run
         self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         # draw epoch: a device word the captured graph READS (the seed itself is baked into the graph by value); every
