@@ -336,6 +336,10 @@ int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const f
 int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,
                           const int32_t* pos, int B, int Tmax, int H, int dtype, vg_stream_t stream);
 int vg_advance(int32_t* pos, int n, int by, vg_stream_t stream);
+/* Read `bytes` (a multiple of 16, 16-byte aligned) with `blocks` narrow workgroups and discard them: brings a weight
+ * range into the Infinity Cache ahead of the latency-bound kernels of the decode step that stream it (lab switch of
+ * inference/speech/session.py, VG_DECODE_PREFETCH; reference loop: trainers/speech/sampler.py:50-62). */
+int vg_touch(const void* ptr, int64_t bytes, int blocks, vg_stream_t stream);
 int vg_embed_fuse(const float* frame, int ldf, const float* emb, int vocab, int E, const float* wf, const float* bf,
                   int latent, void* out, int B, int dtype, vg_stream_t stream);
 int vg_sample_token(const float* logits, int V, float temperature, const float* uniform, float* frame, int ldf,

@@ -223,6 +223,31 @@ VG_DEVICE void store_rows_T(T* __restrict__ dst_row, const f32x16 (&o)[2], float
     }
 }
 
+// bf16: the same rows through a wave-private 4 KB LDS area, leaving as whole 128-byte rows (16-byte stores, 8 rows per
+// wave-instruction) instead of 8-byte pieces at a row stride (32 rows x 16 bytes per wave-instruction: the backward
+// kernels' epilogues were bound by store issue, the forward's O has left this way since round 3).  `area`: 32 rows x
+// 128 bytes this wave owns; the caller has made sure no other wave still reads it.  Rows >= nrows are not stored.
+VG_DEVICE void store_rows_T_lds(bf16_t* __restrict__ dst, long row_stride, int nrows, const f32x16 (&o)[2], float mul,
+                                char* area, int lane) {
+  const int row = lane & 31;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = db * 32 + 8 * g + 4 * (lane >> 5);
+      const bf16x4 v = {(bf16_t)(o[db][4 * g] * mul), (bf16_t)(o[db][4 * g + 1] * mul), (bf16_t)(o[db][4 * g + 2] * mul),
+                        (bf16_t)(o[db][4 * g + 3] * mul)};
+      *reinterpret_cast<bf16x4*>(area + row * 128 + ((((d0 >> 3) ^ (row & 7))) << 4) + (d0 & 7) * 2) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave's LDS accesses stay in order; the data must have landed)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 8 + (lane >> 3), c16 = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(area + r * 128 + ((c16 ^ (r & 7)) << 4));
+    if (r < nrows) *reinterpret_cast<uint4*>(dst + (long)r * row_stride + c16 * 8) = v;
+  }
+}
+
 // lanes l and l + 32 hold the same accumulator column: combine the two halves with one v_permlane32_swap (VALU)
 // instead of a ds_bpermute round trip through the LDS crossbar.  With both operands = v the instruction returns
 // {v[l & 31], v[(l & 31) + 32]} in every lane.
@@ -1010,7 +1035,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       }
     }
   }
-  if (query < Tr) store_rows_T<T>(dqbase + (long)query * rs, dq, SCALE, lane);
+  if constexpr (DMA) {
+    __syncthreads();                                   // every wave is done with the last K / V tile: the stages are free
+    store_rows_T_lds(dqbase + (long)qw0 * rs, rs, min(32, Tr - qw0), dq, SCALE, smem + wave * 4096, lane);
+  } else {
+    if (query < Tr) store_rows_T<T>(dqbase + (long)query * rs, dq, SCALE, lane);
+  }
 }
 
 // =====================================================================================
@@ -1190,7 +1220,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       }
     }
   }
-  if (key < Tr) {
+  if constexpr (DMA) {
+    __syncthreads();                                   // every wave is done with the last Q / dO tile: the stages are free
+    store_rows_T_lds(dkbase + (long)kw0 * rs, rs, min(32, Tr - kw0), dk, SCALE, smem + wave * 8192, lane);
+    store_rows_T_lds(dvbase + (long)kw0 * rs, rs, min(32, Tr - kw0), dv, 1.f, smem + wave * 8192 + 4096, lane);
+  } else if (key < Tr) {
     store_rows_T<T>(dkbase + (long)key * rs, dk, SCALE, lane);
     store_rows_T<T>(dvbase + (long)key * rs, dv, 1.f, lane);
   }

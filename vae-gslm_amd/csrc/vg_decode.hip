@@ -896,6 +896,18 @@ __global__ __launch_bounds__(64) void decode_noise_kernel(unsigned long long see
   }
 }
 
+// Touch a byte range with few, narrow workgroups so that it sits in the 256 MB Infinity Cache when the kernels that need
+// it arrive (decode: layer L + 1's weights while layer L computes).  The loaded words are folded into a value that is
+// stored only under a condition that never holds, so the loads cannot be dropped.
+__global__ __launch_bounds__(256) void touch_kernel(const f32x4* __restrict__ p, long n16, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = p[i];
+    acc ^= __float_as_uint(v[0]) ^ __float_as_uint(v[1]) ^ __float_as_uint(v[2]) ^ __float_as_uint(v[3]);
+  }
+  if (acc == 0x9E3779B9u && sink != nullptr && n16 < 0) *sink = acc;
+}
+
 __global__ void advance_kernel(int* __restrict__ pos, int n, int by) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) pos[i] += by;
@@ -1001,6 +1013,12 @@ extern "C" int vg_attn_layer_decode(const float* x, const float* norm_scale, flo
                                                                          (const float*)wo, bo, (float*)kcache, (float*)vcache,
                                                                          slopes, pos, Tmax, H, x1, zero_buf);
   return vg_host::check_launch("vg_attn_layer_decode");
+}
+
+extern "C" int vg_touch(const void* ptr, int64_t bytes, int blocks, hipStream_t stream) {
+  VG_REQUIRE(ptr != nullptr && bytes >= 16 && blocks >= 1 && ((uintptr_t)ptr % 16) == 0, "vg_touch: bytes=%lld blocks=%d", (long long)bytes, blocks);
+  touch_kernel<<<dim3(blocks), dim3(256), 0, stream>>>((const f32x4*)ptr, bytes / 16, nullptr);
+  return vg_host::check_launch("vg_touch");
 }
 
 extern "C" int vg_advance(int32_t* pos, int n, int by, hipStream_t stream) {

@@ -101,6 +101,11 @@ class DecodeSession:
         # the first one's Gaussian / uniform stream
         self._epoch = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._x1 = [torch.zeros(self.B, self.D, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        # VG_DECODE_PREFETCH=<blocks> (lab): while layer l computes, `blocks` narrow workgroups on a
+        # second stream read layer l + 1's 26 MB of weights, so that the latency-bound kernels of the small-batch step
+        # find them in the Infinity Cache.  Measured and not kept as a default: profiles/r05/README.md.
+        self._prefetch = int(os.environ.get("VG_DECODE_PREFETCH", "0"))
+        self._side = torch.cuda.Stream(device=self.dev) if self._prefetch > 0 else None
         self._graph = None
         self._last = {}
 
@@ -148,8 +153,18 @@ class DecodeSession:
             x = x.float()
         if fused and self.L % 2 == 1:          # layer l accumulates into _x1[l % 2] and clears the other one
             self._x1[0].zero_()
+        main = torch.cuda.current_stream()
         for l, layer in enumerate(st.layers):
             att = layer.self_attn
+            if self._prefetch > 0 and l + 1 < self.L:
+                nxt = st.layers[l + 1]
+                self._side.wait_stream(main)             # fork: the branch starts when layer l does
+                with torch.cuda.stream(self._side):
+                    for wgt in (nxt.self_attn.in_proj.weight, nxt.self_attn.out_proj.weight, nxt.linear1.weight,
+                                nxt.linear2.weight):
+                        sh = self._w(wgt)
+                        hipvg.check(hipvg.lib().vg_touch(hipvg.ptr(sh), sh.numel() * sh.element_size(), self._prefetch,
+                                                         torch.cuda.current_stream().cuda_stream), "vg_touch")
             if fused:
                 # fp32 residual stream; the attention sub-layer is ONE launch that adds into x1 (zero on entry)
                 x1 = HF.attention_layer_decode(x, layer.norm1.scale.detach(), layer.norm1.eps,
@@ -167,6 +182,8 @@ class DecodeSession:
             mid = HF.rows_linear(x1, self._w(layer.linear1.weight), layer.linear1.bias, act=hipvg.ACT_GELU,
                                  norm_scale=layer.norm3.scale.detach(), norm_eps=layer.norm3.eps)
             x = HF.rows_linear(mid, self._w(layer.linear2.weight), layer.linear2.bias, residual=x1)
+        if self._prefetch > 0:
+            main.wait_stream(self._side)                 # join (also inside a captured graph)
         fn = dict(norm_scale=st.final_norm.scale.detach(), norm_eps=st.final_norm.eps)
         qs, ts, tp = m.q_spliter.linear, m.token_spliter.linear, m.token_predictor.linear
         head_linear = HF.rows_linear_mixed if fused else HF.rows_linear
