@@ -37,18 +37,16 @@ def main():
         shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(",")]
     for (B, T) in shapes:
         g = torch.Generator(device="cpu").manual_seed(0)
-        qkv = torch.randn(B * T, 3 * D, generator=g).to(dev).bfloat16()
+        qkv = (torch.randn(B * T, 3 * D, generator=g) * float(os.environ.get("STD", "1.0"))).to(dev).bfloat16()
         dout = torch.randn(B * T, D, generator=g).to(dev).bfloat16()
         slopes = torch.tensor(F.alibi_slopes(H), dtype=torch.float32, device=dev)
         out = torch.empty(B * T, D, dtype=torch.bfloat16, device=dev)
-        lse = torch.empty(H, B, T, dtype=torch.float32, device=dev)
+        ws = F.attn_workspace(B, T, H, B * T, dev)        # log-sum-exp rows + the statistics of the backward's ALiBi window
         dqkv = torch.empty_like(qkv)
-        delta = torch.empty_like(lse)
-        L = hipvg.lib()
-        st = hipvg.stream()
-        p = hipvg.ptr
-        fwd = lambda: L.vg_attn_fwd(p(qkv), p(out), p(lse), p(slopes), B, T, H, None, 1, st)
-        bwd = lambda: L.vg_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(slopes), p(dqkv), p(delta), B, T, H, None, 1, st)
+        delta = torch.empty(H, B * T, dtype=torch.float32, device=dev)
+        # the entry points the model uses (round 5): vg_attn_fwd_stats / vg_attn_bwd_stats; STD=<sigma> scales q / k / v
+        fwd = lambda: F.attn_fwd_raw(qkv, out, ws, slopes, B, T, H, None)
+        bwd = lambda: F.attn_bwd_raw(qkv, out, dout, ws, slopes, dqkv, delta, B, T, H, None)
         fl = 256.0 * B * H * 0.5 * T * (T + 1)
         tf, tb = timeit(fwd), timeit(bwd)
         print(f"B={B} T={T}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF | bwd {tb*1e6:7.1f} us {2.0*fl/tb/1e12:6.1f} TF (2 x forward, SURVEY 8d)", flush=True)

@@ -10,7 +10,12 @@ timeout 200 python bench.py --coalesce 0 --no-cpu-baseline > $O/bench_nocoalesce
 timeout 200 python bench.py --host-batches --no-cpu-baseline > $O/bench_hostbatches.json 2>/dev/null
 timeout 200 python bench.py --mode decode > $O/decode_B8.json 2>/dev/null
 timeout 200 python bench.py --mode decode --decode-batch 1 > $O/decode_B1.json 2>/dev/null
+timeout 200 python bench.py --mode decode --decode-batch 64 > $O/decode_B64.json 2>/dev/null
+timeout 200 python bench.py --mode decode --decode-batch 32 > $O/decode_B32.json 2>/dev/null
+timeout 300 python bench.py --single-rank-rccl --no-cpu-baseline > $O/bench_single_rank_rccl_torch.json 2>/dev/null
+timeout 300 python bench.py --single-rank-rccl --comm abi --no-cpu-baseline > $O/bench_single_rank_rccl_abi.json 2>/dev/null
 timeout 100 python tools/attn_bench.py > $O/attn.txt 2>&1
+STD=0.3 timeout 100 python tools/attn_bench.py > $O/attn_std0.3.txt 2>&1
 VG_DEBUG_GEMM=3 timeout 200 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --graph 0 2>&1 >/dev/null | python tools/gemm_step_table.py 2 > $O/gemm_step_table.txt
 timeout 200 python tools/lab/blaslt_compare.py > $O/gemm_vs_hipblaslt.txt 2>&1
 for f in $O/*.json; do
