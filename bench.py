@@ -409,9 +409,9 @@ def main():
         # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
         # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v9.json), valid for the default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
         if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
         if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16" and args.coalesce and not args.ragged:
             with open(pmc) as f:
                 traffic = json.load(f)["bf16_gemm_family"]["traffic_bytes_per_launch"]
