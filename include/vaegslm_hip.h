@@ -160,7 +160,7 @@ int vg_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const
                        const int32_t* cu_rows, int rows, int dtype, vg_stream_t stream);
 /* The same calls with the ALiBi window of the backward pass (round 5).  `stats`: fp32 workspace of
  * vg_attn_stats_floats(B, T, H) floats per call pair, written by the bf16 forward (per (batch, head): max |k|^2, and per
- * 64 queries max |q|^2 and max -logsumexp; plain stores, no initialisation needed) and read by the backward, which then
+ * 32-query group max |q|^2 and max -logsumexp; plain stores, no initialisation needed) and read by the backward, which then
  * does not stream key / query tiles whose every probability is provably below 2^-20 of its row (the same threshold the
  * kernels already drop products at; fp32 launches ignore it and keep every tile, as does VG_ATTN_WINDOW=0).  The
  * reference (modules/attention/attention.py:60-77) computes the dense masked softmax; under ALiBi

@@ -75,12 +75,12 @@ def main():
             # the window per head of sequence 0, from the statistics
             n = L.vg_attn_stats_floats(1, T, 1)
             stats = ws[H * B * T:].view(B * H, n).cpu()
-            nqt = (n - 1) // 8
+            n128 = (n - 4) // 8
             c2 = 0.125 * math.log2(math.e)
             wins = []
             for h in range(H):
                 s = stats[h]
-                k2, q2, nl = s[0].item(), s[1:1 + 4 * nqt].max().item(), s[1 + 4 * nqt:].max().item()
+                k2, q2, nl = s[0].item(), s[4:4 + 4 * n128].max().item(), s[4 + 4 * n128:].max().item()
                 wins.append((c2 * math.sqrt(q2) * math.sqrt(k2) * 1.01 + nl + 20.0) / (F.alibi_slopes(H)[h] * math.log2(math.e)))
             print(f"B={B} T={T} std={sc}: fwd {tf:6.1f} us {fl/tf/1e6:6.1f} TF | bwd window {tb1:6.1f} us {2*fl/tb1/1e6:6.1f} TF, "
                   f"no window {tb0:6.1f} us | max |d dqkv| {diff:.2e} of {ref:.2e}", flush=True)

@@ -294,6 +294,37 @@ VG_DEVICE f32x16 rows16(const float* arr, int row0, int lane) {
   return r;
 }
 
+// ---- per-(batch, head) statistics the bf16 forward leaves for the backward's ALiBi window (round 5).
+// stats: fp32 [B*H][attn_stats_floats(Tn)]: [0] = max |k_j|^2 over the sequence's keys, written by the one wave that sees
+// every K tile of the pair ([1..3] pad); [4 + g] = max |q_i|^2 and [4 + 4 n128 + g] = max -L_i (L_i: the row's
+// log-sum-exp in the log2 domain) over the valid queries of 32-query group g of the sequence (n128 = 128-query blocks,
+// four groups each; written by both bf16 forward kernels).  Plain stores, one writer per entry: no initialisation, no
+// atomics, bitwise repeatable.  With p_ij = 2^(s_ij - L_i) and
+// s_ij <= c2 |q_i| |k_j| - slope2 (i - j), every probability further than
+//     W = (c2 max|q| max|k| + max(-L) + thr) / slope2
+// from the diagonal is below 2^-thr: the backward kernels do not even STREAM those tiles (the per-tile test they had
+// dropped the products but still paid DMA + barrier + the S product of every tile; at T = 1000 the steep half of the
+// 16 ALiBi heads needs 1-4 of its up to 16 tiles).
+VG_DEVICE int attn_stats_floats(int Tn) { return 4 + 8 * ((Tn + QB - 1) / QB); }        // [0] max |k|^2, [1..3] pad (the arrays stay 16-byte aligned)
+// The window in frames from the statistics of a pair.  Every address is wave-uniform and the buffer is read-only in the
+// backward kernels, so these are SCALAR loads (s_load_dwordx4) and a few v_max on uniform values: the first version --
+// one entry per lane, two DPP wave maxima -- cost 1.4 us per block, which at four rounds of blocks per launch ate what the
+// window saved on the steep heads.  q-side entries [e0, e0 + n) of both arrays, n a multiple of 4.
+VG_DEVICE float attn_window(const float* __restrict__ st, int n128, int e0, int n, float slope2, float c2, float thr) {
+  float q2 = 0.f, nl = -INFINITY;
+  const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(st + 4 + e0);
+  const f32x4* __restrict__ n4 = reinterpret_cast<const f32x4*>(st + 4 + 4 * n128 + e0);
+  for (int i = 0; i < n / 4; ++i) {
+    const f32x4 a = q4[i], c = n4[i];
+    q2 = fmaxf(fmaxf(q2, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+    nl = fmaxf(fmaxf(nl, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
+  }
+  const float bound = c2 * sqrtf(q2 * st[0]) * 1.01f + nl + thr;          // log2 units; 1 % for the rounding of the norms
+  const float w = bound * __builtin_amdgcn_rcpf(slope2) * 1.0001f;        // (approximate reciprocal: rounded up)
+  return w >= 0.f ? w : (w < 0.f ? 0.f : INFINITY);                       // NaN (inf - inf, 0 * inf) -> no window
+}
+
+
 // =====================================================================================
 // forward
 //
@@ -309,7 +340,7 @@ template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const float* __restrict__ slopes,
                                                        int Tn, int H, const int* __restrict__ lengths, int sched,
-                                                       const int* __restrict__ cu, int Mtot) {
+                                                       const int* __restrict__ cu, int Mtot, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_row = smem;
   char* v_tr = smem + LdsPlan<T>::ROW_BYTES;
@@ -331,9 +362,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
   const T* __restrict__ base = qkv + (long)soff * rs + h * DH;
   T* __restrict__ obase = out + (long)soff * D + h * DH;
 
+  // statistics of the backward's ALiBi window (bf16 launches with a workspace; layout: attn_stats_floats)
+  const int n128 = (Tn + QB - 1) / QB;
+  float* __restrict__ st_pair = (sizeof(T) == 2 && stats) ? stats + (long)(b * H + h) * attn_stats_floats(Tn) : nullptr;
   if (q0 >= len) {   // fully padded tile: zero rows (attention.py:80 re-mask)
     f32x16 z[2] = {zero16(), zero16()};
     if (query < Tr) store_rows_T<T>(obase + (long)query * D, z, 0.f, lane);
+    if (st_pair && lane == 0) {
+      st_pair[4 + 4 * qt + wave] = 0.f;
+      st_pair[4 + 4 * n128 + 4 * qt + wave] = -INFINITY;
+    }
     return;
   }
   const int qend = min(q0 + QB, len);
@@ -341,6 +379,22 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
 
   RowRegs<T> qf;
   qf.load(base + (long)min(query, Tr - 1) * rs, lane);
+  float qmax2 = 0.f, kmax2 = 0.f;
+  // the wave that holds the sequence's last valid query computes every K tile of the pair: it takes max |k|^2 along
+  const bool kstat = st_pair != nullptr && len - 1 < q0 + QB && wave == ((len - 1 - q0) >> 5);
+  if constexpr (sizeof(T) == 2) {
+    if (st_pair) {
+      float part = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const bf16x2 v = {qf.f[st][j], qf.f[st][j + 1]};
+          part = __builtin_amdgcn_fdot2_f32_bf16(v, v, part, false);
+        }
+      qmax2 = wave_max(query < len ? xhalf_sum(part) : 0.f);
+    }
+  }
   const float slope = slopes[h];
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   f32x16 kinit;
@@ -387,6 +441,24 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
       }
     }
     if (qw0 + 31 < kv0) continue;   // this wave's queries all precede the tile (causal)
+    if constexpr (sizeof(T) == 2) {
+      if (kstat) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          float part = 0.f;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            const bf16x8 kf = RowTile<T, DH>::frag(k_row, kb * 32 + (lane & 31), st, lane);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const bf16x2 v = {kf[j], kf[j + 1]};
+              part = __builtin_amdgcn_fdot2_f32_bf16(v, v, part, false);
+            }
+          }
+          kmax2 = fmaxf(kmax2, xhalf_sum(part));
+        }
+      }
+    }
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) s[kb] = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, kinit);
@@ -425,11 +497,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) o[db] = mma_tr_acc<T>(v_tr, kb * 32, db, s[kb], lane, o[db]);
   }
+  const float L2 = m + log2f(l) - slope2 * (float)(query - qw0);            // the row's log-sum-exp, log2 domain
   if (query < Tr) {
     const bool valid = query < len;
     store_rows_T<T>(obase + (long)query * D, o, valid ? 1.f / l : 0.f, lane);
-    if (valid && lane < 32)
-      lse[(long)h * Mtot + soff + query] = (m + log2f(l) - slope2 * (float)(query - qw0)) * LN2;
+    if (valid && lane < 32) lse[(long)h * Mtot + soff + query] = L2 * LN2;
+  }
+  if (st_pair) {
+    const float nl = wave_max(query < len ? -L2 : -INFINITY), km = wave_max(kmax2);
+    if (lane == 0) {
+      st_pair[4 + 4 * qt + wave] = qmax2;
+      st_pair[4 + 4 * n128 + 4 * qt + wave] = nl;
+      if (kstat) st_pair[0] = km;
+    }
   }
 }
 
@@ -454,35 +534,6 @@ constexpr int QW2 = 64;             // queries per wave (two 32-query groups)
 constexpr int QB2 = 4 * QW2;        // queries per block
 constexpr int STAGE2 = 2 * TB * 128;   // K row image + V transposed-read image of one 64-key tile
 constexpr int NSTAGE2 = 3;
-
-// ---- per-(batch, head) statistics the bf16 forward leaves for the backward's ALiBi window (round 5).
-// stats: fp32 [B*H][attn_stats_floats(Tn)]: [0] = max |k_j|^2 over the sequence's keys, written by the one wave that sees
-// every K tile of the pair; [1 + 4 qt + w] = max |q_i|^2 and [1 + 4 nqt + 4 qt + w] = max -L_i (L_i: the row's
-// log-sum-exp in the log2 domain) over the valid queries of wave w of 256-query block qt.  Plain stores, one writer per
-// entry: no initialisation, no atomics, bitwise repeatable.  With p_ij = 2^(s_ij - L_i) and
-// s_ij <= c2 |q_i| |k_j| - slope2 (i - j), every probability further than
-//     W = (c2 max|q| max|k| + max(-L) + thr) / slope2
-// from the diagonal is below 2^-thr: the backward kernels do not even STREAM those tiles (the per-tile test they had
-// dropped the products but still paid DMA + barrier + the S product of every tile; at T = 1000 the steep half of the
-// 16 ALiBi heads needs 1-4 of its up to 16 tiles).
-VG_DEVICE int attn_stats_floats(int Tn) { return 4 + 8 * ((Tn + QB2 - 1) / QB2); }      // [0] max |k|^2, [1..3] pad (the arrays stay 16-byte aligned)
-// The window in frames from the statistics of a pair.  Every address is wave-uniform and the buffer is read-only in the
-// backward kernels, so these are SCALAR loads (s_load_dwordx4) and a few v_max on uniform values: the first version --
-// one entry per lane, two DPP wave maxima -- cost 1.4 us per block, which at four rounds of blocks per launch ate what the
-// window saved on the steep heads.  q-side entries [e0, e0 + n) of both arrays, n a multiple of 4.
-VG_DEVICE float attn_window(const float* __restrict__ st, int nqt, int e0, int n, float slope2, float c2, float thr) {
-  float q2 = 0.f, nl = -INFINITY;
-  const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(st + 4 + e0);
-  const f32x4* __restrict__ n4 = reinterpret_cast<const f32x4*>(st + 4 + 4 * nqt + e0);
-  for (int i = 0; i < n / 4; ++i) {
-    const f32x4 a = q4[i], c = n4[i];
-    q2 = fmaxf(fmaxf(q2, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
-    nl = fmaxf(fmaxf(nl, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
-  }
-  const float bound = c2 * sqrtf(q2 * st[0]) * 1.01f + nl + thr;          // log2 units; 1 % for the rounding of the norms
-  const float w = bound * __builtin_amdgcn_rcpf(slope2) * 1.0001f;        // (approximate reciprocal: rounded up)
-  return w >= 0.f ? w : (w < 0.f ? 0.f : INFINITY);                       // NaN (inf - inf, 0 * inf) -> no window
-}
 
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, const float* __restrict__ slopes,
@@ -514,6 +565,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   const T* __restrict__ base = qkv + (long)soff * rs + h * DH;
   T* __restrict__ obase = out + (long)soff * D + h * DH;
   float* __restrict__ st_pair = stats ? stats + (long)(b * H + h) * attn_stats_floats(Tn) : nullptr;
+  const int n128 = (Tn + QB - 1) / QB;
 
   if (q0 >= len) {   // fully padded tile: zero rows (attention.py:80 re-mask)
 #pragma unroll
@@ -522,9 +574,12 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
       const int row = qg0[r64 >> 5] + (r64 & 31);
       if (row < Tr) *reinterpret_cast<uint4*>(obase + (long)row * D + (lane & 7) * 8) = make_uint4(0, 0, 0, 0);
     }
-    if (st_pair && lane == 0) {
-      st_pair[4 + 4 * qt + wave] = 0.f;
-      st_pair[4 + 4 * nqt + 4 * qt + wave] = -INFINITY;
+    if (st_pair && lane < 2) {                       // this wave's two groups: no valid query
+      const int g = lane == 0 ? wave : 7 - wave;
+      if (8 * qt + g < 4 * n128) {
+        st_pair[4 + 8 * qt + g] = 0.f;
+        st_pair[4 + 4 * n128 + 8 * qt + g] = -INFINITY;
+      }
     }
     return;
   }
@@ -610,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0].f[0]), "+v"(qf[0].f[1]), "+v"(qf[0].f[2]), "+v"(qf[0].f[3]),
                "+v"(qf[1].f[0]), "+v"(qf[1].f[1]), "+v"(qf[1].f[2]), "+v"(qf[1].f[3]) :: "memory");
   // statistics for the backward's window: max |q|^2 over this wave's valid queries (before the pre-scaling)
-  float qmax2 = 0.f;
+  float qmax2[2] = {0.f, 0.f};
   if (st_pair) {
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
@@ -623,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
           part = __builtin_amdgcn_fdot2_f32_bf16(v, v, part, false);
         }
       const float whole = xhalf_sum(part);
-      qmax2 = fmaxf(qmax2, qg0[qs] + (lane & 31) < len ? whole : 0.f);
+      qmax2[qs] = wave_max(qg0[qs] + (lane & 31) < len ? whole : 0.f);
     }
   }
 #pragma unroll
@@ -817,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   // ---- epilogue: O^T -> rows through LDS.  The last tile (tile 0) sits in stage (nkt - 1) % 3; the other two stages
   // hold no tile any wave still reads and nothing is in flight: 2 x 16 KB = 8 KB per wave.
   char* ow = smem + ((t0 + 1 + (wave >> 1)) % NSTAGE2) * STAGE2 + (wave & 1) * 8192;
-  float nlmax = -INFINITY;
+  float nlmax[2] = {-INFINITY, -INFINITY};
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
     const float l = xhalf_sum(lp[qs]);
@@ -837,14 +892,18 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
     const float L2 = r[qs] + log2f(l) - slope2 * (float)(lane & 31);        // log-sum-exp of the row, log2 domain
     if (query < len) {
       if (lane < 32) lse[(long)h * Mtot + soff + query] = L2 * LN2;
-      nlmax = fmaxf(nlmax, -L2);
+      nlmax[qs] = -L2;
     }
   }
   if (st_pair) {
-    const float qm = wave_max(qmax2), nl = wave_max(nlmax);
-    if (lane == 0) {
-      st_pair[4 + 4 * qt + wave] = qm;
-      st_pair[4 + 4 * nqt + 4 * qt + wave] = nl;
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const float nl = wave_max(nlmax[qs]);
+      const int g = 8 * qt + (qs == 0 ? wave : 7 - wave);       // 32-query group of the sequence
+      if (lane == 0 && g < 4 * n128) {
+        st_pair[4 + g] = qmax2[qs];
+        st_pair[4 + 4 * n128 + g] = nl;
+      }
     }
     if (kstat) {
       const float km = wave_max(kmax2);
@@ -958,8 +1017,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   const float slope2 = slope * LOG2E, c2 = SCALE * LOG2E;
   int kt_lo = 0;
   if (DMA && stats != nullptr && skip_thr < INFINITY) {
-    const int nqt2 = (Tn + QB2 - 1) / QB2;
-    const float W = attn_window(stats + (long)(b * H + h) * attn_stats_floats(Tn), nqt2, 4 * (q0 / QB2), 4, slope2, c2, skip_thr);
+    const int n128 = (Tn + QB - 1) / QB;          // this block's own four 32-query groups
+    const float W = attn_window(stats + (long)(b * H + h) * attn_stats_floats(Tn), n128, 4 * (q0 / QB), 4, slope2, c2, skip_thr);
     const float lo = (float)q0 - W;
     if (lo > 0.f) kt_lo = min((int)(lo * (1.0f / TB)), q0 / TB);
   }
@@ -1149,8 +1208,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   // keys with probabilities < 2^-skip_thr -- their tiles are not streamed at all
   int qt_first = qt_end - 1;         // the LAST tile of the upward sweep
   if (DMA && stats != nullptr && skip_thr < INFINITY) {
-    const int nqt2 = (Tn + QB2 - 1) / QB2;
-    const float W = attn_window(stats + (long)(b * H + h) * attn_stats_floats(Tn), nqt2, 0, 4 * nqt2, slope2, c2, skip_thr);
+    const int n128 = (Tn + QB - 1) / QB;
+    const float W = attn_window(stats + (long)(b * H + h) * attn_stats_floats(Tn), n128, 0, 4 * n128, slope2, c2, skip_thr);
     const float hi = (float)(k0 + QB - 1) + W;
     if (hi < (float)(qt_end * TB)) qt_first = min(qt_first, (int)(hi * (1.0f / TB)));
   }
@@ -1306,7 +1365,7 @@ static float attn_skip_thr() {
 // `cu` (packed rows, vg_attn_*_varlen): cu[b] = first row of sequence b in the [rows][...] tensors, cu[B] = their total;
 // Mtot = rows of those tensors (= B * Tn in the padded layout); lse / delta are [H][Mtot].
 // host-side mirror of attn_stats_floats (the public vg_attn_stats_floats)
-static int stats_floats_host(int Tn) { return 4 + 8 * ((Tn + QB2 - 1) / QB2); }
+static int stats_floats_host(int Tn) { return 4 + 8 * ((Tn + QB - 1) / QB); }
 
 template <typename T>
 int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int B, int Tn, int H,
@@ -1323,12 +1382,10 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
       return vg_host::check_launch("vg_attn_fwd");
     }
   }
-  // the 128-query kernels leave no statistics: every entry "huge" (0x7f7f7f7f = 3.4e38) = no window in the backward
-  if (stats != nullptr) (void)hipMemsetAsync(stats, 0x7f, sizeof(float) * (size_t)B * H * stats_floats_host(Tn), stream);
   const size_t lds = (sizeof(T) == 2 ? 2 : 1) * (LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
-                     lengths, sched, cu, Mtot);
+                     lengths, sched, cu, Mtot, sizeof(T) == 2 ? stats : nullptr);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_fwd");
 }
