@@ -314,6 +314,17 @@ __global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __re
     for (int i = blockIdx.x * blockDim.x + tid; i < zero_n; i += gridDim.x * blockDim.x) zero_ptr[i] = 0.f;
   const int mt = (M + 15) >> 4;                        // 16-row input tiles (wave-uniform)
   const int kq = (lane >> 4) * 8;
+  // the epilogue's operands (bias, residual) are requested NOW: a launch of this kernel is three dependent memory
+  // round trips otherwise (operands, epilogue operands, stores), and at 64 rows the step is 69 such launches
+  float pre_b[2] = {0.f, 0.f}, pre_r[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * MFW * 64, nn = idx & 15, m = idx >> 4, n = n0 + nn;
+    if (m < M && n < N) {
+      if (bias) pre_b[i] = bias[n];
+      if (residual) pre_r[i] = to_f32<TX>(residual[(long)m * ldr + n]);
+    }
+  }
   const bf16_t* __restrict__ wp = w + (long)min(n0 + (lane & 15), N - 1) * ldw + kq;
   const TX* xp[4];
 #pragma unroll
@@ -369,8 +380,9 @@ __global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __re
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < 16 * 64; idx += MFW * 64) {
-    const int nn = idx & 15, m = idx >> 4, n = n0 + nn;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * MFW * 64, nn = idx & 15, m = idx >> 4, n = n0 + nn;
     if (m >= M || n >= N) continue;
     float r = 0.f;
 #pragma unroll
@@ -381,11 +393,11 @@ __global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __re
       for (int ww = 0; ww < MFW; ++ww) ss += ssq[ww][m];
       r *= rsqrtf(ss / (float)K + norm_eps);
     }
-    if (bias) r += bias[n];
+    r += pre_b[i];
     if (act == VG_ACT_RELU) r = fmaxf(r, 0.f);
     else if (act == VG_ACT_GELU) r = gelu_erf(r);
     else if (act == VG_ACT_SILU) r = silu(r);
-    if (residual) r += to_f32<TX>(residual[(long)m * ldr + n]);
+    r += pre_r[i];
     if (out_f32) reinterpret_cast<float*>(y)[(long)m * ldy + n] = r;
     else reinterpret_cast<bf16_t*>(y)[(long)m * ldy + n] = (bf16_t)r;
   }
