@@ -596,7 +596,11 @@ int check_row_shape(const char* who, int M, int C, int dtype) {
 template <typename T>
 void run_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, int M, int C, float eps,
                      const int32_t* lengths, int Tn, hipStream_t stream) {
-  const int nb = (M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024;
+  // round 5, M = 16000 x 1024 bf16 on cold operands (tools/rows_bench.py, one call): 512 / 1024 / 2048 / 4000 blocks
+  // 26.9 / 17.8 / 18.1 / 16.0 us -- one row per wave and no loop beats two rows in flight per wave (the backward, with
+  // its three row streams and block-level partial sums, is fastest at 512: 31.4 us against 33.3 / 33.9 / 36.0)
+  static const int cap = [] { const char* e = getenv("VG_RMSNORM_FWD_BLOCKS"); return e ? atoi(e) : 4096; }();
+  const int nb = (M + 3) / 4 < cap ? (M + 3) / 4 : cap;
   const int nv = (C / Vec<T>::N + 63) / 64;      // 16-byte vectors per lane and row
   auto k = nv <= 1 ? rmsnorm_fwd_kernel<T, 1> : nv <= 2 ? rmsnorm_fwd_kernel<T, 2> : rmsnorm_fwd_kernel<T, MAXV>;
   k<<<dim3(nb), dim3(256), 0, stream>>>((const T*)x, scale, (T*)y, rstd, M, C, eps, lengths, Tn);
@@ -649,7 +653,8 @@ extern "C" int vg_rmsnorm_fwd(const void* x, const float* scale, void* y, float*
 
 extern "C" int vg_rmsnorm_bwd_blocks(int M) {
   const int b = (M + 3) / 4;
-  return b < 512 ? b : 512;
+  static const int cap = [] { const char* e = getenv("VG_RMSNORM_BWD_BLOCKS"); return e ? atoi(e) : 512; }();
+  return b < cap ? b : cap;
 }
 
 static int rmsnorm_bwd_any(const char* who, const void* dy, const void* x, const float* scale, const float* rstd,
