@@ -498,7 +498,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC_FWD : 1) void att
       for (int kb = 0; kb < 2; ++kb) o[db] = mma_tr_acc<T>(v_tr, kb * 32, db, s[kb], lane, o[db]);
   }
   const float L2 = m + log2f(l) - slope2 * (float)(query - qw0);            // the row's log-sum-exp, log2 domain
-  if (query < Tr) {
+  if constexpr (sizeof(T) == 2) {
+    // bf16: O leaves as whole 128-byte rows through this wave's 4 KB of the freed stages (round 5, as in the backward)
+    __syncthreads();
+    const bool valid = query < len;
+    store_rows_T_lds(obase + (long)qw0 * D, D, min(32, Tr - qw0), o, valid ? 1.f / l : 0.f, smem + wave * 4096, lane);
+    if (valid && lane < 32) lse[(long)h * Mtot + soff + query] = L2 * LN2;
+  } else if (query < Tr) {
     const bool valid = query < len;
     store_rows_T<T>(obase + (long)query * D, o, valid ? 1.f / l : 0.f, lane);
     if (valid && lane < 32) lse[(long)h * Mtot + soff + query] = L2 * LN2;
