@@ -333,6 +333,14 @@ int vg_gemm_rows_mixed(const float* x, int64_t ldx, const void* w, int64_t ldw, 
 int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* residual,
                  int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int act, int out_f32,
                  const float* norm_scale, float norm_eps, int dtype, vg_stream_t stream);
+/* vg_gemm_rows_acc (round 5): y[M][N] (fp32, ZERO on entry) += x[M][K] W[N][K]^T + bias + residual for bf16 x / W and an
+ * fp32 residual, the reduction split over `splits` groups of blocks that meet in y through fp32 atomics: the two
+ * N = d_model products of a decode layer (modules/attention/attention.py:79, modules/transformer/layers.py:82-86) at the
+ * reference's inference batch, where one block per 16 columns would pull every input row through a single CU.  zero_buf
+ * (zero_n floats, not y): cleared by the launch -- the accumulator of a LATER launch. */
+int vg_gemm_rows_acc(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* residual,
+                     int64_t ldr, float* y, int64_t ldy, int M, int N, int K, int splits, float* zero_buf, int zero_n,
+                     vg_stream_t stream);
 int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,
                           const int32_t* pos, int B, int Tmax, int H, int dtype, vg_stream_t stream);
 int vg_advance(int32_t* pos, int n, int by, vg_stream_t stream);

@@ -390,3 +390,22 @@ def test_full_config_decode_session_at_batch_64(full_cfg):
     top2 = want["logits"].topk(2, -1).values
     clear = (top2[..., 0] - top2[..., 1]) > 0.3
     assert bool((got16["logits"].argmax(-1) == want["logits"].argmax(-1))[clear].all())
+
+
+@pytest.mark.parametrize("shape", [(64, 1024, 1024, 4), (33, 1024, 4096, 4), (17, 200, 512, 3), (64, 1024, 4096, 16)])
+def test_gemm_rows_acc(F, shape):
+    """vg_gemm_rows_acc against float64: bf16 rows x bf16 weights + bias + fp32 residual accumulated into a ZEROED fp32
+    buffer by K slices that meet through fp32 atomics (the N = d_model products of a decode layer at 17..64 sequences);
+    the launch also clears the buffer handed in as `zero`."""
+    M, N, K, splits = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev()).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev()).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev())
+    res = torch.randn(M, N, generator=g).to(dev())
+    out = torch.zeros(M, N, device=dev())
+    junk = torch.full((M, 64), 7.0, device=dev())
+    F.rows_linear_acc(x, w, bias, res, out, splits=splits, zero=junk)
+    ref = x.double() @ w.double().T + bias.double() + res.double()
+    torch.testing.assert_close(out.double(), ref, atol=2e-3, rtol=1e-4)
+    assert bool((junk == 0).all())

@@ -297,21 +297,27 @@ template <> struct Frag8<float> {
 constexpr int MFW = 8;          // waves per block of the MFMA rows kernel (K split 8 ways inside the block)
 constexpr int MFU = 4;          // 32-deep k-steps in flight per wave
 
-template <typename TX>
+// ACC (round 5, the two N = 1024 products of a layer at 17..64 sequences: 64 blocks each pulling all the input rows
+// -- 640 KB at K = 4096 -- through one CU): gridDim.y blocks split K, every block adds its 16 x M tile to a ZEROED fp32 y
+// with float atomics (1024 adds per block), the y = 0 slice adds bias and the fp32 residual; no activation, no norm.
+template <typename TX, bool ACC = false>
 __global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ w, long ldw,
                                                                   const float* __restrict__ bias,
-                                                                  const TX* __restrict__ residual, long ldr,
+                                                                  const void* __restrict__ residual_, long ldr,
                                                                   void* __restrict__ y, long ldy, int M, int N, int K,
                                                                   int act, int out_f32,
                                                                   const float* __restrict__ norm_scale, float norm_eps,
                                                                   float* __restrict__ zero_ptr, int zero_n) {
   __shared__ float red[MFW][16][64 + 1];
   __shared__ float ssq[MFW][64];
+  typedef typename std::conditional<ACC, float, TX>::type TR;          // type of the residual rows
+  const TR* __restrict__ residual = reinterpret_cast<const TR*>(residual_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16;
-  if (zero_ptr)
+  if (zero_ptr && blockIdx.y == 0)
     for (int i = blockIdx.x * blockDim.x + tid; i < zero_n; i += gridDim.x * blockDim.x) zero_ptr[i] = 0.f;
+  const bool lead = !ACC || blockIdx.y == 0;                            // the block that adds bias and residual
   const int mt = (M + 15) >> 4;                        // 16-row input tiles (wave-uniform)
   const int kq = (lane >> 4) * 8;
   // the epilogue's operands (bias, residual) are requested NOW: a launch of this kernel is three dependent memory
@@ -320,9 +326,9 @@ __global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __re
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * MFW * 64, nn = idx & 15, m = idx >> 4, n = n0 + nn;
-    if (m < M && n < N) {
+    if (m < M && n < N && lead) {
       if (bias) pre_b[i] = bias[n];
-      if (residual) pre_r[i] = to_f32<TX>(residual[(long)m * ldr + n]);
+      if (residual) pre_r[i] = to_f32<TR>(residual[(long)m * ldr + n]);
     }
   }
   const bf16_t* __restrict__ wp = w + (long)min(n0 + (lane & 15), N - 1) * ldw + kq;
@@ -333,9 +339,11 @@ __global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __re
   float sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // k-steps of 32, dealt round-robin to the waves: step j of the block belongs to wave j % MFW
-  const int nsteps = K >> 5;
-  for (int j0 = wave; j0 < nsteps; j0 += MFW * MFU) {
+  // k-steps of 32, dealt round-robin to the waves: step j of the block belongs to wave j % MFW (ACC: the block's K slice)
+  const int per = ACC ? ((K >> 5) + gridDim.y - 1) / gridDim.y : (K >> 5);
+  const int jbeg = ACC ? blockIdx.y * per : 0;
+  const int nsteps = ACC ? min(K >> 5, jbeg + per) : (K >> 5);
+  for (int j0 = jbeg + wave; j0 < nsteps; j0 += MFW * MFU) {
     bf16x8 wf[MFU];
     Frag8<TX> xf[MFU][4];
     float g[MFU][8];
@@ -398,7 +406,8 @@ __global__ __launch_bounds__(MFW * 64) void gemm_rows_mfma_kernel(const TX* __re
     else if (act == VG_ACT_GELU) r = gelu_erf(r);
     else if (act == VG_ACT_SILU) r = silu(r);
     r += pre_r[i];
-    if (out_f32) reinterpret_cast<float*>(y)[(long)m * ldy + n] = r;
+    if constexpr (ACC) atomicAdd(reinterpret_cast<float*>(y) + (long)m * ldy + n, r);
+    else if (out_f32) reinterpret_cast<float*>(y)[(long)m * ldy + n] = r;
     else reinterpret_cast<bf16_t*>(y)[(long)m * ldy + n] = (bf16_t)r;
   }
 }
@@ -935,7 +944,7 @@ int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* b
     static const int from = [] { const char* e = getenv("VG_ROWS_MFMA"); return e ? atoi(e) : 17; }();
     if (from > 0 && M >= from && K % 32 == 0 && ((uintptr_t)x % 16) == 0 && (norm_scale == nullptr || ((uintptr_t)norm_scale % 16) == 0)) {
       dim3 grid((N + 15) / 16), block(MFW * 64);
-      gemm_rows_mfma_kernel<TX><<<grid, block, 0, stream>>>((const TX*)x, ldx, (const bf16_t*)w, ldw, bias, (const TX*)res, ldr,
+      gemm_rows_mfma_kernel<TX><<<grid, block, 0, stream>>>((const TX*)x, ldx, (const bf16_t*)w, ldw, bias, (const void*)res, ldr,
                                                             y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps, zero_ptr, zero_n);
       return vg_host::check_launch("vg_gemm_rows");
     }
@@ -989,6 +998,19 @@ extern "C" int vg_gemm_rows_mixed(const float* x, int64_t ldx, const void* w, in
                                       norm_eps, zero_buf, zero_n, stream);
   return launch_rows<float, float>(x, ldx, w, ldw, bias, residual, ldr, y, ldy, M, N, K, act, out_f32, norm_scale, norm_eps,
                                    zero_buf, zero_n, stream);
+}
+
+extern "C" int vg_gemm_rows_acc(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                                const float* residual, int64_t ldr, float* y, int64_t ldy, int M, int N, int K, int splits,
+                                float* zero_buf, int zero_n, hipStream_t stream) {
+  VG_REQUIRE(M >= 1 && M <= RMAXM && N >= 1 && K >= 32 && K % 32 == 0, "vg_gemm_rows_acc: M=%d (1..%d) N=%d K=%d (a multiple of 32)", M, RMAXM, N, K);
+  VG_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "vg_gemm_rows_acc: x / w rows must be 16-byte aligned");
+  VG_REQUIRE(splits >= 1 && splits <= 16 && y != nullptr, "vg_gemm_rows_acc: splits=%d (1..16)", splits);
+  VG_REQUIRE(zero_n >= 0 && (zero_n == 0 || zero_buf != nullptr) && zero_buf != y, "vg_gemm_rows_acc: zero_n=%d without a buffer, or the buffer is y", zero_n);
+  dim3 grid((N + 15) / 16, splits), block(MFW * 64);
+  gemm_rows_mfma_kernel<bf16_t, true><<<grid, block, 0, stream>>>((const bf16_t*)x, ldx, (const bf16_t*)w, ldw, bias, (const void*)residual, ldr,
+                                                                  (void*)y, ldy, M, N, K, VG_ACT_NONE, 1, nullptr, 0.f, zero_buf, zero_n);
+  return vg_host::check_launch("vg_gemm_rows_acc");
 }
 
 extern "C" int vg_attn_decode_append(const void* qkv, void* kcache, void* vcache, void* out, const float* slopes,

@@ -97,6 +97,7 @@ SIGNATURES = {
     "vg_decode_noise": [C.c_uint64, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "vg_attn_layer_decode": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vg_gemm_rows_mixed": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp],
+    "vg_gemm_rows_acc": [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _i, _i, _vp, _i, _vp],
     "vg_advance": [_vp, _i, _i, _vp],
     "vg_touch": [_vp, C.c_int64, _i, _vp],
     "vg_flow_blocks": [_i],

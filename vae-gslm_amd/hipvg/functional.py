@@ -1847,6 +1847,23 @@ def rows_linear_mixed(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, 
     return y
 
 
+def rows_linear_acc(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Tensor, out: Tensor, *, splits: int = 4,
+                    zero: Optional[Tensor] = None) -> Tensor:
+    """``out`` (fp32, ZERO on entry) += x W^T + b + residual (vg_gemm_rows_acc): bf16 rows against bf16 weights, the
+    reduction split over ``splits`` groups of blocks that meet in ``out`` through fp32 atomics; ``zero``: an fp32 buffer
+    the launch clears (the accumulator of a later launch)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(1) == 1 and weight.stride(1) == 1
+    assert residual.dtype == torch.float32 and out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    assert zero is None or (zero.dtype == torch.float32 and zero.is_contiguous() and zero.data_ptr() != out.data_ptr())
+    b = None if bias is None else bias.detach().float()
+    check(lib().vg_gemm_rows_acc(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(b), ptr(residual), residual.stride(0),
+                                 ptr(out), out.stride(0), M, N, K, int(splits), ptr(zero), 0 if zero is None else zero.numel(),
+                                 stream()), "vg_gemm_rows_acc")
+    return out
+
+
 def decode_noise(seed: int, pos: Tensor, n_normal: int, epoch: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """(normal [B, n_normal], uniform [B]) for the frame at pos[b] of every sequence (vg_decode_noise): a function of
     (seed, epoch[0], b, pos[b]) only, so hipGraph replays draw fresh numbers as the device-side counter advances;

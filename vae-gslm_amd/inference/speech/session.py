@@ -94,6 +94,10 @@ class DecodeSession:
         # which is what the batch of the reference's inference config (64) cannot afford; from 17 sequences on every
         # Linear is one launch of the matrix-core rows kernel (weights streamed once) around the cache attention
         self._fused = fits and (mode == "1" or (mode != "0" and 4 <= self.B <= 16))
+        # 17 to 64 sequences, bf16 (round 5): an fp32 residual stream with the two N = d_model products of a layer split
+        # over K across blocks (vg_gemm_rows_acc: fp32 atomics into a buffer an earlier launch of the layer cleared);
+        # VG_DECODE_ACC=<splits> (0 = off: five launches on a bf16 stream, every Linear one block per 16 columns)
+        self._acc = 0 if (self._fused or self.B <= 16 or self.dt != torch.bfloat16) else int(os.environ.get("VG_DECODE_ACC", "4"))
         # seed of this session's draws (vg_decode_noise), taken from torch's CPU generator: torch.manual_seed reproduces a run
         self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         # draw epoch: a device word the captured graph READS (the seed itself is baked into the graph by value); every
@@ -147,9 +151,10 @@ class DecodeSession:
                           None if fuser.bias is None else fuser.bias.detach(), dt)
         st = self.stack
         fused = self._fused
+        acc = self._acc
         if st.linear is not None:
-            x = HF.rows_linear(x, self._w(st.linear.weight), st.linear.bias, out_f32=fused)
-        elif fused:
+            x = HF.rows_linear(x, self._w(st.linear.weight), st.linear.bias, out_f32=fused or acc > 0)
+        elif fused or acc > 0:
             x = x.float()
         if fused and self.L % 2 == 1:          # layer l accumulates into _x1[l % 2] and clears the other one
             self._x1[0].zero_()
@@ -175,6 +180,21 @@ class DecodeSession:
                                            norm_scale=layer.norm3.scale.detach(), norm_eps=layer.norm3.eps, out_f32=True)
                 x = HF.rows_linear_mixed(mid, self._w(layer.linear2.weight), layer.linear2.bias, residual=x1, out_f32=True)
                 continue
+            if acc > 0:
+                # fp32 residual stream; buffers: xa receives x1 (cleared by the QKV launch), xb the layer's output
+                # (cleared by the FFN-in launch); the next layer reads xb while its QKV launch clears xa again
+                xa, xb = self._x1
+                qkv = HF.rows_linear_mixed(x, self._w(att.in_proj.weight), att.in_proj.bias,
+                                           norm_scale=layer.norm1.scale.detach(), norm_eps=layer.norm1.eps, zero=xa)
+                ctx = HF.attention_decode_append(qkv, self.kc[l], self.vc[l], self.slopes, self.pos, self.H)
+                x1 = HF.rows_linear_acc(ctx, self._w(att.out_proj.weight), att.out_proj.bias, x, xa, splits=acc)
+                # (from the second layer on x IS xb: the QKV and out-projection launches above have read it before the
+                # FFN-in launch below clears it -- launches of one stream run in order -- and the FFN-out launch then
+                # accumulates the layer's output into it)
+                mid = HF.rows_linear_mixed(x1, self._w(layer.linear1.weight), layer.linear1.bias, act=hipvg.ACT_GELU,
+                                           norm_scale=layer.norm3.scale.detach(), norm_eps=layer.norm3.eps, zero=xb)
+                x = HF.rows_linear_acc(mid, self._w(layer.linear2.weight), layer.linear2.bias, x1, xb, splits=acc)
+                continue
             qkv = HF.rows_linear(x, self._w(att.in_proj.weight), att.in_proj.bias,
                                  norm_scale=layer.norm1.scale.detach(), norm_eps=layer.norm1.eps)
             ctx = HF.attention_decode_append(qkv, self.kc[l], self.vc[l], self.slopes, self.pos, self.H)
@@ -186,7 +206,7 @@ class DecodeSession:
             main.wait_stream(self._side)                 # join (also inside a captured graph)
         fn = dict(norm_scale=st.final_norm.scale.detach(), norm_eps=st.final_norm.eps)
         qs, ts, tp = m.q_spliter.linear, m.token_spliter.linear, m.token_predictor.linear
-        head_linear = HF.rows_linear_mixed if fused else HF.rows_linear
+        head_linear = HF.rows_linear_mixed if (fused or acc > 0) else HF.rows_linear
         cond = head_linear(x, self._w(qs.weight), qs.bias, act=hipvg.ACT_RELU, **fn)
         heads = HF.rows_linear(cond, self._heads_w, self._heads_b, out_f32=True)    # (B, 2 latent + L*128): prior | FiLM
         mu_ls, wb = heads[:, :2 * lat_dim], heads[:, 2 * lat_dim:]
