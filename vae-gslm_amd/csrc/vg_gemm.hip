@@ -451,9 +451,15 @@ int fill_params(const vg_gemm_desc* d, GemmParams& p, int& splits, const char* w
   p.colsum_out = d->colsum_out;
   static const int cs_rr = [] { const char* e = getenv("VG_COLSUM_RR"); return e ? atoi(e) : 1; }();
   p.colsum_rr = cs_rr;
-  // tools/gemm_rotate.py + bench.py, same box: bands of 4 row-tiles +0.9 % end to end over n-fastest (8: +0.6 %)
+  // tile order of a plain launch.  Products up to 8 column-tiles wide: bands of 4 row-tiles walked m-fastest (tools/gemm_rotate.py
+  // + bench.py, round 3: +0.9 % end to end over n-fastest, 8: +0.6 %).  N >= 3072 (QKV, FFN-in and the dgrads of their shape):
+  // n-fastest, an XCD's 32 blocks = two or three whole rows of tiles -- round 5, alternating bench.py runs of one call
+  // (profiles/r05/labs/tile_order_wide_products.txt): NT launches 66.1 -> 64.3 us on average, NN 69.8 -> 69.2, step 28.24 ->
+  // 28.08 ms; the same pair on cold operands in isolation measures level (131 - 133 us either way at N = 4096).
   static const int group_m = [] { const char* e = getenv("VG_GEMM_GROUP_M"); return e ? atoi(e) : 4; }();
-  p.group_m = group_m;
+  static const int group_m_wide = [] { const char* e = getenv("VG_GEMM_GROUP_M_WIDE"); return e ? atoi(e) : 0; }();
+  static const int wide_n = [] { const char* e = getenv("VG_GEMM_WIDE_N"); return e ? atoi(e) : 3072; }();
+  p.group_m = (group_m_wide >= 0 && !d->a_tr && d->N >= wide_n) ? group_m_wide : group_m;
   VG_REQUIRE(d->colsum_out == nullptr || (d->a_tr && d->b_tr), "%s: colsum_out needs a_tr = b_tr = 1", who);
   int kps = (d->K + splits - 1) / splits;
   kps = ((kps + bk - 1) / bk) * bk;
