@@ -262,6 +262,9 @@ int vg_colsum_partials_multi(const vg_colsum_task* tasks, int n, int nb, int dty
  * view in the reference-shaped code).  part: nb * nseg * cols floats of scratch, nb <= 64 row blocks per segment. */
 int vg_colsum_segments(const void* x, int nseg, int rows, int cols, int64_t ld, float* part, int nb, float* out, int dtype,
                        vg_stream_t stream);
+/* the same over ragged segments laid end to end (packed rows): segment s = rows [cu_rows[s], cu_rows[s + 1]) */
+int vg_colsum_segments_cu(const void* x, const int32_t* cu_rows, int nseg, int cols, int64_t ld, float* part, int nb,
+                          float* out, int dtype, vg_stream_t stream);
 /* dx = dy * act'(aux): ReLU takes aux = activation output, GELU (erf) takes aux = pre-activation
  * (modules/activations.py:5-18 backward, for Linear+activation heads with several consumers). */
 int vg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, vg_stream_t stream);
@@ -288,6 +291,18 @@ int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, const float* cb
                   const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
                   float* norm_part, float* w_part, int M, int C, int T, int taps, int shift, int dtype,
                   vg_stream_t stream);
+/* Packed rows (ragged batches without their padding; the reference pads, utils/helpers.py:80-135, and convolves the
+ * padding, modules/conv/layers.py:70-135): the same two operators on sequences laid end to end -- sequence s = rows
+ * [cu_rows[s], cu_rows[s + 1]), s < nseq <= 64, every sequence with its own zero padding on both sides; temb row
+ * min(s, nbatch - 1) (sequences past nbatch are the zero-length pseudo sequences that cover a bucket's spare rows).
+ * bf16, C = 512, taps = 7 only (every conv block of vae-gslm.yaml); other shapes are refused. */
+int vg_dwnorm_fwd_seg(const void* x, const float* w, const float* cbias, const float* temb, const float* gamma,
+                      const float* beta, void* y, float* mean, float* rstd, int M, int C, const int32_t* cu_rows, int nseq,
+                      int nbatch, int taps, int shift, float eps, int dtype, vg_stream_t stream);
+int vg_dwnorm_bwd_seg(const void* dy, const void* x, const float* w, const float* cbias, const float* temb,
+                      const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
+                      float* norm_part, float* w_part, int M, int C, const int32_t* cu_rows, int nseq, int nbatch, int taps,
+                      int shift, int dtype, vg_stream_t stream);
 
 /* ---------------------------------------------------------------- autoregressive decode step
  * LVTR.step (models/speech/lvtr.py:227-286): one new frame per sequence.

@@ -64,6 +64,11 @@ template <> struct V8<bf16_t> {
 struct DwArgs {
   int M, C, Tn, taps, shift;   // output frame t reads input frames t + k - shift, k = 0..taps-1
   float eps;
+  // packed rows (round 5; the run kernels only): sequence s = rows [cu[s], cu[s + 1]) for s < nseq <= 64 -- every
+  // sequence with its own zero padding on both sides -- and the time-embedding row min(s, nbatch - 1); nullptr: M / Tn
+  // sequences of Tn rows each
+  const int* cu = nullptr;
+  int nseq = 0, nbatch = 0;
 };
 
 // The frame-invariant parameters (taps x C weights, conv bias, norm affine) reach the lanes through LDS: one
@@ -295,6 +300,54 @@ __global__ __launch_bounds__(512) void dwnorm_fwd_kernel(const T* __restrict__ x
 // ---------------------------------------------------------------------------------------------------------
 constexpr int RUNF = 8;
 
+// Runs of RF consecutive frames of ONE sequence, numbered through the launch.  Uniform sequences: run r belongs to
+// sequence r / ceil(Tn / RF).  Packed rows: lane s of every wave holds sequence s (its first row, its length and the
+// number of runs before it, from one 64-wide scan at kernel entry); a run finds its sequence with one ballot over
+// "all my runs come before r" and three v_readlane.
+template <int RF> struct SegRuns {
+  int len, base, excl, incl, rps;
+  int nruns;
+  VG_DEVICE void init(const DwArgs& a, int lane) {
+    if (a.cu) {
+      const bool in = lane < a.nseq;
+      base = in ? a.cu[lane] : 0;
+      len = in ? a.cu[lane + 1] - base : 0;
+      const int n = (len + RF - 1) / RF;
+      int sum = n;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(sum, d);
+        if (lane >= d) sum += o;
+      }
+      incl = sum;
+      excl = sum - n;
+      nruns = __builtin_amdgcn_readlane(sum, 63);
+      rps = 1;
+    } else {
+      rps = (a.Tn + RF - 1) / RF;
+      nruns = (a.M / a.Tn) * rps;
+      len = base = excl = incl = 0;
+    }
+  }
+  // sequence b (time-embedding row bt), first frame t0 of the run, the sequence's length Tn and first row
+  VG_DEVICE void locate(const DwArgs& a, int run, int& b, int& bt, int& t0, int& Tn, long& row_base) const {
+    if (a.cu) {
+      const int s = __builtin_popcountll(__ballot(incl <= run));
+      b = s;
+      bt = min(s, a.nbatch - 1);
+      t0 = (run - __builtin_amdgcn_readlane(excl, s)) * RF;
+      Tn = __builtin_amdgcn_readlane(len, s);
+      row_base = __builtin_amdgcn_readlane(base, s);
+    } else {
+      b = run / rps;
+      bt = b;
+      t0 = (run - b * rps) * RF;
+      Tn = a.Tn;
+      row_base = (long)b * a.Tn;
+    }
+  }
+};
+
 VG_DEVICE void load8(const float* p, float (&o)[8]) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
   o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
@@ -330,7 +383,8 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __res
                                                              DwArgs a) {
   constexpr int NR = RUNF + TAPS - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rps = (a.Tn + RUNF - 1) / RUNF, nruns = (a.M / a.Tn) * rps;
+  SegRuns<RUNF> sr;
+  sr.init(a, lane);
   RunParams<TAPS> P;
   P.load(w, lane);
   float cb[8], gm[8], bt[8];
@@ -340,19 +394,21 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __res
   if (gamma) load8(gamma + lane * 8, gm);
   if (beta) load8(beta + lane * 8, bt);
   const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
-  for (int run = blockIdx.x * (blockDim.x >> 6) + wave; run < nruns; run += gridDim.x * (blockDim.x >> 6)) {
-    const int b = run / rps, t0 = (run - b * rps) * RUNF;
-    const bf16_t* xb = x + (long)b * a.Tn * a.C + lane * 8;
+  for (int run = blockIdx.x * (blockDim.x >> 6) + wave; run < sr.nruns; run += gridDim.x * (blockDim.x >> 6)) {
+    int b, bte, t0, Tn;
+    long rbase;
+    sr.locate(a, run, b, bte, t0, Tn, rbase);
+    const bf16_t* xb = x + rbase * a.C + lane * 8;
     uint4 raw[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      const int tc = min(max(t0 - a.shift + j, 0), a.Tn - 1);
+      const int tc = min(max(t0 - a.shift + j, 0), Tn - 1);
       raw[j] = *reinterpret_cast<const uint4*>(xb + (long)tc * a.C);
     }
     float v[RUNF][8];
     {
       float te[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (temb) load8(temb + (long)b * a.C + lane * 8, te);
+      if (temb) load8(temb + (long)bte * a.C + lane * 8, te);
 #pragma unroll
       for (int f = 0; f < RUNF; ++f)
 #pragma unroll
@@ -361,7 +417,7 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __res
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int ti = t0 - a.shift + j;
-      const float on = (ti >= 0 && ti < a.Tn) ? 1.f : 0.f;       // per-sequence zero padding
+      const float on = (ti >= 0 && ti < Tn) ? 1.f : 0.f;         // per-sequence zero padding
       float xv[8];
       V8<bf16_t>::expand(raw[j], xv);
 #pragma unroll
@@ -390,10 +446,10 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __res
       for (int e = 0; e < 8; ++e) { const float d = v[f][e] - mean[f]; q = fmaf(d, d, q); }
       rstd[f] = rsqrtf(wave_sum(q) * inv_c1 + a.eps);
     }
-    const long row0 = (long)b * a.Tn + t0;
+    const long row0 = rbase + t0;
 #pragma unroll
     for (int f = 0; f < RUNF; ++f) {
-      if (t0 + f < a.Tn) {
+      if (t0 + f < Tn) {
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = fmaf(gm[e], (v[f][e] - mean[f]) * rstd[f], bt[e]);
@@ -420,7 +476,8 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
   constexpr int NR = RF + TAPS - 1;
   __shared__ float red[4][2][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rps = (a.Tn + RF - 1) / RF, nruns = (a.M / a.Tn) * rps;
+  SegRuns<RF> sr;
+  sr.init(a, lane);
   RunParams<TAPS> P;
   P.load(w, lane);
   float cb[8], gm[8], sg[8], sb[8];
@@ -429,23 +486,25 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
   if (cbias) load8(cbias + lane * 8, cb);
   if (gamma) load8(gamma + lane * 8, gm);
   const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
-  for (int run = blockIdx.x * 4 + wave; run < nruns; run += gridDim.x * 4) {
-    const int b = run / rps, t0 = (run - b * rps) * RF;
-    const long row0 = (long)b * a.Tn + t0;
-    const bf16_t* xb = x + (long)b * a.Tn * a.C + lane * 8;
+  for (int run = blockIdx.x * 4 + wave; run < sr.nruns; run += gridDim.x * 4) {
+    int b, bte, t0, Tn;
+    long rbase;
+    sr.locate(a, run, b, bte, t0, Tn, rbase);
+    const long row0 = rbase + t0;
+    const bf16_t* xb = x + rbase * a.C + lane * 8;
     uint4 raw[NR], rdy[RF];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      const int tc = min(max(t0 - a.shift + j, 0), a.Tn - 1);
+      const int tc = min(max(t0 - a.shift + j, 0), Tn - 1);
       raw[j] = *reinterpret_cast<const uint4*>(xb + (long)tc * a.C);
     }
 #pragma unroll
     for (int f = 0; f < RF; ++f)
-      rdy[f] = *reinterpret_cast<const uint4*>(dy + ((long)b * a.Tn + min(t0 + f, a.Tn - 1)) * a.C + lane * 8);
+      rdy[f] = *reinterpret_cast<const uint4*>(dy + (rbase + min(t0 + f, Tn - 1)) * a.C + lane * 8);
     float v[RF][8];
     {
       float te[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (temb) load8(temb + (long)b * a.C + lane * 8, te);
+      if (temb) load8(temb + (long)bte * a.C + lane * 8, te);
 #pragma unroll
       for (int f = 0; f < RF; ++f)
 #pragma unroll
@@ -454,7 +513,7 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int ti = t0 - a.shift + j;
-      const float on = (ti >= 0 && ti < a.Tn) ? 1.f : 0.f;
+      const float on = (ti >= 0 && ti < Tn) ? 1.f : 0.f;
       float xv[8];
       V8<bf16_t>::expand(raw[j], xv);
 #pragma unroll
@@ -471,9 +530,9 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
     float s1[RF], s2[RF], rr[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-      const int tf = min(t0 + f, a.Tn - 1);
-      const float mean = mean_in[(long)b * a.Tn + tf], r = rstd_in[(long)b * a.Tn + tf];
-      const float on = t0 + f < a.Tn ? 1.f : 0.f;               // frames past the end of the sequence contribute nothing
+      const int tf = min(t0 + f, Tn - 1);
+      const float mean = mean_in[rbase + tf], r = rstd_in[rbase + tf];
+      const float on = t0 + f < Tn ? 1.f : 0.f;                 // frames past the end of the sequence contribute nothing
       rr[f] = r;
       float dyv[8];
       V8<bf16_t>::expand(rdy[f], dyv);
@@ -498,7 +557,7 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
     for (int f = 0; f < RF; ++f) s2[f] = wave_sum(s2[f]) * rr[f] * rr[f] * rr[f] * inv_c1;
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-      if (t0 + f < a.Tn) {
+      if (t0 + f < Tn) {
         float dyv[8], o[8];
         V8<bf16_t>::expand(rdy[f], dyv);
 #pragma unroll
@@ -530,30 +589,33 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_run_kernel(const bf16_t* 
   constexpr int NR = RF + TAPS - 1;
   __shared__ float red[4][8 * TAPS * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rps = (a.Tn + RF - 1) / RF, nruns = (a.M / a.Tn) * rps;
+  SegRuns<RF> sr;
+  sr.init(a, lane);
   float gw[8][TAPS];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
     for (int k = 0; k < TAPS; ++k) gw[e][k] = 0.f;
-  for (int run = blockIdx.x * 4 + wave; run < nruns; run += gridDim.x * 4) {
-    const int b = run / rps, t0 = (run - b * rps) * RF;
-    const long row0 = (long)b * a.Tn + t0;
-    const bf16_t* dub = du + (long)b * a.Tn * a.C + lane * 8;
-    const bf16_t* xb = x + (long)b * a.Tn * a.C + lane * 8;
+  for (int run = blockIdx.x * 4 + wave; run < sr.nruns; run += gridDim.x * 4) {
+    int b, bte, t0, Tn;
+    long rbase;
+    sr.locate(a, run, b, bte, t0, Tn, rbase);
+    const long row0 = rbase + t0;
+    const bf16_t* dub = du + rbase * a.C + lane * 8;
+    const bf16_t* xb = x + rbase * a.C + lane * 8;
     {   // ---- dx: window row j holds du frame t0 + shift - (TAPS - 1) + j; frame f, tap k reads row f + TAPS - 1 - k
       RunParams<TAPS> P;
       P.load(w, lane);
       uint4 raw[NR], radd[RF];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        const int tc = min(max(t0 + a.shift - (TAPS - 1) + j, 0), a.Tn - 1);
+        const int tc = min(max(t0 + a.shift - (TAPS - 1) + j, 0), Tn - 1);
         raw[j] = *reinterpret_cast<const uint4*>(dub + (long)tc * a.C);
       }
       if (dx_add) {
 #pragma unroll
         for (int f = 0; f < RF; ++f)
-          radd[f] = *reinterpret_cast<const uint4*>(dx_add + ((long)b * a.Tn + min(t0 + f, a.Tn - 1)) * a.C + lane * 8);
+          radd[f] = *reinterpret_cast<const uint4*>(dx_add + (rbase + min(t0 + f, Tn - 1)) * a.C + lane * 8);
       }
       float o[RF][8];
 #pragma unroll
@@ -567,7 +629,7 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_run_kernel(const bf16_t* 
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const int td = t0 + a.shift - (TAPS - 1) + j;
-        const float on = (td >= 0 && td < a.Tn) ? 1.f : 0.f;
+        const float on = (td >= 0 && td < Tn) ? 1.f : 0.f;
         float dv[8];
         V8<bf16_t>::expand(raw[j], dv);
 #pragma unroll
@@ -583,30 +645,30 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_conv_run_kernel(const bf16_t* 
       }
 #pragma unroll
       for (int f = 0; f < RF; ++f)
-        if (t0 + f < a.Tn) V8<bf16_t>::store(dx + (row0 + f) * a.C + lane * 8, o[f]);
+        if (t0 + f < Tn) V8<bf16_t>::store(dx + (row0 + f) * a.C + lane * 8, o[f]);
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the second phase's loads behind the first phase (registers: two waves per SIMD)
     {   // ---- tap gradients: window row j holds x frame t0 - shift + j; frame f, tap k reads row f + k
       uint4 raw[NR], rdu[RF];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        const int tc = min(max(t0 - a.shift + j, 0), a.Tn - 1);
+        const int tc = min(max(t0 - a.shift + j, 0), Tn - 1);
         raw[j] = *reinterpret_cast<const uint4*>(xb + (long)tc * a.C);
       }
 #pragma unroll
-      for (int f = 0; f < RF; ++f) rdu[f] = *reinterpret_cast<const uint4*>(dub + (long)min(t0 + f, a.Tn - 1) * a.C);
+      for (int f = 0; f < RF; ++f) rdu[f] = *reinterpret_cast<const uint4*>(dub + (long)min(t0 + f, Tn - 1) * a.C);
       float duv[RF][8];
 #pragma unroll
       for (int f = 0; f < RF; ++f) {
         V8<bf16_t>::expand(rdu[f], duv[f]);
-        const float on = t0 + f < a.Tn ? 1.f : 0.f;
+        const float on = t0 + f < Tn ? 1.f : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) duv[f][e] *= on;
       }
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const int ts = t0 - a.shift + j;
-        const float on = (ts >= 0 && ts < a.Tn) ? 1.f : 0.f;
+        const float on = (ts >= 0 && ts < Tn) ? 1.f : 0.f;
         float xv[8];
         V8<bf16_t>::expand(raw[j], xv);
 #pragma unroll
@@ -882,4 +944,44 @@ extern "C" int vg_dwnorm_bwd(const void* dy, const void* x, const float* w, cons
   }
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_dwnorm_bwd");
+}
+
+// ---- packed rows (round 5): the same block on ragged sequences laid end to end -- sequence s = rows [cu_rows[s],
+// cu_rows[s + 1]), each with its own zero padding; temb row min(s, nbatch - 1).  bf16, 512 channels, 7 taps (the run
+// kernels: every conv block of vae-gslm.yaml); anything else is refused and the caller keeps padded rows.
+static int check_seg(const char* who, int M, int C, const int* cu_rows, int nseq, int nbatch, int taps, int dtype) {
+  VG_REQUIRE(dtype == VG_BF16 && C == 512 && taps == 7, "%s: packed rows need bf16, C = 512, 7 taps (C=%d taps=%d dtype=%d)", who, C,
+             taps, dtype);
+  VG_REQUIRE(M > 0 && cu_rows != nullptr && nseq >= 1 && nseq <= 64 && nbatch >= 1 && nbatch <= nseq,
+             "%s: M=%d nseq=%d (1..64) nbatch=%d", who, M, nseq, nbatch);
+  return 0;
+}
+
+extern "C" int vg_dwnorm_fwd_seg(const void* x, const float* w, const float* cbias, const float* temb, const float* gamma,
+                                 const float* beta, void* y, float* mean, float* rstd, int M, int C, const int* cu_rows,
+                                 int nseq, int nbatch, int taps, int shift, float eps, int dtype, hipStream_t stream) {
+  if (int e = check_seg("vg_dwnorm_fwd_seg", M, C, cu_rows, nseq, nbatch, taps, dtype)) return e;
+  DwArgs a{M, C, M, taps, shift, eps, cu_rows, nseq, nbatch};
+  const int tok = vg_host::prof_begin(VG_PROF_DWNORM_FWD, (double)M * (2.0 * C * 2 + 8.0), stream);
+  const int nruns = M / RUNF + nseq;          // an upper bound: the kernel counts the real ones from cu_rows
+  dwnorm_fwd_run_kernel<7><<<dim3(min((nruns + 3) / 4, 1024)), dim3(256), 0, stream>>>(
+      (const bf16_t*)x, w, cbias, temb, gamma, beta, (bf16_t*)y, mean, rstd, a);
+  vg_host::prof_end(tok, stream);
+  return vg_host::check_launch("vg_dwnorm_fwd_seg");
+}
+
+extern "C" int vg_dwnorm_bwd_seg(const void* dy, const void* x, const float* w, const float* cbias, const float* temb,
+                                 const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du,
+                                 void* dx, float* norm_part, float* w_part, int M, int C, const int* cu_rows, int nseq,
+                                 int nbatch, int taps, int shift, int dtype, hipStream_t stream) {
+  if (int e = check_seg("vg_dwnorm_bwd_seg", M, C, cu_rows, nseq, nbatch, taps, dtype)) return e;
+  DwArgs a{M, C, M, taps, shift, 0.f, cu_rows, nseq, nbatch};
+  const int nb = vg_dwnorm_blocks(M);          // the caller sized the partial-sum arrays for it
+  const int tok = vg_host::prof_begin(VG_PROF_DWNORM_BWD, (double)M * ((dx_add ? 5.0 : 4.0) * C * 2 + 8.0), stream);
+  dwnorm_bwd_norm_run_kernel<7, 4><<<dim3(nb), dim3(256), 0, stream>>>((const bf16_t*)dy, (const bf16_t*)x, w, cbias, temb, gamma,
+                                                                   mean, rstd, (bf16_t*)du, norm_part, a);
+  dwnorm_bwd_conv_run_kernel<7, 4><<<dim3(nb), dim3(256), 0, stream>>>((const bf16_t*)du, (const bf16_t*)x, w,
+                                                                   (const bf16_t*)dx_add, (bf16_t*)dx, w_part, a);
+  vg_host::prof_end(tok, stream);
+  return vg_host::check_launch("vg_dwnorm_bwd_seg");
 }

@@ -1232,14 +1232,16 @@ namespace {
 // per-SEGMENT column sums, first stage: x is [nseg * rows][ld]; part[blockIdx.y][seg][cols] = sum over this row
 // block's rows of segment seg.  A plain column sum over the nb rows of part (viewed [nb][nseg * cols]) finishes it.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_segments_kernel(const T* __restrict__ x, int rows, int N, long ld,
-                                                              float* __restrict__ part) {
+__global__ __launch_bounds__(256) void colsum_segments_kernel(const T* __restrict__ x, int rows_, int N, long ld,
+                                                              float* __restrict__ part, const int* __restrict__ cu) {
   constexpr int V = Vec<T>::N;
   __shared__ float red[4][64][V];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int seg = blockIdx.z, nseg = gridDim.z;
   const int c0 = (blockIdx.x * 64 + tx) * V;
-  const T* __restrict__ xs = x + (long)seg * rows * ld;
+  // cu: segment seg = rows [cu[seg], cu[seg + 1]) (packed ragged sequences); otherwise rows_ rows each
+  const int first = cu ? cu[seg] : seg * rows_, rows = cu ? cu[seg + 1] - first : rows_;
+  const T* __restrict__ xs = x + (long)first * ld;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < N) {
     const int step = gridDim.y * 4;
@@ -1277,10 +1279,25 @@ extern "C" int vg_colsum_segments(const void* x, int nseg, int rows, int cols, i
                  cols > 0 && cols % vec == 0 && ld % vec == 0 && ((uintptr_t)x % 16) == 0,
              "vg_colsum_segments: nseg=%d rows=%d cols=%d ld=%ld nb=%d", nseg, rows, cols, (long)ld, nb);
   dim3 grid((cols + 64 * vec - 1) / (64 * vec), nb, nseg), block(64, 4);
-  if (dtype == VG_BF16) colsum_segments_kernel<bf16_t><<<grid, block, 0, stream>>>((const bf16_t*)x, rows, cols, (long)ld, part);
-  else colsum_segments_kernel<float><<<grid, block, 0, stream>>>((const float*)x, rows, cols, (long)ld, part);
+  if (dtype == VG_BF16) colsum_segments_kernel<bf16_t><<<grid, block, 0, stream>>>((const bf16_t*)x, rows, cols, (long)ld, part, nullptr);
+  else colsum_segments_kernel<float><<<grid, block, 0, stream>>>((const float*)x, rows, cols, (long)ld, part, nullptr);
   launch_colsum_small(part, nb, nseg * cols, (long)nseg * cols, out, 0, stream);
   return vg_host::check_launch("vg_colsum_segments");
+}
+
+// the same sums over ragged segments laid end to end: segment s = rows [cu_rows[s], cu_rows[s + 1])
+extern "C" int vg_colsum_segments_cu(const void* x, const int* cu_rows, int nseg, int cols, int64_t ld, float* part, int nb,
+                                     float* out, int dtype, hipStream_t stream) {
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "vg_colsum_segments_cu: bad dtype %d", dtype);
+  const int vec = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(x != nullptr && cu_rows != nullptr && part != nullptr && out != nullptr && nseg >= 1 && nseg <= 65535 && nb >= 1 &&
+                 nb <= 64 && cols > 0 && cols % vec == 0 && ld % vec == 0 && ((uintptr_t)x % 16) == 0,
+             "vg_colsum_segments_cu: nseg=%d cols=%d ld=%ld nb=%d", nseg, cols, (long)ld, nb);
+  dim3 grid((cols + 64 * vec - 1) / (64 * vec), nb, nseg), block(64, 4);
+  if (dtype == VG_BF16) colsum_segments_kernel<bf16_t><<<grid, block, 0, stream>>>((const bf16_t*)x, 0, cols, (long)ld, part, cu_rows);
+  else colsum_segments_kernel<float><<<grid, block, 0, stream>>>((const float*)x, 0, cols, (long)ld, part, cu_rows);
+  launch_colsum_small(part, nb, nseg * cols, (long)nseg * cols, out, 0, stream);
+  return vg_host::check_launch("vg_colsum_segments_cu");
 }
 
 extern "C" int vg_colsum_partials_multi(const vg_colsum_task* tasks, int n, int nb, int dtype, hipStream_t stream) {

@@ -85,6 +85,7 @@ SIGNATURES = {
     "vg_masked_means_blocks": [_i],
     "vg_colsum_partials_multi": [C.POINTER(ColsumTask), _i, _i, _i, _vp],
     "vg_colsum_segments": [_vp, _i, _i, _i, _i64, _vp, _i, _vp, _i, _vp],
+    "vg_colsum_segments_cu": [_vp, _vp, _i, _i, _i64, _vp, _i, _vp, _i, _vp],
     "vg_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "vg_mask_rows": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
@@ -107,6 +108,9 @@ SIGNATURES = {
     "vg_dwnorm_blocks": [_i],
     "vg_dwnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "vg_dwnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "vg_dwnorm_fwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "vg_dwnorm_bwd_seg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i,
+                          _vp],
     "vg_embed_fuse_blocks": [_i],
     "vg_embed_fuse_fwd": [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "vg_embed_fuse_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _i, _vp],

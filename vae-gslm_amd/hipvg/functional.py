@@ -532,12 +532,25 @@ def masked_means(items, lengths: Optional[Tensor], T: int) -> Optional[Tensor]:
     return out
 
 
-def segment_colsum(x: Tensor, nseg: int) -> Tensor:
+def segment_colsum(x: Tensor, nseg) -> Tensor:
     """``x.view(nseg, -1, C).float().sum(1)`` for [M, C] rows (M = nseg * T) in two small launches
-    (``vg_colsum_segments``): fp32 [nseg, C]."""
+    (``vg_colsum_segments``): fp32 [nseg, C].  ``nseg`` may be a ``PackPlan``: the segments are its (ragged) sequences."""
     M, Cc = x.shape
-    rows = M // nseg
     vec = 8 if x.dtype == torch.bfloat16 else 4
+    if isinstance(nseg, PackPlan):
+        plan = nseg
+        if x.dtype not in (torch.bfloat16, torch.float32) or Cc % vec or x.stride(1) != 1 or x.stride(0) % vec or x.data_ptr() % 16:
+            x = x.float().contiguous()
+            vec = 4
+            if Cc % 4:
+                raise RuntimeError("segment_colsum over packed rows needs a multiple of 4 columns")
+        nb = max(1, min(64, plan.T // 64))
+        part = torch.empty((nb, plan.nseq, Cc), dtype=torch.float32, device=x.device)
+        out = torch.empty((plan.nseq, Cc), dtype=torch.float32, device=x.device)
+        check(lib().vg_colsum_segments_cu(ptr(x), ptr(plan.cu), plan.nseq, Cc, x.stride(0), ptr(part), nb, ptr(out),
+                                          dtype_id(x.dtype), stream()), "vg_colsum_segments_cu")
+        return out
+    rows = M // nseg
     if (x.dtype not in (torch.bfloat16, torch.float32) or M % nseg or Cc % vec or x.stride(1) != 1 or x.stride(0) % vec
             or x.data_ptr() % 16 or nseg > 65535):
         return x.view(nseg, rows, Cc).float().sum(1)
@@ -866,19 +879,31 @@ def attention(qkv, slopes, B, T, H, lengths=None):
 
 # ---------------------------------------------------------------- packed rows (valid frames of a right-padded batch)
 class PackPlan:
-    """Row maps of one right-padded batch (``utils/tensormask.py:45-54``: prefix masks) for running the Transformer
-    stack on its VALID frames only: ``rows`` packed rows (the sum of the lengths rounded up to ``granule``, so that a
-    hipGraph is captured per bucket and not per batch), every tensor of static shape and computed on the device from
-    ``lengths`` -- the plan can be (re)filled inside a captured graph.
+    """Row maps of one right-padded batch (``utils/tensormask.py:45-54``: prefix masks) for running on its VALID frames
+    only: ``rows`` packed rows (the sum of the lengths rounded up to ``granule``, so that a hipGraph is captured per
+    bucket and not per batch), every tensor of static shape and computed on the device from ``lengths`` -- the plan can
+    be (re)filled inside a captured graph.
 
-    ``idx[i]``  frame (b * T + t) of packed row i, -1 for the rows the rounding added;
+    ``idx[i]``  frame (b * T + t) of packed row i, -1 for the rows the rounding added (and for halo rows);
     ``inv[m]``  packed row of frame m, -1 for padded frames;
     ``cu`` / ``lengths``  row ranges of the B real sequences followed by zero-length pseudo sequences (each at most T
     rows) that cover the added rows: the attention kernels zero-fill those, every other kernel of the stack is
-    row-local and sees them as all-zero frames (their gradients are exactly zero)."""
+    row-local and sees them as all-zero frames (their gradients are exactly zero).
 
-    def __init__(self, B: int, T: int, rows: int, device, granule: Optional[int] = None):
-        self.B, self.T, self.M, self.rows = B, T, B * T, rows
+    ``halo`` > 0 (round 5: the whole step on packed rows, not only the Transformer stack): sequence b owns
+    min(len_b + halo, T) rows, its valid frames followed by the first padded ones.  The reference convolves the padding
+    (modules/conv/layers.py:70-135 runs on the padded (B, C, T) tensor): under the diffusion UNet's three look-ahead
+    blocks (configs/train/speech/vae-gslm.yaml:156-157, 7 taps each) a valid frame depends on up to 18 padded frames
+    after its sequence's end, and those padded frames hold computed values (biases, time embedding, left context), not
+    zeros.  With an 18-row halo per sequence the valid frames -- values and gradients -- are those of the padded run:
+    after the k-th look-ahead block the rows from len + 18 - 6 k on differ from the padded run's, the gradient reaches
+    exactly the rows below that, and the end of a sequence's range is padded with zeros as the end of the batch is
+    (min(.., T): a sequence that fills the batch has nothing after it there either).
+    ``valid[i]`` 1 for a real frame (the row predicate of every row-local kernel: ``lengths = valid, T = 1``), ``seq[i]``
+    the sequence of row i, ``shift_src`` / ``shift_dst`` the row maps of the one-frame shift inside each sequence."""
+
+    def __init__(self, B: int, T: int, rows: int, device, granule: Optional[int] = None, halo: int = 0):
+        self.B, self.T, self.M, self.rows, self.halo = B, T, B * T, rows, int(halo)
         # the rows the rounding adds (at most one granule: rows = max(granule, total rounded up); all of them when the
         # granule is not given) are covered by zero-length pseudo sequences of at most T rows each
         self.npseudo = -(-min(rows, granule or rows) // T)
@@ -887,16 +912,23 @@ class PackPlan:
         self.inv = torch.empty(B * T, dtype=torch.int32, device=device)
         self.cu = torch.empty(self.nseq + 1, dtype=torch.int32, device=device)
         self.lengths = torch.empty(self.nseq, dtype=torch.int32, device=device)
+        self.valid = torch.empty(rows, dtype=torch.int32, device=device)
+        self.seq = torch.empty(rows, dtype=torch.int32, device=device)
+        self.shift_src = torch.empty(rows, dtype=torch.int32, device=device)
+        self.shift_dst = torch.empty(rows + B, dtype=torch.int32, device=device)
         self._t = torch.arange(T, device=device, dtype=torch.int32)[None]
         self._m = torch.arange(B * T, device=device, dtype=torch.int32)
         self._j = torch.arange(self.npseudo + 1, device=device, dtype=torch.int32)
+        self._r = torch.arange(rows, device=device, dtype=torch.int32)
+        self._b = torch.arange(B, device=device, dtype=torch.int32)
 
     def fill(self, lengths32: Tensor) -> "PackPlan":
         """Device-only (no host synchronisation): safe to record into a hipGraph whose ``lengths32`` is a static input."""
         B, T, rows = self.B, self.T, self.rows
         lens = lengths32.to(torch.int32).clamp(0, T)
-        ends = torch.cumsum(lens, 0, dtype=torch.int32)
-        starts = ends - lens
+        ext = torch.clamp(lens + self.halo, max=T) if self.halo else lens
+        ends = torch.cumsum(ext, 0, dtype=torch.int32)
+        starts = ends - ext
         valid = self._t < lens[:, None]
         inv = torch.where(valid, starts[:, None] + self._t, torch.full_like(self._t, -1)).reshape(-1)
         self.inv.copy_(inv)
@@ -907,6 +939,18 @@ class PackPlan:
         tail = torch.minimum(total + self._j * T, torch.full_like(self._j, rows))       # pseudo-sequence boundaries
         self.cu.copy_(torch.cat([torch.zeros(1, dtype=torch.int32, device=lens.device), ends[:-1], tail]))
         self.lengths.copy_(torch.cat([lens, torch.zeros(self.npseudo, dtype=torch.int32, device=lens.device)]))
+        self.valid.copy_((self.idx >= 0).to(torch.int32))
+        seq = torch.searchsorted(self.cu[1:].contiguous(), self._r, right=True).clamp(max=self.nseq - 1).to(torch.int32)
+        self.seq.copy_(seq)
+        # one-frame shift inside every sequence: row i takes row i - 1, a sequence's first row takes start row b of the
+        # source's B extra rows; shift_dst is the inverse map (source row -> the row it moved to)
+        first = self._r == self.cu[seq.long()]
+        ok = self.valid > 0
+        src = torch.where(ok, torch.where(first, rows + seq, self._r - 1), torch.full_like(self._r, -1))
+        self.shift_src.copy_(src)
+        nxt = torch.cat([src[1:], torch.full((1,), -1, dtype=torch.int32, device=lens.device)])
+        fwd = torch.where(nxt == self._r, self._r + 1, torch.full_like(self._r, -1))
+        self.shift_dst.copy_(torch.cat([fwd, torch.where(lens > 0, starts, torch.full_like(starts, -1))]))
         return self
 
 
@@ -946,6 +990,40 @@ def pack_rows(x2: Tensor, plan: PackPlan) -> Tensor:
 def unpack_rows(xp: Tensor, plan: PackPlan) -> Tensor:
     """[plan.rows, C] packed rows -> [B * T, C] padded rows (zeros on padded frames)."""
     return GatherRowsFn.apply(xp, plan.inv, plan.idx)
+
+
+def shift_rows(xp: Tensor, start: Tensor, plan: PackPlan) -> Tensor:
+    """The one-frame right shift of ``TensorMask.push(start).pop(1).apply_mask()`` (reference models/speech/lvtr.py:
+    shifted prior input) on packed rows: row i of a sequence takes row i - 1, its first row takes ``start[b]``; rows
+    that hold no frame are zero."""
+    src = torch.cat([xp, start.to(xp.dtype).reshape(plan.B, -1)], 0).contiguous()
+    return GatherRowsFn.apply(src, plan.shift_src, plan.shift_dst)[:plan.rows]
+
+
+class SeqRowsFn(torch.autograd.Function):
+    """rows[i] = per_seq[seq[i]]: a per-sequence vector on every packed row of its sequence (``u_c[:, None].expand(-1, T,
+    -1)`` of the padded layout, rows of pseudo sequences take the last real one); the backward is the per-sequence
+    column sum, in a fixed order (an index_add would not be)."""
+
+    @staticmethod
+    def forward(ctx, per_seq, plan):
+        src = per_seq.contiguous()
+        assert src.dim() == 2 and (src.shape[1] * src.element_size()) % 16 == 0
+        fmap = plan.seq.clamp(max=plan.B - 1)
+        dst = torch.empty((plan.rows, src.shape[1]), dtype=src.dtype, device=src.device)
+        check(lib().vg_gather_rows(ptr(src), ptr(fmap), ptr(dst), plan.rows, src.shape[1] * src.element_size(), stream()),
+              "vg_gather_rows")
+        ctx.plan = plan
+        return dst
+
+    @staticmethod
+    def backward(ctx, d):
+        plan = ctx.plan
+        return segment_colsum(d.contiguous(), plan)[:plan.B].to(d.dtype), None
+
+
+def seq_rows(per_seq: Tensor, plan: PackPlan) -> Tensor:
+    return SeqRowsFn.apply(per_seq, plan)
 
 
 def attention_decode(q, kcache, vcache, slopes, pos, H):
@@ -1475,10 +1553,19 @@ def transformer_layer(x, n1s, wqkv, bqkv, wo, bo, n3s, w1, b1, w2, b2, slopes, l
 
 # ---------------------------------------------------------------- conv bottleneck block (channels-last)
 def dwnorm_fwd_raw(x, w, cb, te, gamma, beta, T, taps, shift, eps):
+    """``T``: frames per sequence, or a ``PackPlan`` (packed rows: ragged sequences laid end to end)."""
     M, Cc = x.shape
     y = torch.empty_like(x)
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
     rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    if isinstance(T, PackPlan):
+        if taps == 0:        # the norm alone is row-local
+            T = 1
+        else:
+            check(lib().vg_dwnorm_fwd_seg(ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(beta), ptr(y), ptr(mean),
+                                          ptr(rstd), M, Cc, ptr(T.cu), T.nseq, T.B, int(taps), int(shift), float(eps),
+                                          dtype_id(x.dtype), stream()), "vg_dwnorm_fwd_seg")
+            return y, mean, rstd
     check(lib().vg_dwnorm_fwd(ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(beta), ptr(y), ptr(mean),
                               ptr(rstd), M, Cc, int(T), int(taps), int(shift), float(eps), dtype_id(x.dtype),
                               stream()), "vg_dwnorm_fwd")
@@ -1492,10 +1579,22 @@ def dwnorm_bwd_raw(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
     dx = torch.empty_like(x) if taps > 0 else du
     npart = torch.empty((nb, 2 * Cc), dtype=torch.float32, device=x.device)
     wpart = torch.empty((nb, Cc * max(taps, 1)), dtype=torch.float32, device=x.device)
-    check(lib().vg_dwnorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
-                              ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, int(T), int(taps),
-                              int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd")
+    if isinstance(T, PackPlan) and taps > 0:
+        check(lib().vg_dwnorm_bwd_seg(ptr(dy), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
+                                      ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, ptr(T.cu), T.nseq, T.B,
+                                      int(taps), int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd_seg")
+    else:
+        if isinstance(T, PackPlan):
+            T = 1
+        check(lib().vg_dwnorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
+                                  ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, int(T), int(taps),
+                                  int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd")
     return du, dx, npart[:, :Cc], npart[:, Cc:], (wpart if taps > 0 else None)
+
+
+def conv_rows_packable(x: Tensor, taps: int) -> bool:
+    """Can a conv block of this shape run on packed rows (``vg_dwnorm_*_seg``: bf16, 512 channels, 7 taps)?"""
+    return x.dtype == torch.bfloat16 and x.shape[1] == 512 and taps == 7
 
 
 def _sink_or_return(p, value):
@@ -1617,7 +1716,10 @@ class ConvBlockFn(torch.autograd.Function):
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
         dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
-        dte = segment_colsum(dv, dv.shape[0] // T)
+        if isinstance(T, PackPlan):
+            dte = segment_colsum(dv, T)[:T.B]          # per-sequence sums; the pseudo sequences' rows carry no gradient
+        else:
+            dte = segment_colsum(dv, dv.shape[0] // T)
         # the five small reductions of this block (conv weight / bias, norm weight / bias, c2's bias) in one launch
         g_c2b, g_c1w, g_c1b, g_nw, g_nb = vec_grads([
             (None if id(c2b) in fused_bias else c2b, parts[0] if parts and parts[0] is not None else dpre),

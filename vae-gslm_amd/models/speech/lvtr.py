@@ -110,6 +110,12 @@ class LVTR(nn.Module):
             GaussianParameterize(width, latent, std=hp.transformer.get("fix_std", None),
                                  std_range=hp.transformer.get("std_range", None), use_tanh=False,
                                  mean=hp.transformer.get("fix_mean", None)))
+        # Packed step (hip.packed_step; set per batch by the trainer): None = padded rows; "auto" = pack whenever the batch
+        # has enough padding (reads the lengths on the host: eager launches only); an int = pack into exactly that many
+        # rows (the trainer's hipGraph path picks the bucket before it picks the graph).  See _forward_packed.
+        self.pack_rows = None
+        self.pack_granule = 1024
+        self._pack_plans = {}
         self.utterance_encoder = None
         if hp.has("utterance_encoder"):
             self.utterance_encoder = nn.Sequential(
@@ -152,6 +158,91 @@ class LVTR(nn.Module):
         lin = self.token_predictor.linear
         return dense_2d(hid.value, lin.weight, lin.bias, out_f32=True)
 
+    # ------------------------------------------------------------------ packed step
+    def pack_halo(self) -> int:
+        """Padded frames after a sequence's end that its valid frames depend on: the look-ahead taps of the diffusion
+        UNet's upward blocks (the posterior encoder and the downward blocks are causal)."""
+        nets = [self.encoder[0], self.decoder.model.unet]
+        return max(n.lookahead_frames() if hasattr(n, "lookahead_frames") else 0 for n in nets)
+
+    def packable(self) -> bool:
+        nets = [self.encoder[0], self.decoder.model.unet]
+        return (self.use_tokens and self.transformer_flow is not None and hipvg.compute_dtype() == torch.bfloat16
+                and all(hasattr(n, "packable") and n.packable() for n in nets)
+                and self.transformer[0].first_norm is None and os.environ.get("VG_CONV_STOCK", "0") != "1")
+
+    def _step_plan(self, B: int, T: int, lens, device):
+        rows = self.pack_rows
+        if rows is None or lens is None or not self.packable():
+            return None
+        halo = self.pack_halo()
+        M = B * T
+        if rows == "auto":
+            rows = HF.pack_rows_bucket(int(torch.clamp(lens + halo, max=T).sum().item()), self.pack_granule)
+        else:
+            rows = int(rows)
+            if not torch.cuda.is_current_stream_capturing():        # the caller's promise is cheap to check outside a capture
+                total = int(torch.clamp(lens + halo, max=T).sum().item())
+                npseudo = -(-min(rows, self.pack_granule or rows) // T)
+                if total > rows or rows - total > npseudo * T:
+                    return None
+        if rows > int(0.94 * M):
+            return None
+        key = (B, T, rows, device, halo)
+        plan = self._pack_plans.get(key)
+        if plan is None:
+            plan = HF.PackPlan(B, T, rows, device, self.pack_granule, halo=halo)
+            if plan.nseq > 64:
+                return None            # the packed conv kernels hold one sequence per lane
+            self._pack_plans[key] = plan
+        return plan.fill(lens)
+
+    def _forward_packed(self, plan, x: TensorMask, c, spkr, utterance, noise) -> Mapping:
+        """The whole training forward on the VALID frames of a ragged batch (the reference pads, utils/helpers.py:80-135,
+        and computes on the padding): the inputs are gathered into ``plan.rows`` rows -- every sequence's frames followed by
+        an 18-row halo of its padding (hipvg.functional.PackPlan) -- and handed to ``forward`` as a pseudo batch of
+        ``rows`` one-frame sequences whose mask says which rows hold a frame.  Row-local modules need nothing else
+        (``lengths = valid, T = 1`` is their row predicate); the four places with time structure read the plan from the
+        mask: the conv blocks (per-sequence zero padding), the Transformer stack (varlen attention), the one-frame shift
+        and the per-utterance vectors.  The outputs are scattered back to (B, T, .)."""
+        B, T = x.mask.shape
+        rows = plan.rows
+        noise = dict(noise or {})
+        v = x.value
+        ids_f = v[..., 0].reshape(-1)
+        sel = plan.idx.clamp(min=0).long()
+        ids_p = torch.where(plan.idx >= 0, ids_f[sel], torch.zeros((), dtype=v.dtype, device=v.device))
+        mel_p = HF.pack_rows(v[..., 1:].reshape(B * T, -1).contiguous(), plan)
+        xp = torch.cat([ids_p[:, None], mel_p], -1).view(rows, 1, -1)
+        mask_p = (plan.valid > 0)[:, None]
+        mask_p._vg_plan = plan
+        mask_p._vg_len32 = plan.valid
+        for k in ("eps_q", "eps_diff"):
+            if noise.get(k) is not None:
+                n2 = noise[k].reshape(B * T, -1).float().contiguous()
+                noise[k] = HF.pack_rows(n2, plan).view(rows, 1, -1)
+        out = self.forward(TensorMask(xp, mask_p), c, spkr, utterance, None, noise)
+        mask = x.mask
+
+        def back(t):
+            if isinstance(t, TensorMask):
+                val = t.value
+                flat = val.reshape(rows, -1) if val.dim() > 2 else val.reshape(rows, 1)
+                if (flat.shape[1] * flat.element_size()) % 16 == 0 and flat.is_floating_point():
+                    full = HF.unpack_rows(flat.contiguous(), plan)
+                else:
+                    inv = plan.inv.long()
+                    full = torch.where((inv >= 0)[:, None], flat[inv.clamp(min=0)], torch.zeros((), dtype=flat.dtype, device=flat.device))
+                return TensorMask(full.view(B, T, *val.shape[2:]), mask)
+            if isinstance(t, dict):
+                return {k: back(u) for k, u in t.items()}
+            return t
+
+        res = {k: back(u) for k, u in out.items() if k not in ("token_argmax", "logits", "lengths")}
+        res["token_argmax"] = back(TensorMask(out["token_argmax"].view(rows, 1, 1), mask_p)).value.view(B, T)
+        res["logits"] = back(TensorMask(out["logits"].view(rows, 1, -1), mask_p)).value
+        return res
+
     # ------------------------------------------------------------------ training forward
     def forward(self, x: TensorMask, c: Optional[TensorMask] = None, spkr=None,
                 utterance: Optional[TensorMask] = None, diff_input: Optional[TensorMask] = None,
@@ -162,6 +253,12 @@ class LVTR(nn.Module):
         mask, lens = x.mask, x.lengths32
         B, T = mask.shape
         D = self.hp.latent_dim
+        plan = getattr(mask, "_vg_plan", None)      # set: this IS the packed pseudo batch (see _forward_packed)
+        if plan is None and diff_input is None and x.value.is_cuda and self.pack_rows is not None:
+            step_plan = self._step_plan(B, T, lens, x.value.device)
+            if step_plan is not None:
+                return self._forward_packed(step_plan, x, c, spkr, utterance, noise)
+        nseq = plan.B if plan is not None else B      # real sequences (per-utterance vectors, start frames, diffusion steps)
         # token embedding + token_fuser + add as one row kernel when the configuration is the yaml's (ReLU fuser,
         # fp32 embedding table); the module path below is the general one
         fuser = self.token_fuser
@@ -218,8 +315,11 @@ class LVTR(nn.Module):
             fused = TensorMask(leaf, fused.mask)
         init = noise.get("init_state")
         if init is None:
-            init = self.initial_state(B, mel.device)
-        shifted = fused.push(init.to(fused.value.dtype)).pop(1).apply_mask()
+            init = self.initial_state(nseq, mel.device)
+        if plan is not None:
+            shifted = TensorMask(HF.shift_rows(fused.value.reshape(B * T, -1), init, plan).view(B, T, -1), mask)
+        else:
+            shifted = fused.push(init.to(fused.value.dtype)).pop(1).apply_mask()
         latent = self.transformer[0](shifted, c)
         cond, mu_ls_p = self._prior_stats(latent)
         # ---- flow + prior log-density + KL (fused row kernel)
@@ -241,10 +341,16 @@ class LVTR(nn.Module):
         with _side_autocast():
             if self.utterance_encoder is not None:
                 u_c = self.utterance_encoder(utterance).float()
-                diffusion_input = diffusion_input.cat(u_c[:, None].expand(-1, T, -1))
+                if plan is not None:
+                    diffusion_input = diffusion_input.cat(HF.seq_rows(u_c, plan)[:, None])
+                else:
+                    diffusion_input = diffusion_input.cat(u_c[:, None].expand(-1, T, -1))
             target = mel if diff_input is None else diff_input
+            t_diff = noise.get("t_diff")
+            if t_diff is None and plan is not None:        # one diffusion step per SEQUENCE (the pseudo batch has `rows`)
+                t_diff = torch.randint(0, self.decoder.num_timesteps, (nseq,), device=mel.device).long()
             rec = self.decoder(target / self.diff_scaling, diffusion_input,
-                               t=noise.get("t_diff"), noise=noise.get("eps_diff"))
+                               t=t_diff, noise=noise.get("eps_diff"))
         mu_p, ls_p = mu_ls_p[..., :D], mu_ls_p[..., D:]
         # the monitors (TensorMask.mean() of the prior / posterior statistics, |posterior mean|, log p, log q): one launch
         # for all seven instead of five stock launches each; the stock expressions remain the fallback

@@ -91,10 +91,11 @@ class BottleneckBlock(nn.Module):
     def hip_ready(self) -> bool:
         return isinstance(self.norm, InstanceNorm) and hip_act_id(self.act) in ("relu", "silu")
 
-    def forward_rows(self, x2: torch.Tensor, T: int, cond2: Optional[torch.Tensor],
+    def forward_rows(self, x2: torch.Tensor, T, cond2: Optional[torch.Tensor],
                      temb: Optional[torch.Tensor], te: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Channels-last HIP path: x2 [B*T, C] in the compute dtype.  ``te``: this block's time-embedding
-        projection if the caller already computed it (one batched GEMM for all blocks)."""
+        projection if the caller already computed it (one batched GEMM for all blocks).  ``T``: frames per sequence,
+        or a ``hipvg.functional.PackPlan`` (packed rows: ragged sequences laid end to end, ``te`` per real sequence)."""
         if te is None:
             te = self.time_emb(self.act(temb)) if self.has_time else None
         return HF.conv_block(x2, te, cond2 if self.has_cond else None, self.conv1.weight, self.conv1.bias,
@@ -154,6 +155,17 @@ class BottleNeckResNet(nn.Module):
         self.final_norm = get_norm_fn(widths[-1], hp.layer.norm) if hp.get("final_norm", False) else None
         self.first_norm = get_norm_fn(widths[0], hp.layer.norm) if hp.get("first_norm", False) else None
 
+    def packable(self) -> bool:
+        """Can this stack run on packed rows (hipvg.functional.PackPlan with a halo)?  Every block on the run kernels
+        (bf16, 512 channels, 7 taps), per-frame norms only."""
+        norms_ok = all(n is None or isinstance(n, InstanceNorm) for n in (self.final_norm, self.first_norm))
+        return (norms_ok and hipvg.compute_dtype() == torch.bfloat16
+                and all(b.hip_ready() and b.taps == 7 and b.conv1.in_channels == 512 for b in self.layers))
+
+    def lookahead_frames(self) -> int:
+        """Frames after a sequence's end that its valid frames depend on (the halo a packed layout must carry)."""
+        return sum(b.taps - 1 - b.shift for b in self.layers)
+
     def _hip_ok(self, x: TensorMask) -> bool:
         norms_ok = all(n is None or isinstance(n, InstanceNorm) for n in (self.final_norm, self.first_norm))
         return (x.value.is_cuda and os.environ.get("VG_CONV_STOCK", "0") != "1" and norms_ok
@@ -164,6 +176,10 @@ class BottleNeckResNet(nn.Module):
         row kernels, skip connections as two accumulating GEMMs (no concat, no transposes)."""
         mask, lens = x.mask, x.lengths32
         B, T = mask.shape
+        # packed rows (LVTR.forward's packed step): the batch is a pseudo batch of B = rows one-frame sequences whose
+        # mask says which rows hold a frame; the time structure is the plan's
+        plan = getattr(mask, "_vg_plan", None)
+        Tseq = plan if plan is not None else T
         dt = hipvg.compute_dtype()
         h = x.value.reshape(B * T, -1)
         if self.linear is not None:
@@ -187,7 +203,7 @@ class BottleNeckResNet(nn.Module):
             for i, piece in zip(timed, F.linear(a, W, bvec).split(sizes, dim=1)):
                 tes[i] = piece
         for i, block in enumerate(self.layers):
-            h = block.forward_rows(h, T, cond2 if self.conditional[i] else None,
+            h = block.forward_rows(h, Tseq, cond2 if self.conditional[i] else None,
                                    temb if self.time_dim is not None else None, tes.get(i))
             src = self.skip_connection[i]
             if src is not None:

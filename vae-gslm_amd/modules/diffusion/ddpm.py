@@ -96,8 +96,11 @@ class GaussianDiffusion1D(nn.Module):
             from hipvg import functional as HF
             B, T, C = xv.shape
             lens = x_start.lengths32
+            plan = getattr(x_start.mask, "_vg_plan", None)
+            # packed rows (a pseudo batch of one-frame sequences): the diffusion step of a row is its sequence's
+            t_row = t if plan is None else t[plan.seq.clamp(max=plan.B - 1).long()]
             x_t = HF.qsample(xv.reshape(B * T, C), noise.reshape(B * T, C), self.sqrt_alphas_cumprod,
-                             self.sqrt_one_minus_alphas_cumprod, t, lens, T)
+                             self.sqrt_one_minus_alphas_cumprod, t_row, lens, T)
             pred = self.model(TensorMask(x_t.view(B, T, C), x_start.mask), t, cond, **kwargs)
             return HF.masked_l1_sum(pred.value.reshape(B * T, C), noise.reshape(B * T, C), lens, T)
         x_t = TensorMask(self.q_sample(x_start.value, t, noise), x_start.mask).apply_mask()

@@ -168,11 +168,15 @@ class TransformerLayerStack(nn.Module):
             x2 = self._norm2d(self.first_norm, x2, lens, T, masked=True)
         fast = past_kv is None and not return_attn and not return_kv
         layer_outs = []
-        plan = self._pack_plan(B, T, lens, x2) if fast else None
+        # rows that arrive packed (LVTR.forward's packed step: a pseudo batch of one-frame sequences, the time structure
+        # in the plan that rides on the mask): no gather here, no scatter at the end
+        given = getattr(mask, "_vg_plan", None) if fast and self.first_norm is None else None
+        plan = given if given is not None else (self._pack_plan(B, T, lens, x2) if fast else None)
+        Bl, Tl = (plan.B, plan.T) if given is not None else (B, T)
         if fast:
             slopes = _slopes_from((self.rpe_id, self.rpe), None, x2.device).slopes
             cut = getattr(self, "grad_cut_layer", None)
-            if plan is not None:
+            if plan is not None and given is None:
                 # the stack runs on the valid frames only (the padded ones are zero rows that every layer re-masks in
                 # the reference, utils/tensormask.py:63-67): gather once here, scatter back after the final norm
                 x2 = HF.pack_rows(x2, plan)
@@ -183,7 +187,7 @@ class TransformerLayerStack(nn.Module):
                     leaf = x2.detach().requires_grad_(True)
                     self.grad_cuts.append(((x2,), (leaf,)))
                     x2 = leaf
-                x2 = layer.forward_2d(x2, B, T, lens, slopes, plan)
+                x2 = layer.forward_2d(x2, Bl, Tl, lens, slopes, plan)
                 if plan is None:
                     layer_outs.append(TensorMask(x2.view(B, T, D), mask))
         else:
@@ -205,10 +209,10 @@ class TransformerLayerStack(nn.Module):
         if self.final_norm is not None:
             # the reference does not re-mask here (:186-189); zero rows stay zero under RMSNorm
             x2 = self._norm2d(self.final_norm, x2, lens, T, masked=plan is None)
-            if plan is not None:
+            if plan is not None and given is None:
                 x2 = HF.unpack_rows(x2, plan)
             layer_outs.append(TensorMask(x2.view(B, T, D), mask))
-        elif plan is not None:
+        elif plan is not None and given is None:
             x2 = HF.unpack_rows(x2, plan)
         if self.out is not None:
             x2 = HF.linear(x2, self.out.weight, self.out.bias, lengths=lens, T=T)

@@ -71,6 +71,12 @@ class LVTRTrainer(BaseTrainer):
         # hip.packed_rows: the Transformer stack of a ragged batch runs on its valid frames only
         self.packed_rows = bool(hip.get("packed_rows", False)) if hip is not None else False
         self.packed_granule = int(hip.get("packed_rows_granule", 1024)) if hip is not None else 1024
+        # hip.packed_step: the WHOLE step of a ragged batch on its valid frames (conv stacks, heads and losses too; every
+        # sequence carries an 18-frame halo of its padding for the UNet's look-ahead blocks, models.speech.lvtr.
+        # LVTR._forward_packed); falls back to packed_rows / padded rows when a batch or the build cannot take it
+        self.packed_step = bool(hip.get("packed_step", False)) if hip is not None else False
+        if os.environ.get("VG_PACKED_STEP") is not None:
+            self.packed_step = os.environ["VG_PACKED_STEP"] == "1"
         self._held = []
         self._clean_epoch = None       # hipvg.functional.write_epoch() at the moment the gradients were last cleared
         self._watched = False
@@ -419,17 +425,23 @@ class LVTRTrainer(BaseTrainer):
 
     # ------------------------------------------------------------ packed rows
     def _choose_pack_rows(self, batch: Optional[Mapping], eager: bool = False):
-        """Sets ``TransformerLayerStack.pack_rows`` for the coming forward and returns it (None: padded rows)."""
+        """Sets ``LVTR.pack_rows`` (packed step) or ``TransformerLayerStack.pack_rows`` for the coming forward and returns
+        the choice (None: padded rows) -- it is part of a hipGraph's key."""
         stack = self.model.transformer[0] if hasattr(self.model, "transformer") else None
         if stack is None or not hasattr(stack, "pack_rows"):
             return None
         rows = None
         stack.pack_granule = self.packed_granule
-        if self.packed_rows and batch is not None:
+        step_ok = self.packed_step and hasattr(self.model, "packable") and self.model.packable() and "cropped_mel" not in (batch or {})
+        if hasattr(self.model, "pack_rows"):
+            self.model.pack_rows, self.model.pack_granule = None, self.packed_granule
+        if (self.packed_rows or step_ok) and batch is not None:
             tm = batch.get("tokens", batch.get("mel"))
             if tm is not None and not getattr(tm.mask, "_vg_full", False):
                 if eager:
                     rows = "auto"
+                    if step_ok:
+                        self.model.pack_rows = "auto"      # (a batch it declines falls through to the stack's own packing)
                 else:
                     from hipvg import functional as HF
                     B, T = tm.mask.shape[:2]
@@ -438,15 +450,30 @@ class LVTRTrainer(BaseTrainer):
                     total = getattr(tm.mask, "_vg_valid", None)
                     if total is None:
                         total = int(tm.mask.sum().item())
-                    cand = HF.pack_rows_bucket(int(total), self.packed_granule)
-                    rows = cand if cand <= int(0.94 * B * T) else None
-        stack.pack_rows = rows
+                    if step_ok:
+                        # + the halo rows: min(len + halo, T) per sequence needs the lengths; the bound len + halo is
+                        # within a granule of it and a bucket only has to be large enough
+                        halo = self.model.pack_halo()
+                        lens = tm.mask.sum(-1)
+                        need = int(torch.clamp(lens + halo, max=T).sum().item())
+                        cand = HF.pack_rows_bucket(need, self.packed_granule)
+                        nseq = B + -(-min(cand, self.packed_granule) // T)
+                        if cand <= int(0.94 * B * T) and nseq <= 64:
+                            self.model.pack_rows = cand
+                            stack.pack_rows = None
+                            return ("step", cand)
+                    if self.packed_rows:
+                        cand = HF.pack_rows_bucket(int(total), self.packed_granule)
+                        rows = cand if cand <= int(0.94 * B * T) else None
+        stack.pack_rows = rows if self.packed_rows else None
         return rows
 
     def _clear_pack_rows(self) -> None:
         stack = self.model.transformer[0] if hasattr(self.model, "transformer") else None
         if stack is not None and hasattr(stack, "pack_rows"):
             stack.pack_rows = None
+        if hasattr(self.model, "pack_rows"):
+            self.model.pack_rows = None
 
     # ------------------------------------------------------------ hipGraph replay of a micro-step
     def _pad_for_graph(self, batch: Mapping) -> Mapping:
