@@ -458,6 +458,8 @@ class LVTRTrainer(BaseTrainer):
                         need = int(torch.clamp(lens + halo, max=T).sum().item())
                         cand = HF.pack_rows_bucket(need, self.packed_granule)
                         nseq = B + -(-min(cand, self.packed_granule) // T)
+                        if os.environ.get("VG_DEBUG_PACK"):
+                            print(f"[packed step] B={B} T={T} need={need} bucket={cand} nseq={nseq} limit={int(0.94 * B * T)}", flush=True)
                         if cand <= int(0.94 * B * T) and nseq <= 64:
                             self.model.pack_rows = cand
                             stack.pack_rows = None
