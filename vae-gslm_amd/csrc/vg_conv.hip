@@ -581,8 +581,13 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
 // run-based backward through the depthwise convolution: dx[t] = dx_add[t] + sum_k w[c][k] du[t - (k - shift)] from one
 // 14-row window of du, then the tap gradients wpart[block][c][k] = sum_rows du[t] x[t + k - shift] from one 14-row
 // window of x and the run's own 8 du rows.
+// (one wave per SIMD: 256 VGPRs + 22 AGPRs.  Forced to two -- 31 registers spilled -- the kernel is slower, 24.4 -> 29.3 us at
+// 16000 x 512, tools/lab/dw_bwd_probe.py, round 5.)
+#ifndef VG_DW_BWDCONV_OCC
+#define VG_DW_BWDCONV_OCC 1
+#endif
 template <int TAPS, int RF>
-__global__ __launch_bounds__(256) void dwnorm_bwd_conv_run_kernel(const bf16_t* __restrict__ du, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, VG_DW_BWDCONV_OCC) void dwnorm_bwd_conv_run_kernel(const bf16_t* __restrict__ du, const bf16_t* __restrict__ x,
                                                                   const float* __restrict__ w,
                                                                   const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ dx,
                                                                   float* __restrict__ wpart, DwArgs a) {
