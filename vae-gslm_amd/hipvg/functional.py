@@ -90,14 +90,63 @@ _SPLIT_WS = {}
 
 
 def _split_workspace(device):
-    """Per-device scratch of the in-launch split-K reduction (fp32 slabs + tile counters).  Launches on one
-    stream serialise, so they share it; 64 MiB covers every weight gradient of the full config."""
-    ent = _SPLIT_WS.get(device)
+    """Scratch of the in-launch split-K reduction (fp32 slabs + tile counters), per device and per SIDE stream.  Launches
+    on one stream serialise, so they share it; 64 MiB covers every weight gradient of the full config (the side branch
+    of the step -- side_stream() -- has its own, smaller one: its launches overlap the main stream's)."""
+    side = on_side_stream()
+    key = (device, stream()) if side else device
+    ent = _SPLIT_WS.get(key)
     if ent is None:
-        ent = (torch.empty(16 << 20, dtype=torch.float32, device=device),
+        ent = (torch.empty((2 << 20) if side else (16 << 20), dtype=torch.float32, device=device),
                torch.zeros(4096, dtype=torch.int32, device=device))
-        _SPLIT_WS[device] = ent
+        _SPLIT_WS[key] = ent
     return ent
+
+
+# ---------------------------------------------------------------- the side branch of the training step
+# The utterance encoder and the diffusion decoder's time-embedding MLPs are ~100 launches of a few microseconds each,
+# forward and backward, that depend on nothing the main chain computes until the UNet reads their results: on a second
+# HIP stream (forked and joined with stream waits, so a hipGraph capture records two parallel branches) they run under
+# the Transformer stack instead of in front of the UNet.  Autograd runs a node's backward on the stream of its forward,
+# so their backward runs under the Transformer stack's backward as well.  What is shared with the main stream is kept
+# apart: the split-K scratch (above), the deferral queues (a product issued from the side stream launches at once), and
+# "gradient ready" reports (delivered on the main stream after it has waited for the side stream).
+_SIDE = {"streams": {}, "ids": {}}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    dev = torch.device(device)
+    st = _SIDE["streams"].get(dev)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _SIDE["streams"][dev] = st
+        _SIDE["ids"][st.cuda_stream] = st
+    return st
+
+
+def on_side_stream() -> bool:
+    return bool(_SIDE["ids"]) and torch.cuda.is_available() and torch.cuda.current_stream().cuda_stream in _SIDE["ids"]
+
+
+_MAIN_OF_SIDE = {}
+
+
+def fork_side(device):
+    """-> (side, main): the side stream now waits for everything queued on the current stream."""
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device)
+    side.wait_stream(main)
+    _MAIN_OF_SIDE[side.cuda_stream] = main
+    return side, main
+
+
+def join_side(side, main, tensors=()) -> None:
+    """The current (main) stream waits for the side stream; ``tensors`` were allocated there and are read here."""
+    main.wait_stream(side)
+    for t in tensors:
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(main)
+
 
 
 def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False,
@@ -344,7 +393,7 @@ def sink_wgrad_group(items, fire: bool = True, tag: str = "misc") -> None:
     if not items:
         return
     ok = _PH_GROUP and len(items) <= GROUP_MAX and all(_wgrad_item_ok(*it) for it in items)
-    if ok and _WDEFER["on"]:
+    if ok and _WDEFER["on"] and not on_side_stream():
         _wgrad_enqueue(items, fire, tag)
         return
     if ok and len({it[2].shape[0] for it in items}) == 1:
@@ -442,7 +491,7 @@ def vec_grad(p, src2d: Tensor):
     if p is None:
         return None
     if _sinkable(p):
-        if _DEFER["on"] and src2d.dim() == 2:
+        if _DEFER["on"] and src2d.dim() == 2 and not on_side_stream():
             if _small_f32(src2d, p.numel()):
                 _defer_task(p, src2d)
                 return None
@@ -470,7 +519,7 @@ def vec_grads(pairs):
         if not ok:
             out[i] = vec_grad(p, src)
             continue
-        if _DEFER["on"] and _sinkable(p):
+        if _DEFER["on"] and _sinkable(p) and not on_side_stream():
             _defer_task(p, src)
             continue
         if _sinkable(p):
@@ -1258,7 +1307,19 @@ def _grad_buffer(p: Tensor) -> Tensor:
 def _fire(p: Tensor) -> None:
     p._vg_sunk = True            # this parameter's gradient is written by the library, not by AccumulateGrad
     _WPASS["epoch"] += 1         # (a library write outside any trainer pass also ends "the buffers hold zeros")
-    for h in getattr(p, "_vg_grad_hooks", ()):
+    hooks = getattr(p, "_vg_grad_hooks", ())
+    if hooks and on_side_stream():
+        # written from the side branch: whoever acts on the report (the reducer puts buckets on the wire behind the
+        # CURRENT stream) must see this write -- report on the main stream, after it has waited for the side stream
+        side = torch.cuda.current_stream()
+        main = _MAIN_OF_SIDE.get(side.cuda_stream)
+        if main is not None:
+            main.wait_stream(side)
+            with torch.cuda.stream(main):
+                for h in hooks:
+                    h(p)
+            return
+    for h in hooks:
         h(p)
 
 
@@ -1269,7 +1330,7 @@ def sink_wgrad(p: Tensor, dy: Tensor, x: Tensor, bias: Optional[Tensor] = None, 
     N = p.shape[0]
     K = p.numel() // N
     M = x.shape[0]
-    if (bias is None and _WDEFER["on"] and x.dim() == 2 and x.shape[1] == K and p.is_contiguous()
+    if (bias is None and _WDEFER["on"] and not on_side_stream() and x.dim() == 2 and x.shape[1] == K and p.is_contiguous()
             and _wgrad_item_ok(p, dy, x, 0)):
         _wgrad_enqueue([(p, dy, x, 0)], fire, "misc")      # leaves with the other products of this backward piece
         return

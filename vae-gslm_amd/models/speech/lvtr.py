@@ -259,6 +259,20 @@ class LVTR(nn.Module):
             if step_plan is not None:
                 return self._forward_packed(step_plan, x, c, spkr, utterance, noise)
         nseq = plan.B if plan is not None else B      # real sequences (per-utterance vectors, start frames, diffusion steps)
+        # ---- side branch (hipvg.functional.fork_side): the utterance encoder and the decoder's time-embedding MLPs depend on
+        # nothing computed below until the UNet reads them; on a second stream they (and, through autograd, their
+        # backward) run under the Transformer stack
+        side = None
+        if (os.environ.get("VG_SIDE_STREAM", "1") != "0" and x.value.is_cuda and diff_input is None and utterance is not None
+                and self.utterance_encoder is not None and hasattr(self.decoder.model, "time_embedding")):
+            t_diff = noise.get("t_diff")
+            if t_diff is None:
+                t_diff = torch.randint(0, self.decoder.num_timesteps, (nseq,), device=x.value.device).long()
+            side, main = HF.fork_side(x.value.device)
+            with torch.cuda.stream(side), _side_autocast():
+                u_c_side = self.utterance_encoder(utterance).float()
+                temb_side = self.decoder.model.time_embedding(t_diff)
+                tes_side = self.decoder.model.unet.time_projections(temb_side.float())
         # token embedding + token_fuser + add as one row kernel when the configuration is the yaml's (ReLU fuser,
         # fp32 embedding table); the module path below is the general one
         fuser = self.token_fuser
@@ -338,9 +352,15 @@ class LVTR(nn.Module):
             with _side_autocast():
                 diffusion_input = self.fuse_inputs(self.encoder(diff_input).sample, tokens)
         u_c = None
+        dec_kw = {}
+        if side is not None:
+            HF.join_side(side, main, [u_c_side, temb_side, *tes_side.values()])
+            dec_kw = {"temb": temb_side, "tes": tes_side}
+            noise = dict(noise)
+            noise["t_diff"] = t_diff
         with _side_autocast():
             if self.utterance_encoder is not None:
-                u_c = self.utterance_encoder(utterance).float()
+                u_c = u_c_side if side is not None else self.utterance_encoder(utterance).float()
                 if plan is not None:
                     diffusion_input = diffusion_input.cat(HF.seq_rows(u_c, plan)[:, None])
                 else:
@@ -350,7 +370,7 @@ class LVTR(nn.Module):
             if t_diff is None and plan is not None:        # one diffusion step per SEQUENCE (the pseudo batch has `rows`)
                 t_diff = torch.randint(0, self.decoder.num_timesteps, (nseq,), device=mel.device).long()
             rec = self.decoder(target / self.diff_scaling, diffusion_input,
-                               t=t_diff, noise=noise.get("eps_diff"))
+                               t=t_diff, noise=noise.get("eps_diff"), **dec_kw)
         mu_p, ls_p = mu_ls_p[..., :D], mu_ls_p[..., D:]
         # the monitors (TensorMask.mean() of the prior / posterior statistics, |posterior mean|, log p, log q): one launch
         # for all seven instead of five stock launches each; the stock expressions remain the fallback

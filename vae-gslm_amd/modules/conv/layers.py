@@ -171,7 +171,22 @@ class BottleNeckResNet(nn.Module):
         return (x.value.is_cuda and os.environ.get("VG_CONV_STOCK", "0") != "1" and norms_ok
                 and all(b.hip_ready() for b in self.layers))
 
-    def forward_hip(self, x: TensorMask, c: Optional[TensorMask], t: Optional[torch.Tensor]) -> TensorMask:
+    def time_projections(self, temb: Optional[torch.Tensor]) -> dict:
+        """Time-embedding projections of all blocks as ONE Linear: same SiLU(t) for every block, the six (256 -> 512)
+        weights concatenated along N (6 x ~14 tiny launches forward + backward become ~17).  {block index: [B, C]}."""
+        tes = {}
+        timed = [i for i, b in enumerate(self.layers) if b.has_time] if (temb is not None and self.time_dim is not None) else []
+        if (len(timed) > 1 and len({type(self.layers[i].act) for i in timed}) == 1
+                and os.environ.get("VG_BATCH_TEMB", "1") != "0"):
+            a = self.layers[timed[0]].act(temb)
+            W = torch.cat([self.layers[i].time_emb.weight for i in timed], 0)
+            bvec = torch.cat([self.layers[i].time_emb.bias for i in timed], 0)
+            sizes = [self.layers[i].time_emb.out_features for i in timed]
+            for i, piece in zip(timed, F.linear(a, W, bvec).split(sizes, dim=1)):
+                tes[i] = piece
+        return tes
+
+    def forward_hip(self, x: TensorMask, c: Optional[TensorMask], t: Optional[torch.Tensor], tes: Optional[dict] = None) -> TensorMask:
         """Same computation on [B*T, C] rows: 1x1 convs on the MFMA GEMM, fused depthwise-conv+norm
         row kernels, skip connections as two accumulating GEMMs (no concat, no transposes)."""
         mask, lens = x.mask, x.lengths32
@@ -190,18 +205,8 @@ class BottleNeckResNet(nn.Module):
         cond2 = None if c is None else c.value.reshape(B * T, -1).to(dt).contiguous()
         temb = None if t is None else t.float()
         history = [h]
-        # time-embedding projections of all blocks as ONE Linear: same SiLU(t) for every block, the six
-        # (256 -> 512) weights concatenated along N (6 x ~14 tiny launches forward + backward become ~17)
-        tes = {}
-        timed = [i for i, b in enumerate(self.layers) if b.has_time] if (temb is not None and self.time_dim is not None) else []
-        if (len(timed) > 1 and len({type(self.layers[i].act) for i in timed}) == 1
-                and os.environ.get("VG_BATCH_TEMB", "1") != "0"):
-            a = self.layers[timed[0]].act(temb)
-            W = torch.cat([self.layers[i].time_emb.weight for i in timed], 0)
-            bvec = torch.cat([self.layers[i].time_emb.bias for i in timed], 0)
-            sizes = [self.layers[i].time_emb.out_features for i in timed]
-            for i, piece in zip(timed, F.linear(a, W, bvec).split(sizes, dim=1)):
-                tes[i] = piece
+        if tes is None:
+            tes = self.time_projections(temb)
         for i, block in enumerate(self.layers):
             h = block.forward_rows(h, Tseq, cond2 if self.conditional[i] else None,
                                    temb if self.time_dim is not None else None, tes.get(i))
@@ -223,10 +228,11 @@ class BottleNeckResNet(nn.Module):
         return TensorMask(h.view(B, T, -1), mask).apply_mask()
 
     def forward(self, x: TensorMask, c: Optional[TensorMask] = None,
-                t: Optional[torch.Tensor] = None) -> TensorMask:
-        """x: (B, T, C) TensorMask; c: (B, T, Cc) TensorMask; t: (B, time_dim)."""
+                t: Optional[torch.Tensor] = None, tes: Optional[dict] = None) -> TensorMask:
+        """x: (B, T, C) TensorMask; c: (B, T, Cc) TensorMask; t: (B, time_dim); tes: ``time_projections(t)`` if the caller
+        already has them (computed on the step's side branch)."""
         if self._hip_ok(x):
-            return self.forward_hip(x, c, t)
+            return self.forward_hip(x, c, t, tes)
         mask = x.mask
         h = x.value
         if self.linear is not None:

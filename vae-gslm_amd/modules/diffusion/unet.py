@@ -38,8 +38,9 @@ class ConditionalBottleNeckUNet(nn.Module):
         self.time_embedding = TimeEmbedding(hp.time_embedding)
         self.unet = BottleNeckResNet(hp.unet, input_dim=noise_dim, output_dim=noise_dim)
 
-    def forward(self, noise: TensorMask, t: torch.Tensor, cond: TensorMask) -> TensorMask:
-        """noise, cond: (B, T, C) TensorMasks; t: (B,) integer diffusion steps."""
+    def forward(self, noise: TensorMask, t: torch.Tensor, cond: TensorMask, temb=None, tes=None) -> TensorMask:
+        """noise, cond: (B, T, C) TensorMasks; t: (B,) integer diffusion steps.  ``temb`` / ``tes``: the time embedding and
+        the blocks' projections of it when the caller computed them ahead (LVTR.forward's side branch)."""
         if cond.value.is_cuda and cond.value.dim() == 3:
             # conditioning projection (cond_dim -> 32) through the HIP GEMM: the mask is its epilogue's row predicate
             from modules.linear.layers import dense_2d
@@ -47,4 +48,4 @@ class ConditionalBottleNeckUNet(nn.Module):
                                     T=cond.value.shape[1]), cond.mask)
         else:
             c = TensorMask(self.cond_net(cond.value), cond.mask).apply_mask()
-        return self.unet(noise, c, self.time_embedding(t))
+        return self.unet(noise, c, self.time_embedding(t) if temb is None else temb, tes)
