@@ -36,6 +36,21 @@ def _vocoder_hparams(path: str) -> Hparams:
     return Hparams(n_mels=80, sample_rate=16000)
 
 
+class _WeightedSum(torch.autograd.Function):
+    """sum_i w[i] * term_i for scalar terms: a stack and a dot product; the backward hands every term g * w[i]."""
+
+    @staticmethod
+    def forward(ctx, w, *terms):
+        ctx.save_for_backward(w)
+        ctx.shapes = [t.shape for t in terms]
+        return torch.dot(torch.stack([t.reshape(()) for t in terms]), w)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return (None, *(gi.reshape(sh) for gi, sh in zip((g * w).unbind(0), ctx.shapes)))
+
+
 class LVTRTrainer(BaseTrainer):
     def __init__(self, hp: Hparams) -> None:
         super().__init__(hp)
@@ -241,14 +256,31 @@ class LVTRTrainer(BaseTrainer):
         if self.use_tokens:
             model_input = batch["tokens"].expand().cat(batch["mel"])
         out = self.model(model_input, noise=noise, **kwargs)
-        kld = out["kld"] * self.entropy_weight if self.entropy_weight == 1.0 else None
+        kld = out["kld"] if self.entropy_weight == 1.0 else None
         if kld is None:   # non-default entropy weighting: generic path
             from training_lib.losses import masked_loss
             kld = masked_loss(out["log_q"] * self.entropy_weight, out["log_p"], fn=lambda a, b: a - b)
         rec = out["decoder_output"]
-        loss = rec * self.rec_loss_scale + kld * kld_weight
-        if self.use_tokens:
-            loss = loss + out["ce_loss"] * (self.token_kld_weight * kld_weight)
+        # loss = rec * rec_scale + kld * w + ce * token_kld_weight * w as ONE weighted sum (a stack + a dot forward, one
+        # product backward) instead of seven scalar launches forward and as many backward; the KL weight may be the
+        # device scalar of a captured step (it changes from replay to replay)
+        terms = [rec, kld] + ([out["ce_loss"]] if self.use_tokens else [])
+        base = [float(self.rec_loss_scale), 1.0] + ([float(self.token_kld_weight)] if self.use_tokens else [])
+        if (os.environ.get("VG_LOSS_DOT", "1") != "0" and all(torch.is_tensor(t) and t.is_cuda and t.numel() == 1 and t.dtype == torch.float32
+                                                                for t in terms)):
+            dev = rec.device
+            key = (dev, tuple(base))
+            cache = self.__dict__.setdefault("_loss_w", {})
+            if key not in cache:      # [rec_scale, 0, 0] + w * [0, 1, token_kld_weight]
+                cache[key] = (torch.tensor([base[0]] + [0.0] * (len(base) - 1), device=dev),
+                              torch.tensor([0.0] + base[1:], device=dev))
+            fixed, scaled = cache[key]
+            kw = kld_weight if torch.is_tensor(kld_weight) else float(kld_weight)
+            loss = _WeightedSum.apply(torch.addcmul(fixed, scaled, kw) if torch.is_tensor(kw) else fixed + scaled * kw, *terms)
+        else:
+            loss = rec * self.rec_loss_scale + kld * kld_weight
+            if self.use_tokens:
+                loss = loss + out["ce_loss"] * (self.token_kld_weight * kld_weight)
         if self.reducer is not None:
             # the set of inputs decides which sub-networks run how often (``cropped_mel`` sends the posterior
             # encoder and the token fuser through a second time), hence how often each parameter reports
