@@ -6,6 +6,7 @@ timeout 200 python bench.py --seq-len 640 --no-cpu-baseline > $O/bench_T640.json
 timeout 300 python bench.py --seq-len 2000 --no-cpu-baseline > $O/bench_T2000.json 2>/dev/null
 timeout 200 python bench.py --ragged --no-cpu-baseline > $O/bench_ragged.json 2>/dev/null
 timeout 200 python bench.py --ragged --packed-rows 0 --no-cpu-baseline > $O/bench_ragged_padded.json 2>/dev/null
+timeout 200 python bench.py --ragged --packed-step 1 --no-cpu-baseline > $O/bench_ragged_packed_step.json 2>/dev/null
 timeout 200 python bench.py --coalesce 0 --no-cpu-baseline > $O/bench_nocoalesce.json 2>/dev/null
 timeout 200 python bench.py --host-batches --no-cpu-baseline > $O/bench_hostbatches.json 2>/dev/null
 timeout 200 python bench.py --mode decode > $O/decode_B8.json 2>/dev/null

@@ -21,5 +21,8 @@ SHAPES=16x1000 ITERS=5 python3 tools/lab/pmc_any.py $O/raw/pmc_attn attn2_fwd,at
 cp $O/raw/pmc_attn/summary.json $O/pmc_attn_sq.json 2>/dev/null
 SHAPE=ffn_out PMC_GROUPS=0,1 python3 tools/lab/pmc_any.py $O/raw/pmc_gemm_k4096 gemm_ph_kernel -- python3 tools/lab/one_gemm.py > $O/pmc_gemm_sq_k4096.txt 2>&1
 SHAPE=qkv PMC_GROUPS=0,1 python3 tools/lab/pmc_any.py $O/raw/pmc_gemm_k1024 gemm_ph_kernel -- python3 tools/lab/one_gemm.py > $O/pmc_gemm_sq_k1024.txt 2>&1
+( cd /tmp; export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw/listing -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 )
+python3 tools/lab/step_listing.py $O/raw/listing $O/step_listing.txt > $O/step_table_replayed_graph.txt 2>&1
+python3 tools/lab/small_runs.py $O/raw/listing > $O/small_launches.txt 2>&1
 rm -rf $O/raw
 ls -la $O
