@@ -263,8 +263,12 @@ class LVTR(nn.Module):
         # nothing computed below until the UNet reads them; on a second stream they (and, through autograd, their
         # backward) run under the Transformer stack
         side = None
-        if (os.environ.get("VG_SIDE_STREAM", "1") != "0" and x.value.is_cuda and diff_input is None and utterance is not None
-                and self.utterance_encoder is not None and hasattr(self.decoder.model, "time_embedding")):
+        side_ok = (os.environ.get("VG_SIDE_STREAM", "1") != "0" and x.value.is_cuda and diff_input is None and utterance is not None
+                   and self.utterance_encoder is not None and hasattr(self.decoder.model, "time_embedding"))
+        side_late = os.environ.get("VG_SIDE_FORK", "early") == "late"
+
+        def run_side():
+            nonlocal side, main, t_diff, u_c_side, temb_side, tes_side
             t_diff = noise.get("t_diff")
             if t_diff is None:
                 t_diff = torch.randint(0, self.decoder.num_timesteps, (nseq,), device=x.value.device).long()
@@ -273,6 +277,10 @@ class LVTR(nn.Module):
                 u_c_side = self.utterance_encoder(utterance).float()
                 temb_side = self.decoder.model.time_embedding(t_diff)
                 tes_side = self.decoder.model.unet.time_projections(temb_side.float())
+
+        main = t_diff = u_c_side = temb_side = tes_side = None
+        if side_ok and not side_late:
+            run_side()
         # token embedding + token_fuser + add as one row kernel when the configuration is the yaml's (ReLU fuser,
         # fp32 embedding table); the module path below is the general one
         fuser = self.token_fuser
@@ -334,6 +342,8 @@ class LVTR(nn.Module):
             shifted = TensorMask(HF.shift_rows(fused.value.reshape(B * T, -1), init, plan).view(B, T, -1), mask)
         else:
             shifted = fused.push(init.to(fused.value.dtype)).pop(1).apply_mask()
+        if side_ok and side_late:
+            run_side()
         latent = self.transformer[0](shifted, c)
         cond, mu_ls_p = self._prior_stats(latent)
         # ---- flow + prior log-density + KL (fused row kernel)

@@ -379,7 +379,7 @@ class LVTRTrainer(BaseTrainer):
         if cur != torch.cuda.default_stream(dev):
             return
         if self._compute_stream is None:
-            self._compute_stream = torch.cuda.Stream(device=dev)
+            self._compute_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("VG_MAIN_PRIO", "0")))
         self._compute_stream.wait_stream(cur)
         torch.cuda.set_stream(self._compute_stream)
 
