@@ -1382,7 +1382,7 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
   if constexpr (sizeof(T) == 2) {
     if (!attn_v1(Tn, (long)B * H)) {
       dim3 grid2(((Tn + QB2 - 1) / QB2) * H * B);
-      hipLaunchKernelGGL(attn2_fwd_kernel, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
+      VG_LAUNCH(attn2_fwd_kernel, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
                          lse, slopes, Tn, H, lengths, attn_skip_thr(), sched, cu, Mtot, stats);
       vg_host::prof_end(tok, stream);
       return vg_host::check_launch("vg_attn_fwd");
@@ -1390,7 +1390,7 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
   }
   const size_t lds = (sizeof(T) == 2 ? 2 : 1) * (LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES);
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
-  hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
+  VG_LAUNCH(attn_fwd_kernel<T>, grid, dim3(256), lds, stream, (const T*)qkv, (T*)out, lse, slopes, Tn, H,
                      lengths, sched, cu, Mtot, sizeof(T) == 2 ? stats : nullptr);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_fwd");
@@ -1409,7 +1409,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   if (attn_env("VG_ATTN_WINDOW", 1) == 0) stats = nullptr;      // A/B switch: the round-4 sweep over every tile
   const size_t lds_q = sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES) : 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
   const float skip = sizeof(T) == 2 ? attn_skip_thr() : INFINITY;     // the fp32 parity path keeps every tile
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
+  VG_LAUNCH(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
                      delta, (const T*)out, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot, stats);
   const size_t lds_k = sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES + 2 * 64 * sizeof(float))
                                       : 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float);
@@ -1419,7 +1419,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
     attr[sizeof(T) == 2] = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, dim3(256), lds_k, stream, (const T*)qkv, (const T*)dout, lse,
+  VG_LAUNCH(attn_bwd_dkv_kernel<T>, grid, dim3(256), lds_k, stream, (const T*)qkv, (const T*)dout, lse,
                      delta, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot, stats);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_attn_bwd");
@@ -1485,10 +1485,10 @@ extern "C" int vg_attn_decode(const void* q, const void* kcache, const void* vca
   VG_REQUIRE(B > 0 && Tmax > 0 && H > 0, "vg_attn_decode: empty problem");
   dim3 grid(H, B);
   if (dtype == VG_BF16)
-    hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, grid, dim3(64), 0, stream, (const bf16_t*)q,
+    VG_LAUNCH(attn_decode_kernel<bf16_t>, grid, dim3(64), 0, stream, (const bf16_t*)q,
                        (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, slopes, pos, Tmax, H);
   else
-    hipLaunchKernelGGL(attn_decode_kernel<float>, grid, dim3(64), 0, stream, (const float*)q, (const float*)kcache,
+    VG_LAUNCH(attn_decode_kernel<float>, grid, dim3(64), 0, stream, (const float*)q, (const float*)kcache,
                        (const float*)vcache, (float*)out, slopes, pos, Tmax, H);
   return vg_host::check_launch("vg_attn_decode");
 }

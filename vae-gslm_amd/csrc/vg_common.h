@@ -10,6 +10,7 @@
 // templated on the storage type.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef __bf16 bf16_t;
@@ -344,9 +345,23 @@ int check_launch(const char* what);
 // optional HIP-event timing (vg_prof.hip); kinds are the VG_PROF_* enum of the public header
 int prof_begin(int kind, double work, hipStream_t stream, double bytes = 0.0);
 void prof_end(int token, hipStream_t stream);
+// Inside an open prof_begin / prof_end bracket of this thread: a fresh (start, stop) event pair for ONE kernel dispatch
+// (VG_LAUNCH hands it to hipExtLaunchKernelGGL, which stamps the events with the dispatch's own start and end -- the
+// kernel's execution time as rocprofv3 reports it, without the gap to the previous dispatch that a recorded event pair
+// around the launch includes).  false: no bracket is open, or VG_PROF_EXT is not set (the default: see vg_prof.hip): launch plainly.
+bool prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
 // out[n] += sum_m x[m][n] in one launch without workspace (vg_rows.hip; slow path of fused bias gradients)
 void colsum_accumulate(const void* x, int M, int N, long ld, float* out, int dtype, hipStream_t stream);
 }  // namespace vg_host
+
+#define VG_LAUNCH(kernel, grid, block, lds, stream, ...)                                                   \
+  do {                                                                                                     \
+    hipEvent_t vg_ev0_, vg_ev1_;                                                                           \
+    if (vg_host::prof_kernel_events(&vg_ev0_, &vg_ev1_))                                                   \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, vg_ev0_, vg_ev1_, 0, __VA_ARGS__);           \
+    else                                                                                                   \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                   \
+  } while (0)
 
 #define VG_REQUIRE(cond, ...)                 \
   do {                                        \

@@ -264,7 +264,7 @@ bool launch_thin(const GemmParams& p, int a_tr, int b_tr, int splits, hipStream_
   if (a_tr && chunks > 1) q.accumulate = 1;
   const long outs = (long)p.M * p.N;
   dim3 grid((unsigned)((outs + 255) / 256), chunks);
-  thin_gemm_kernel<T><<<grid, dim3(256), 0, stream>>>(q, sai, sar, sbj, sbr, p.K, rchunk);
+  VG_LAUNCH(thin_gemm_kernel<T>, grid, dim3(256), 0, stream, q, sai, sar, sbj, sbr, p.K, rchunk);
   return true;
 }
 
@@ -343,7 +343,7 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
     attr_done[ti][ki] = true;
   }
   const int tok = vg_host::prof_begin(kind, 2.0 * p.M * p.N * p.K, stream, gemm_algorithmic_bytes(p, sizeof(T)));
-  hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+  VG_LAUNCH(k, grid, block, lds, stream, p);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_gemm");
 }

@@ -319,7 +319,7 @@ int launch_cfg(const GemmParams& p, int splits, hipStream_t stream) {
     attr_done = true;
   }
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(WM * WN * 64), lds, stream, p);
+  VG_LAUNCH(k, dim3(ntn * ntm, 1, splits), dim3(WM * WN * 64), lds, stream, p);
   return 0;
 }
 
@@ -333,7 +333,7 @@ int launch_cfg32(const GemmParams& p, int splits, hipStream_t stream) {
     attr_done = true;
   }
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(WM * WN * 64), lds, stream, p);
+  VG_LAUNCH(k, dim3(ntn * ntm, 1, splits), dim3(WM * WN * 64), lds, stream, p);
   return 0;
 }
 

@@ -799,7 +799,7 @@ int launch_duo_epi(const GemmParams& p, int splits, hipStream_t stream) {
     attr_done = true;
   }
   const int ntn = (p.N + 127) / 128, ntm = (p.M + 255) / 256;
-  hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(256), lds, stream, p);
+  VG_LAUNCH(k, dim3(ntn * ntm, 1, splits), dim3(256), lds, stream, p);
   return 0;
 }
 template <bool A_TR, bool B_TR>
@@ -983,7 +983,7 @@ int launch_ph(const GemmParams& p, int splits, hipStream_t stream) {
     attr_done = true;
   }
   const int ntn = (p.N + 255) / 256, ntm = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL(k, dim3(ntn * ntm, 1, splits), dim3(512), lds, stream, p);
+  VG_LAUNCH(k, dim3(ntn * ntm, 1, splits), dim3(512), lds, stream, p);
   return 0;
 }
 
@@ -1105,7 +1105,7 @@ int gemm_group_launch(const GemmParams* ps, const int* splits, int n, hipStream_
     set_lds(k, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, stream, gp);
+  VG_LAUNCH(k, dim3(blocks), dim3(512), lds, stream, gp);
   return 0;
 }
 }  // namespace vg_host
