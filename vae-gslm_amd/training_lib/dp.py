@@ -153,6 +153,12 @@ class GradReducer:
 
     def _make_hook(self, bi: int):
         def hook(param):
+            # a report arrives on the stream that wrote the gradient -- the main stream, or the side branch of the step
+            # (hipvg.functional.fork_side: autograd runs a node's backward on the stream of its forward): the bucket's
+            # collective has to wait for every stream that wrote into it, not only for the one that completes it
+            if param.is_cuda:
+                st = torch.cuda.current_stream(param.device)
+                self.buckets[bi].setdefault("streams", {})[st.cuda_stream] = st
             if not self._epoch:            # plain autograd use: every report counts
                 b = self.buckets[bi]
                 b["pending"] -= 1
@@ -231,11 +237,18 @@ class GradReducer:
         return int(dist.get_world_size(self.group))
 
     def _launch(self, b):
+        writers = list(b.pop("streams", {}).values()) if b["flat"].is_cuda else []
         if self.comm_stream is not None and self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for st in writers:
+                self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 h = self._timed_allreduce(b["flat"])
         else:
+            cur = torch.cuda.current_stream() if b["flat"].is_cuda else None
+            for st in writers:
+                if st.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(st)
             h = self._timed_allreduce(b["flat"])
         b["handle"], b["launched"] = h, True
         self.launch_log.append((next(i for i, x in enumerate(self.buckets) if x is b), self.phase))
