@@ -417,3 +417,46 @@ def test_eight_ranks_on_one_device(full_cfg):
         assert same and finite and w == world and seg, (r, out[r])
         orders.add(tuple(order))
     assert len(orders) == 1 and list(orders)[0] == tuple(sorted(list(orders)[0]))    # one launch order, bucket-index order
+
+
+@pytest.mark.parametrize("last_report_from", ["main", "side"])
+def test_a_bucket_collective_waits_for_every_stream_that_wrote_into_it(last_report_from):
+    """The step's side branch (hipvg.functional.fork_side) writes some gradients from its own stream, and a bucket goes on
+    the wire from whichever report completes it.  Deterministic form of the race that
+    test_two_rank_training_on_gpu[False] caught once in three runs: one gradient of a bucket is written on a side stream
+    behind a long sleep, the other on the main stream; the "collective" (a snapshot taken on the communication stream)
+    must see both, whichever stream makes the last report."""
+    from training_lib.dp import GradReducer
+    d = torch.device("cuda:0")
+    pa = torch.nn.Parameter(torch.zeros(256, device=d))
+    pb = torch.nn.Parameter(torch.zeros(256, device=d))
+    r = GradReducer([pa, pb], bucket_mb=1.0)
+    assert len(r.buckets) == 1
+    r.exchange = True
+    snaps = []
+    r._allreduce = lambda flat: snaps.append(flat.clone()) or None
+    side = torch.cuda.Stream(device=d)
+    main = torch.cuda.current_stream(d)
+    side.wait_stream(main)
+
+    def side_part():
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(int(3e8))                   # ~0.15 s: the write lands long after the main stream's
+            pb.grad.add_(1.0)
+            pb._vg_grad_hooks[0](pb)
+
+    def main_part():
+        pa.grad.add_(2.0)
+        pa._vg_grad_hooks[0](pa)
+
+    first, second = (side_part, main_part) if last_report_from == "main" else (main_part, side_part)
+    first()
+    assert not snaps
+    second()
+    assert len(snaps) == 1                                  # the second report completed the bucket
+    r.finish()
+    torch.cuda.synchronize()
+    flat = snaps[0]
+    offs = dict(zip([id(p) for p in r.buckets[0]["params"]], r.buckets[0]["offsets"]))
+    assert bool((flat[offs[id(pa)]: offs[id(pa)] + 256] == 2.0).all()), "the main stream's gradient is missing"
+    assert bool((flat[offs[id(pb)]: offs[id(pb)] + 256] == 1.0).all()), "the side stream's gradient is missing"
