@@ -167,7 +167,9 @@ class LVTR(nn.Module):
 
     def packable(self) -> bool:
         nets = [self.encoder[0], self.decoder.model.unet]
+        # (the row gathers move whole 16-byte pieces: fp32 mel frames and latent noise rows of a multiple of four values)
         return (self.use_tokens and self.transformer_flow is not None and hipvg.compute_dtype() == torch.bfloat16
+                and (self.input_dim or 0) % 4 == 0 and self.hp.latent_dim % 4 == 0
                 and all(hasattr(n, "packable") and n.packable() for n in nets)
                 and self.transformer[0].first_norm is None and os.environ.get("VG_CONV_STOCK", "0") != "1")
 
