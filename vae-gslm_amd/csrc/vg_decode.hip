@@ -938,10 +938,12 @@ template <typename TX, typename T>
 int launch_rows(const void* x, long ldx, const void* w, long ldw, const float* bias, const void* res, long ldr, void* y,
                 long ldy, int M, int N, int K, int act, int out_f32, const float* norm_scale, float norm_eps,
                 float* zero_ptr, int zero_n, hipStream_t stream) {
-  // more than 16 rows of bf16 weights: the matrix-core kernel (weights streamed once).  VG_ROWS_MFMA=<M> moves the
-  // threshold (rows from which it is used; 0 = never), for A/B runs
+  // bf16 weights: the matrix-core kernel (weights streamed once, 16 output columns per block).  Built for more than 16
+  // rows, it is the faster one at EVERY row count (round 5, decode step per frame with the threshold at 17 / 1:
+  // B = 1 0.580 / 0.502 ms, B = 8 0.604 / 0.546, B = 16 0.647 / 0.600).  VG_ROWS_MFMA=<M> moves the threshold (rows
+  // from which it is used; 0 = never: the 8-row kernel), for A/B runs
   if constexpr (std::is_same<T, bf16_t>::value) {
-    static const int from = [] { const char* e = getenv("VG_ROWS_MFMA"); return e ? atoi(e) : 17; }();
+    static const int from = [] { const char* e = getenv("VG_ROWS_MFMA"); return e ? atoi(e) : 1; }();
     if (from > 0 && M >= from && K % 32 == 0 && ((uintptr_t)x % 16) == 0 && (norm_scale == nullptr || ((uintptr_t)norm_scale % 16) == 0)) {
       dim3 grid((N + 15) / 16), block(MFW * 64);
       gemm_rows_mfma_kernel<TX><<<grid, block, 0, stream>>>((const TX*)x, ldx, (const bf16_t*)w, ldw, bias, (const void*)res, ldr,

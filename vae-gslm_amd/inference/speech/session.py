@@ -93,11 +93,14 @@ class DecodeSession:
         # ... and up to 16: the fused launch re-reads a head's weights once per SEQUENCE (one block per (head, sequence)),
         # which is what the batch of the reference's inference config (64) cannot afford; from 17 sequences on every
         # Linear is one launch of the matrix-core rows kernel (weights streamed once) around the cache attention
-        self._fused = fits and (mode == "1" or (mode != "0" and 4 <= self.B <= 16))
-        # 17 to 64 sequences, bf16 (round 5): an fp32 residual stream with the two N = d_model products of a layer split
+        # (round 5, later: in bf16 the five-launch form with the split products below beats the fused launch at EVERY batch
+        # -- B = 1: 0.643 -> 0.582 ms per frame, 8: 0.646 -> 0.605, 16: 0.668 -> 0.648 -- so `auto` fuses fp32 sessions only)
+        self._fused = fits and (mode == "1" or (mode != "0" and 4 <= self.B <= 16 and self.dt != torch.bfloat16))
+        # bf16 sessions (round 5; first from 17 sequences up, then at every batch): an fp32 residual stream with the two N = d_model products of a layer split
         # over K across blocks (vg_gemm_rows_acc: fp32 atomics into a buffer an earlier launch of the layer cleared);
         # VG_DECODE_ACC=<splits> (0 = off: five launches on a bf16 stream, every Linear one block per 16 columns)
-        self._acc = 0 if (self._fused or self.B <= 16 or self.dt != torch.bfloat16) else int(os.environ.get("VG_DECODE_ACC", "4"))
+        acc_min_b = int(os.environ.get("VG_DECODE_ACC_MINB", "1"))        # 17: rounds 1-5a (the split form from 17 sequences up only)
+        self._acc = 0 if (self._fused or self.B < acc_min_b or self.dt != torch.bfloat16) else int(os.environ.get("VG_DECODE_ACC", "4"))
         # seed of this session's draws (vg_decode_noise), taken from torch's CPU generator: torch.manual_seed reproduces a run
         self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         # draw epoch: a device word the captured graph READS (the seed itself is baked into the graph by value); every
