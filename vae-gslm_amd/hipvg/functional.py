@@ -328,6 +328,7 @@ def _launch_wgrad_items(items) -> None:
 # its own rhythm) is flushed when it holds a whole number of rounds (>= 2), when a weight comes back a second time
 # (two products adding into one gradient inside one launch would race), and at the end of the piece.
 _WDEFER = {"on": False, "q": {}, "keys": {}, "fire": []}
+_WDEFER_MIN_ROUNDS = int(os.environ.get("VG_WDEFER_MIN_ROUNDS", "2"))      # whole rounds of CUs a queue must hold before it leaves
 
 
 _CUS = []
@@ -361,7 +362,7 @@ def _wgrad_enqueue(items, fire: bool, tag: str) -> None:
     # whole rounds (>= 2) leave at once; a queue whose tile count never lands on a round (e.g. 108 tiles per layer at
     # d = 768) leaves at six rounds anyway, so the queued operands of every layer do not stay alive for the whole
     # backward piece
-    if (tiles >= 2 * cus and tiles % cus == 0) or tiles >= 6 * cus:
+    if (tiles >= _WDEFER_MIN_ROUNDS * cus and tiles % cus == 0) or tiles >= max(6, _WDEFER_MIN_ROUNDS) * cus:
         flush_wgrads(tag)
 
 
