@@ -342,6 +342,10 @@ class LVTR(nn.Module):
             init = self.initial_state(nseq, mel.device)
         if plan is not None:
             shifted = TensorMask(HF.shift_rows(fused.value.reshape(B * T, -1), init, plan).view(B, T, -1), mask)
+        elif getattr(mask, "_vg_full", False):
+            # a batch without padding stays without padding under the shift: no mask arithmetic, no re-mask, and the
+            # stack's input projection (forward epilogue and backward) runs unmasked
+            shifted = TensorMask(torch.cat([init.to(fused.value.dtype), fused.value[:, :-1]], 1), mask)
         else:
             shifted = fused.push(init.to(fused.value.dtype)).pop(1).apply_mask()
         if side_ok and side_late:
