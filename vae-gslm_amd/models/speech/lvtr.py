@@ -275,10 +275,14 @@ class LVTR(nn.Module):
             if t_diff is None:
                 t_diff = torch.randint(0, self.decoder.num_timesteps, (nseq,), device=x.value.device).long()
             side, main = HF.fork_side(x.value.device)
-            with torch.cuda.stream(side), _side_autocast():
-                u_c_side = self.utterance_encoder(utterance).float()
-                temb_side = self.decoder.model.time_embedding(t_diff)
-                tes_side = self.decoder.model.unet.time_projections(temb_side.float())
+            with torch.cuda.stream(side):
+                with _side_autocast():
+                    u_c_side = self.utterance_encoder(utterance).float()
+                # the time-embedding MLPs ([B, 256] activations) in fp32: under autocast every call re-casts their
+                # weights and biases (about twenty cast launches per step for three Linears and their backward)
+                with torch.autocast("cuda", enabled=False):
+                    temb_side = self.decoder.model.time_embedding(t_diff).float()
+                    tes_side = self.decoder.model.unet.time_projections(temb_side)
 
         main = t_diff = u_c_side = temb_side = tes_side = None
         if side_ok and not side_late:
