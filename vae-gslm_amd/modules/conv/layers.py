@@ -224,7 +224,9 @@ class BottleNeckResNet(nn.Module):
         if self.final_norm is not None:
             h = channel_norm_rows(h, self.final_norm, T)
         if self.out_linear is not None:
+            # (its epilogue's row predicate already zeroes the padded frames: no second mask pass)
             h = dense_2d(h, self.out_linear.weight, self.out_linear.bias, out_f32=True, lengths=lens, T=T)
+            return TensorMask(h.view(B, T, -1), mask)
         return TensorMask(h.view(B, T, -1), mask).apply_mask()
 
     def forward(self, x: TensorMask, c: Optional[TensorMask] = None,

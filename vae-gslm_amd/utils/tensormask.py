@@ -99,6 +99,8 @@ class TensorMask(object):
     # ------------------------------------------------------------ masking / reshaping
     def apply_mask(self, mask_value: Number = 0) -> "TensorMask":
         assert self.axis == 1
+        if getattr(self.mask, "_vg_full", False):         # no padding at all: nothing to mask (saves a fill + a select,
+            return TensorMask(self.value, self.mask)      # forward and backward, per call)
         keep = _broadcastable(self.mask, self.value.dim())
         return TensorMask(torch.where(keep, self.value, mask_value), self.mask)
 
