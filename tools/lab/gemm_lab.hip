@@ -330,6 +330,10 @@ int main() {
     run16<256, 128, 4, 2, 1, 2>(p, "256x128 8w(4x2) 2st mfma16 pipe", it);
     run16<256, 128, 4, 2, 1, 3>(p, "256x128 8w(4x2) 3st mfma16 pipe", it);
     run16<256, 256, 2, 4, 1, 2>(p, "256x256 8w(2x4) 2st mfma16 pipe", it);
+    // round 5: FOUR waves of 128 x 128 (one per SIMD, 256 accumulator registers per lane in AGPRs): half the fragment
+    // reads per MFMA of the 8-wave layouts, the reads of k-step s + 1 issued before the MFMAs of s inside the wave
+    run16<256, 256, 2, 2, 1, 2>(p, "256x256 4w(2x2) 2st mfma16 pipe", it);
+    run16<256, 256, 2, 2, 0, 2>(p, "256x256 4w(2x2) 2st mfma16 nopipe", it);
     hipFree((void*)p.A); hipFree((void*)p.B); hipFree((void*)p.C);
   }
   return 0;
