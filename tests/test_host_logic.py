@@ -310,3 +310,39 @@ def test_full_config_bucket_plan_lets_the_segmented_replay_run(full_cfg, monkeyp
     assert all(any(n.startswith(f"transformer.0.layers.{k}.") for n in done) for k in range(len(stack.layers)))
     left = [i for i in range(len(red.buckets)) if i not in early[-1]]
     assert len(left) == 1 and red.buckets[left[0]]["flat"].numel() * 4 < 64 << 20
+
+
+def test_pack_plan_with_a_halo_on_cpu():
+    """hipvg.functional.PackPlan is plain tensor arithmetic (it runs inside a captured graph on the GPU): the row ranges,
+    validity, sequence ids and the one-frame-shift maps of a plan with a halo, checked on the CPU against their
+    definitions (the GPU tests check the same plan through the row gathers)."""
+    from hipvg import functional as F
+    B, T, halo = 5, 24, 6
+    lens = torch.tensor([24, 7, 0, 13, 20], dtype=torch.int32)
+    need = int(torch.clamp(lens + halo, max=T).sum())
+    rows = F.pack_rows_bucket(need, 32)
+    p = F.PackPlan(B, T, rows, "cpu", 32, halo=halo).fill(lens)
+    cu, valid, seq, idx, inv = p.cu.tolist(), p.valid.tolist(), p.seq.tolist(), p.idx.tolist(), p.inv.tolist()
+    want = [0]
+    for n in lens.tolist():
+        want.append(want[-1] + min(n + halo, T))
+    assert cu[:B + 1] == want and cu[-1] == rows and all(b - a <= T for a, b in zip(cu, cu[1:]))
+    assert p.lengths.tolist() == lens.tolist() + [0] * p.npseudo
+    for s in range(B):
+        for r in range(cu[s], cu[s + 1]):
+            t = r - cu[s]
+            real = t < int(lens[s])
+            assert seq[r] == s and valid[r] == int(real) and idx[r] == (s * T + t if real else -1)
+            if real:
+                assert inv[s * T + t] == r
+    assert sum(valid) == int(lens.sum()) and sum(1 for v in inv if v >= 0) == int(lens.sum())
+    src, dst = p.shift_src.tolist(), p.shift_dst.tolist()
+    for r in range(rows):
+        if valid[r]:
+            assert src[r] == (rows + seq[r] if r == cu[seq[r]] else r - 1) and dst[src[r]] == r
+        else:
+            assert src[r] == -1
+    assert sum(1 for v in dst if v >= 0) == sum(valid)
+    # halo 0 is the round-3 plan of the Transformer stack
+    q = F.PackPlan(B, T, F.pack_rows_bucket(int(lens.sum()), 32), "cpu", 32).fill(lens)
+    assert q.cu.tolist()[:B + 1] == [0, 24, 31, 31, 44, 64] and sum(q.valid.tolist()) == 64
