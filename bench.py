@@ -192,6 +192,9 @@ def main():
                     help="hip.packed_rows of the yaml (1): the Transformer stack runs on the valid frames only "
                          "(row gather + varlen attention); 0 keeps the padded rows")
     ap.add_argument("--packed-granule", type=int, default=None, help="hip.packed_rows_granule (rows per bucket)")
+    ap.add_argument("--side-unet", type=int, default=None,
+                    help="hip.side_unet of the yaml (0): 1 runs the diffusion decoder beside the Transformer stack on the step's "
+                         "side stream (faster step, but every kernel's own duration then includes sharing the chip)")
     ap.add_argument("--packed-step", type=int, default=None,
                     help="hip.packed_step of the yaml (1): the WHOLE step of a ragged batch runs on its valid frames (+ an 18-frame "
                          "halo per sequence for the UNet's look-ahead blocks); 0: only the Transformer stack (hip.packed_rows)")
@@ -249,6 +252,8 @@ def main():
         hp.hip.packed_rows_granule = args.packed_granule
     if args.packed_step is not None:
         hp.hip.packed_step = bool(args.packed_step)
+    if args.side_unet is not None:
+        hp.hip.side_unet = bool(args.side_unet)
     hp.hip.coalesce_accumulation = bool(args.coalesce)
     hp.hip.comm = args.comm
     if args.graph_bucket_mb is not None:

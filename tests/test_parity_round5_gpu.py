@@ -409,3 +409,54 @@ def test_gemm_rows_acc(F, shape):
     ref = x.double() @ w.double().T + bias.double() + res.double()
     torch.testing.assert_close(out.double(), ref, atol=2e-3, rtol=1e-4)
     assert bool((junk == 0).all())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_decoder_on_the_side_branch_changes_nothing_but_the_schedule(full_cfg, graph):
+    """hip.side_unet: the diffusion decoder runs on the step's side stream beside the Transformer stack (its backward
+    follows through autograd; its weight-gradient products queue apart from the main chain's).  Same arithmetic, another
+    schedule: the losses of one step and every gradient against the default placement, eager and as a captured graph."""
+    import copy
+    from hparams.hp import Hparams
+    from oracle.lvtr_oracle import small_config
+    from trainers.speech.lvtr import LVTRTrainer
+    from training_lib.synthetic import make_batch
+    d = torch.device("cuda:0")
+    B, T = 4, 256
+    batch = make_batch(B, T, d, seed=9, lengths=[256, 200, 256, 31])
+    g = torch.Generator().manual_seed(4)
+    D, E = full_cfg["model"]["latent_dim"], full_cfg["model"]["tokens"]["embedding_dim"]
+    noise = {"eps_q": torch.randn(B, T, D, generator=g).to(d), "eps_diff": torch.randn(B, T, 80, generator=g).to(d),
+             "t_diff": torch.randint(0, 1000, (B,), generator=g).to(d), "init_state": (torch.rand(B, 1, E, generator=g) * 2 - 1).to(d)}
+    res = {}
+    for side in (False, True):
+        cfg = copy.deepcopy(full_cfg)
+        cfg["model"] = small_config(cfg["model"])
+        cfg["hip"].update(precision="bf16", graph=graph, side_unet=side, coalesce_accumulation=False)
+        cfg["training"]["gradient_accumulation"] = 1
+        torch.manual_seed(3)
+        tr = LVTRTrainer(Hparams.from_dict(cfg)).to(d)
+        tr.configure_optimizers()
+        tr.attach_reducer()
+        tr.global_step = 10 ** 9
+        assert tr.model.side_unet == side
+        if graph:
+            import models.speech.lvtr as M
+            orig = M.LVTR.forward
+            fixed = noise
+
+            def fwd(self, x, c=None, spkr=None, utterance=None, diff_input=None, noise=None, _o=orig):
+                return _o(self, x, c, spkr, utterance, diff_input, fixed if noise is None else noise)
+            M.LVTR.forward = fwd
+            try:
+                o = tr._graphed_micro_step(batch, 0, True)
+            finally:
+                M.LVTR.forward = orig
+        else:
+            o = tr._training_loop(batch, 0, noise=noise)
+        torch.cuda.synchronize()
+        res[side] = (o, torch.cat([bk["flat"] for bk in tr.reducer.buckets]).clone())
+    (oa, ga), (ob, gb) = res[True], res[False]
+    for k in ("loss", "kld", "rec_loss", "token_kld"):
+        assert abs(float(oa[k]) - float(ob[k])) <= 1e-5 * max(1.0, abs(float(ob[k]))), (k, float(oa[k]), float(ob[k]))
+    assert float((ga - gb).norm()) <= 1e-3 * float(gb.norm())

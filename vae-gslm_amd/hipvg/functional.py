@@ -112,6 +112,14 @@ def _split_workspace(device):
 # apart: the split-K scratch (above), the deferral queues (a product issued from the side stream launches at once), and
 # "gradient ready" reports (delivered on the main stream after it has waited for the side stream).
 _SIDE = {"streams": {}, "ids": {}}
+_SIDE_DEFER = [os.environ.get("VG_SIDE_UNET", "0") == "1"]    # weight-gradient products issued on the side branch are queued too
+
+
+def side_defer(on: bool) -> None:
+    """With the diffusion decoder on the side branch (hip.side_unet) its weight-gradient products are queued like the main
+    chain's, in queues of their own: a queue holds products of ONE stream, a mid-pass flush launches on the stream that
+    enqueues, and the flush at the end of the backward piece comes after autograd has joined the streams."""
+    _SIDE_DEFER[0] = bool(on)
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -394,8 +402,8 @@ def sink_wgrad_group(items, fire: bool = True, tag: str = "misc") -> None:
     if not items:
         return
     ok = _PH_GROUP and len(items) <= GROUP_MAX and all(_wgrad_item_ok(*it) for it in items)
-    if ok and _WDEFER["on"] and not on_side_stream():
-        _wgrad_enqueue(items, fire, tag)
+    if ok and _WDEFER["on"] and (not on_side_stream() or _SIDE_DEFER[0]):
+        _wgrad_enqueue(items, fire, tag + "@side" if on_side_stream() else tag)       # (see side_defer)
         return
     if ok and len({it[2].shape[0] for it in items}) == 1:
         _launch_wgrad_items(items)

@@ -354,6 +354,27 @@ class LVTR(nn.Module):
             shifted = fused.push(init.to(fused.value.dtype)).pop(1).apply_mask()
         if side_ok and side_late:
             run_side()
+        rec_side = None
+        unet_side = os.environ.get("VG_SIDE_UNET")
+        unet_side = getattr(self, "side_unet", False) if unet_side is None else unet_side == "1"
+        if side is not None and unet_side:
+            # hip.side_unet (off by default): the WHOLE diffusion decoder on the side branch -- it reads the fused
+            # (token, z) frames, not the Transformer's output -- so that its forward (and, through autograd, its
+            # backward) runs beside the stack: its half-empty N = 512 launches and ~150 small ones fill in around the
+            # stack's tiles.  Step 28.42 -> 27.68 ms (+2.7 % tokens/s, alternating runs of one call); NOT the default
+            # because the co-running launches stretch every kernel they share the chip with -- the layer GEMMs and the
+            # attention kernels measure 6 % longer each (attn_ffn_path_frac 0.418 -> 0.392) although nothing about them
+            # changed, and the per-kernel roofline record of this build is taken kernel by kernel.
+            HF.side_defer(True)
+            side.wait_stream(main)
+            fused.value.record_stream(side)
+            with torch.cuda.stream(side), _side_autocast():
+                if plan is not None:
+                    d_in = fused.cat(HF.seq_rows(u_c_side, plan)[:, None])
+                else:
+                    d_in = fused.cat(u_c_side[:, None].expand(-1, T, -1))
+                rec_side = self.decoder(mel / self.diff_scaling, d_in, t=t_diff, noise=noise.get("eps_diff"),
+                                        temb=temb_side, tes=tes_side)
         latent = self.transformer[0](shifted, c)
         cond, mu_ls_p = self._prior_stats(latent)
         # ---- flow + prior log-density + KL (fused row kernel)
@@ -389,8 +410,13 @@ class LVTR(nn.Module):
             t_diff = noise.get("t_diff")
             if t_diff is None and plan is not None:        # one diffusion step per SEQUENCE (the pseudo batch has `rows`)
                 t_diff = torch.randint(0, self.decoder.num_timesteps, (nseq,), device=mel.device).long()
-            rec = self.decoder(target / self.diff_scaling, diffusion_input,
-                               t=t_diff, noise=noise.get("eps_diff"), **dec_kw)
+            if rec_side is not None:
+                main.wait_stream(side)
+                rec_side.record_stream(main)
+                rec = rec_side
+            else:
+                rec = self.decoder(target / self.diff_scaling, diffusion_input,
+                                   t=t_diff, noise=noise.get("eps_diff"), **dec_kw)
         mu_p, ls_p = mu_ls_p[..., :D], mu_ls_p[..., D:]
         # the monitors (TensorMask.mean() of the prior / posterior statistics, |posterior mean|, log p, log q): one launch
         # for all seven instead of five stock launches each; the stock expressions remain the fallback

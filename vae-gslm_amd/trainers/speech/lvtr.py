@@ -92,6 +92,9 @@ class LVTRTrainer(BaseTrainer):
         self.packed_step = bool(hip.get("packed_step", False)) if hip is not None else False
         if os.environ.get("VG_PACKED_STEP") is not None:
             self.packed_step = os.environ["VG_PACKED_STEP"] == "1"
+        # hip.side_unet: the diffusion decoder runs beside the Transformer stack on the step's side branch (LVTR.forward)
+        if hasattr(self.model, "pack_rows"):
+            self.model.side_unet = bool(hip.get("side_unet", False)) if hip is not None else False
         self._held = []
         self._clean_epoch = None       # hipvg.functional.write_epoch() at the moment the gradients were last cleared
         self._watched = False
