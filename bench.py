@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--packed-step", type=int, default=None,
                     help="hip.packed_step of the yaml (1): the WHOLE step of a ragged batch runs on its valid frames (+ an 18-frame "
                          "halo per sequence for the UNet's look-ahead blocks); 0: only the Transformer stack (hip.packed_rows)")
+    ap.add_argument("--ragged-range", type=str, default="0.5,1.0",
+                    help="with --ragged: sequence lengths ~ U{lo T .. hi T} (default 0.5,1.0; one sequence of every batch keeps "
+                         "the full length so that the padded shape is the same)")
     ap.add_argument("--ragged", action="store_true",
                     help="sequence lengths ~ U{T/2..T} (right-padded batches, SURVEY 8d): shows the cost of masking; "
                          "tokens/s then counts valid frames only")
@@ -286,7 +289,8 @@ def main():
         if not args.ragged:
             return None
         g = torch.Generator().manual_seed(99 + rank * 1000 + i)
-        ls = torch.randint(T_SEQ // 2, T_SEQ + 1, (B,), generator=g)
+        lo, hi = (float(v) for v in args.ragged_range.split(","))
+        ls = torch.randint(max(1, int(lo * T_SEQ)), max(2, int(hi * T_SEQ)) + 1, (B,), generator=g)
         ls[0] = T_SEQ                      # the batch keeps its padded length
         return ls.tolist()
     all_lens = [lens_for(i) for i in range(n_micro)]

@@ -137,7 +137,8 @@ def _trainer(full_cfg, packed, graph, precision="bf16"):
     from trainers.speech.lvtr import LVTRTrainer
     cfg = copy.deepcopy(full_cfg)
     cfg["model"] = small_config(cfg["model"])
-    cfg["hip"].update(precision=precision, graph=graph, packed_rows=packed, packed_rows_granule=256, coalesce_accumulation=False)
+    cfg["hip"].update(precision=precision, graph=graph, packed_rows=packed, packed_rows_granule=256, coalesce_accumulation=False,
+                      packed_step=False)      # (the stack's own packing is what these tests are about: tests/test_packed_step_gpu.py has the other)
     cfg["training"]["gradient_accumulation"] = 1
     hp = Hparams.from_dict(cfg)
     torch.manual_seed(3)
@@ -191,7 +192,7 @@ def test_graph_replays_with_packed_rows_match_eager_padded_rows(full_cfg, monkey
     results = {}
     for mode in ("eager padded", "graph packed"):
         tr = r2._trainer_c1(full_cfg, graph=(mode == "graph packed"))
-        tr.packed_rows, tr.packed_granule = mode == "graph packed", 256
+        tr.packed_rows, tr.packed_granule, tr.packed_step = mode == "graph packed", 256, False
         tr.global_step = 10 ** 9
         outs = []
         for i, b in enumerate(batches):

@@ -115,6 +115,7 @@ class LVTR(nn.Module):
         # rows (the trainer's hipGraph path picks the bucket before it picks the graph).  See _forward_packed.
         self.pack_rows = None
         self.pack_granule = 1024
+        self.pack_fill = 0.94              # packed rows / padded rows above which a batch is not worth packing
         self._pack_plans = {}
         self.utterance_encoder = None
         if hp.has("utterance_encoder"):
@@ -188,7 +189,7 @@ class LVTR(nn.Module):
                 npseudo = -(-min(rows, self.pack_granule or rows) // T)
                 if total > rows or rows - total > npseudo * T:
                     return None
-        if rows > int(0.94 * M):
+        if rows > int(self.pack_fill * M):
             return None
         key = (B, T, rows, device, halo)
         plan = self._pack_plans.get(key)

@@ -89,9 +89,14 @@ class LVTRTrainer(BaseTrainer):
         # hip.packed_step: the WHOLE step of a ragged batch on its valid frames (conv stacks, heads and losses too; every
         # sequence carries an 18-frame halo of its padding for the UNet's look-ahead blocks, models.speech.lvtr.
         # LVTR._forward_packed); falls back to packed_rows / padded rows when a batch or the build cannot take it
-        self.packed_step = bool(hip.get("packed_step", False)) if hip is not None else False
+        ps = hip.get("packed_step", False) if hip is not None else False
         if os.environ.get("VG_PACKED_STEP") is not None:
-            self.packed_step = os.environ["VG_PACKED_STEP"] == "1"
+            ps = {"1": True, "0": False}.get(os.environ["VG_PACKED_STEP"], os.environ["VG_PACKED_STEP"])
+        # "auto": only where it pays -- the conv stacks' 256-row GEMM tiles need as many rounds at 13,312 rows as at 16,384,
+        # so the packed step is level with packed_rows at 77 % fill and ahead from about half-full batches down
+        # (bench.py --ragged --ragged-range: +3.7 % at U{0.2 T .. 0.7 T}, +7.5 % at U{0.1 T .. 0.5 T}, +10.6 % at U{0.05 T .. 0.3 T})
+        self.packed_step = bool(ps)
+        self.packed_step_fill = float(hip.get("packed_step_fill", 0.62)) if (hip is not None and ps == "auto") else 0.94
         # hip.side_unet: the diffusion decoder runs beside the Transformer stack on the step's side branch (LVTR.forward)
         if hasattr(self.model, "pack_rows"):
             self.model.side_unet = bool(hip.get("side_unet", False)) if hip is not None else False
@@ -469,7 +474,7 @@ class LVTRTrainer(BaseTrainer):
         stack.pack_granule = self.packed_granule
         step_ok = self.packed_step and hasattr(self.model, "packable") and self.model.packable() and "cropped_mel" not in (batch or {})
         if hasattr(self.model, "pack_rows"):
-            self.model.pack_rows, self.model.pack_granule = None, self.packed_granule
+            self.model.pack_rows, self.model.pack_granule, self.model.pack_fill = None, self.packed_granule, self.packed_step_fill
         if (self.packed_rows or step_ok) and batch is not None:
             tm = batch.get("tokens", batch.get("mel"))
             if tm is not None and not getattr(tm.mask, "_vg_full", False):
@@ -495,7 +500,7 @@ class LVTRTrainer(BaseTrainer):
                         nseq = B + -(-min(cand, self.packed_granule) // T)
                         if os.environ.get("VG_DEBUG_PACK"):
                             print(f"[packed step] B={B} T={T} need={need} bucket={cand} nseq={nseq} limit={int(0.94 * B * T)}", flush=True)
-                        if cand <= int(0.94 * B * T) and nseq <= 64:
+                        if cand <= int(self.packed_step_fill * B * T) and nseq <= 64:
                             self.model.pack_rows = cand
                             stack.pack_rows = None
                             return ("step", cand)
