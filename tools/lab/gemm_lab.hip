@@ -302,8 +302,138 @@ float run16(const P& p, const char* name, int iters) {
   return (float)t;
 }
 
+
+// ---- variant C (round 5, exploration for the next main loop; RESULT: as written the compiler keeps 256 VGPRs + 256 AGPRs
+//      and spills 343 registers (576 B of scratch per lane): 88 TFLOP/s.  With one wave per SIMD and every register in
+//      use the allocation has to be done by hand -- see DESIGN.md "what is ranked next"): FOUR waves of 128 x 128, K steps of 32 on a four-slot ring
+//      (32 KB per slot: A 256 x 32 and B 256 x 32, rows of 64 bytes = one 16 x 32 MFMA fragment block per KB, no swizzle needed),
+//      the fragment reads of step s + 1 placed between the MFMAs of step s (sched_group_barrier), one barrier per step.
+template <int PIPE>
+__global__ __launch_bounds__(256) void lab4_kernel(P p) {
+  constexpr int BM = 256, BN = 256, BKS = 32, NS = 4, SLOT = (BM + BN) * BKS * 2, A_BYTES = BM * BKS * 2;
+  constexpr int PIECES = SLOT / 1024 / 4;            // LDS-DMA instructions per wave and step (8)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, nwg = ntn * ntm;
+  const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+  const int nks = p.K / BKS;
+  const long ldb = (long)p.K * 2;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long)p.M * ldb), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((long)p.N * ldb), 0x00020000);
+  f32x4v acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // one DMA instruction = 16 rows x 64 bytes (lane: row l >> 2, 16-byte chunk l & 3) -> 1 KB of LDS in lane order
+  auto issue = [&](int ks) {
+    char* st = smem + (ks % NS) * SLOT;
+#pragma unroll
+    for (int j = 0; j < PIECES / 2; ++j) {
+      const int piece = j * 4 + wave;                  // 16 pieces of 16 rows per operand
+      const int row = piece * 16 + (lane >> 2);
+      const unsigned va = (unsigned)((long)(m0 + row) * ldb + (long)(ks * BKS + (lane & 3) * 8) * 2);
+      const unsigned vb = (unsigned)((long)(n0 + row) * ldb + (long)(ks * BKS + (lane & 3) * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st + piece * 1024), 16, va, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st + A_BYTES + piece * 1024), 16, vb, 0, 0, 0);
+    }
+  };
+  // fragment block b (16 rows) of an operand image: lane reads row (lane & 15), chunk (lane >> 4): 1 KB in lane order
+  auto frag = [&](const char* img, int b) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(img + b * 1024 + (lane & 15) * 64 + (lane >> 4) * 16);
+  };
+  bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+  auto read_step = [&](int ks, bf16x8 (&fa)[8], bf16x8 (&fb)[8]) {
+    const char* st = smem + (ks % NS) * SLOT;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = frag(st, wm * 8 + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fb[j] = frag(st + A_BYTES, wn * 8 + j);
+  };
+  auto step = [&](int ks, bf16x8 (&fa)[8], bf16x8 (&fb)[8], bf16x8 (&na)[8], bf16x8 (&nb)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments of step ks are in registers (every wave: slot ks is free)
+    if (ks + 1 < nks) {
+      if (ks + 3 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+      else if (ks + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (ks + NS < nks) issue(ks + NS);
+    if (ks + 1 < nks) read_step(ks + 1, na, nb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    if constexpr (PIPE == 1) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+      }
+    }
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < NS; ++s0)
+    if (s0 < nks) issue(s0);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PIECES) : "memory");
+  __builtin_amdgcn_s_barrier();
+  read_step(0, fa0, fb0);
+  for (int ks = 0; ks < nks; ks += 2) {
+    step(ks, fa0, fb0, fa1, fb1);
+    if (ks + 1 < nks) step(ks + 1, fa1, fb1, fa0, fb0);
+  }
+  constexpr int SW = 8 * 16 + 4, CPR = 16, RPP = 4;
+  __syncthreads();
+  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SW);
+  const int crow = lane / CPR, cch = lane % CPR;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) strip[((lane >> 4) * 4 + rr) * SW + j * 16 + (lane & 15)] = acc[i][j][rr];
+    for (int ps = 0; ps < 16 / RPP; ++ps) {
+      const int rloc = ps * RPP + crow;
+      const int m = m0 + wm * 128 + i * 16 + rloc, n = n0 + wn * 128 + cch * 8;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + rloc * SW + cch * 8 + 4);
+      if (m >= p.M || n >= p.N) continue;
+      bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                  (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+      *reinterpret_cast<bf16x8*>(p.C + (long)m * p.N + n) = o;
+    }
+  }
+}
+
+template <int PIPE>
+float run4(const P& p, const char* name, int iters) {
+  constexpr size_t lds = 4 * 512 * 32 * 2;
+  auto k = lab4_kernel<PIPE>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  auto at = [&](int i) { P q = p; q.A = p.A + (size_t)(i % g_nsets) * g_strideA; q.B = p.B + (size_t)(i % g_nsets) * g_strideB; return q; };
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(ntn * ntm), dim3(256), lds, 0, at(i));
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(ntn * ntm), dim3(256), lds, 0, at(i + 3));
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  const double t = ms * 1e-3 / iters, fl = 2.0 * p.M * p.N * p.K;
+  printf("%-38s %4dx%4dx%4d  %7.1f us  %7.1f TF\n", name, p.M, p.N, p.K, t * 1e6, fl / t / 1e12);
+  fflush(stdout);
+  return (float)t;
+}
+
 int main() {
-  const int M = 8000;
+  const int M = getenv("M") ? atoi(getenv("M")) : 8000;
   const int shapes[3][2] = {{4096, 1024}, {1024, 1024}, {1024, 4096}};
   for (auto& sh : shapes) {
     const int N = sh[0], K = sh[1];
@@ -334,6 +464,8 @@ int main() {
     // reads per MFMA of the 8-wave layouts, the reads of k-step s + 1 issued before the MFMAs of s inside the wave
     run16<256, 256, 2, 2, 1, 2>(p, "256x256 4w(2x2) 2st mfma16 pipe", it);
     run16<256, 256, 2, 2, 0, 2>(p, "256x256 4w(2x2) 2st mfma16 nopipe", it);
+    run4<0>(p, "256x256 4w k32 ring4 (compiler order)", it);
+    run4<1>(p, "256x256 4w k32 ring4 (reads between MFMAs)", it);
     hipFree((void*)p.A); hipFree((void*)p.B); hipFree((void*)p.C);
   }
   return 0;
