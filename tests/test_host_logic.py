@@ -346,3 +346,41 @@ def test_pack_plan_with_a_halo_on_cpu():
     # halo 0 is the round-3 plan of the Transformer stack
     q = F.PackPlan(B, T, F.pack_rows_bucket(int(lens.sum()), 32), "cpu", 32).fill(lens)
     assert q.cu.tolist()[:B + 1] == [0, 24, 31, 31, 44, 64] and sum(q.valid.tolist()) == 64
+
+
+def test_packed_step_auto_takes_half_empty_batches_only():
+    """hip.packed_step: auto -- the trainer's row-bucket choice (host logic, no kernels): a batch whose packed rows (valid
+    frames + an 18-frame halo per sequence, rounded to the granule) are at most 0.62 of the padded ones runs the packed
+    step; a fuller one keeps the Transformer stack's own packing (hip.packed_rows); a batch without padding neither."""
+    import copy
+    import os
+    import yaml
+    from hparams.hp import Hparams
+    from oracle.lvtr_oracle import small_config
+    from trainers.speech.lvtr import LVTRTrainer
+    from utils.tensormask import TensorMask
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "vae-gslm_amd", "configs", "train", "speech", "vae-gslm.yaml")))
+    cfg = copy.deepcopy(cfg)
+    cfg["model"] = small_config(cfg["model"])
+    cfg["hip"].update(precision="bf16", graph=True, packed_rows=True, packed_step="auto", packed_rows_granule=256)
+    tr = LVTRTrainer(Hparams.from_dict(cfg))
+    assert tr.packed_step and abs(tr.packed_step_fill - 0.62) < 1e-9 and tr.model.packable()
+    B, T = 4, 256
+
+    def batch(lens):
+        mask = torch.arange(T)[None] < torch.tensor(lens)[:, None]
+        return {"mel": TensorMask(torch.zeros(B, T, 80), mask), "tokens": TensorMask(torch.zeros(B, T), mask)}
+
+    halo = tr.model.pack_halo()
+    assert halo == 18
+    low = [256, 20, 9, 60]                       # 345 valid frames: 256 + 38 + 27 + 78 = 399 rows -> 512 <= 0.62 * 1024
+    assert tr._choose_pack_rows(batch(low)) == ("step", 512) and tr.model.pack_rows == 512
+    assert tr.model.transformer[0].pack_rows is None
+    high = [256, 200, 180, 150]                  # 786 valid frames: 840 rows -> 1024 > 0.62 * 1024: the stack's packing (786 -> 1024? no: 786 -> 1024 > 0.94 * 1024)
+    choice = tr._choose_pack_rows(batch(high))
+    assert tr.model.pack_rows is None and choice in (None, 1024)
+    mid = [256, 150, 100, 120]                   # 626 valid frames: 680 rows -> 768 > 634: not the packed step; the stack packs 626 -> 768
+    assert tr._choose_pack_rows(batch(mid)) == 768 and tr.model.pack_rows is None and tr.model.transformer[0].pack_rows == 768
+    full = {"mel": TensorMask(torch.zeros(B, T, 80)), "tokens": TensorMask(torch.zeros(B, T))}
+    assert tr._choose_pack_rows(full) is None and tr.model.pack_rows is None
