@@ -37,7 +37,15 @@ enum { VG_ACT_NONE = 0, VG_ACT_RELU = 1, VG_ACT_GELU = 2, VG_ACT_SILU = 3,
        VG_ACT_STORED = 4,
        /* flag OR-ed into act: aux_out receives act'(pre-activation) instead of the pre-activation, so the
           backward epilogue is one multiply instead of re-evaluating erf/exp per element */
-       VG_ACT_SAVE_DERIV = 16 };
+       VG_ACT_SAVE_DERIV = 16,
+       /* flag OR-ed into act (with VG_ACT_GELU | VG_ACT_SAVE_DERIV) and into dact (with VG_ACT_STORED), bf16 launches
+          only (round 6): the stored derivative is ONE BYTE per element, aux_out / aux_in = uint8 [M][ldc] (ldc counted in
+          elements = bytes, ldc % 8 == 0, 8-byte aligned base), code = round((GELU' - VG_DERIV_U8_LO) / VG_DERIV_U8_STEP).
+          GELU' lies in [-0.1290, 1.1290], so 256 codes of step 0.005 from -0.13 cover it: absolute error <= 0.0025, what
+          bf16 keeps near 1 (0.002 - 0.004) -- and half the bytes of the second M x N stream of both FFN-in launches. */
+       VG_ACT_DERIV_U8 = 32 };
+#define VG_DERIV_U8_STEP 0.005f
+#define VG_DERIV_U8_LO (-0.13f)
 
 int vg_version(void);
 /* copies the calling thread's last error message (NUL terminated) */

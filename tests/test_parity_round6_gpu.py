@@ -1,0 +1,311 @@
+"""Round-6 parity tests (need an MI355X; everything enters through the C ABI):
+
+* the 8-bit stored GELU derivative of the bf16 FFN (VG_ACT_DERIV_U8, include/vaegslm_hip.h): every bf16 pre-activation in
+  [-9, 9] against float64 exact-erf GELU' (reference: modules/activations.py:11, modules/transformer/layers.py:82), the
+  lean and the generic epilogue bitwise alike, the forward's GELU output untouched, the dgrad product x the decoded
+  derivative against float64, and a whole Transformer layer's gradients against the bf16-derivative build of the same
+  layer;
+* the packed step (hip.packed_step forced on) against the REFERENCE golden step_c1.npz and against the oracle at half
+  fill (it was only checked against the padded HIP step).  The packed conv kernels exist in bf16 only
+  (csrc/vg_conv.hip: vg_dwnorm_fwd_seg / _bwd_seg), so the comparison with the fp32 reference runs at the bounds the
+  PADDED bf16 step is held to (test_model_parity_gpu.py::test_step_c1_bf16_tracks_reference) -- plus the tight one that
+  is available: packed bf16 against padded bf16 on the very same golden inputs, 1e-5 on every loss.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import hipvg
+    hipvg.lib()
+    from hipvg import functional
+    return functional
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _all_bf16_values(lo_exp=-12, hi=9.0):
+    bits = torch.arange(0, 1 << 15, dtype=torch.int32)
+    vals = (bits << 16).view(torch.float32)
+    vals = vals[(vals >= 2.0 ** lo_exp) & (vals <= hi)]
+    return torch.cat([vals, -vals, torch.zeros(1)])
+
+
+def _gelu_grad64(ud):
+    phi = 0.5 * torch.erfc(-ud / math.sqrt(2.0))
+    return phi + ud * torch.exp(-0.5 * ud * ud) / math.sqrt(2.0 * math.pi)
+
+
+def _decode(codes):
+    import hipvg
+    return codes.double() * hipvg.DERIV_U8_STEP + hipvg.DERIV_U8_LO
+
+
+@pytest.mark.parametrize("tile_cfg", [13, 1], ids=["lean-epilogue", "generic-epilogue"])
+def test_gelu_derivative_u8_within_half_a_code(F, tile_cfg):
+    """GELU'(u) stored as one byte: |code * 0.005 - 0.13 - GELU'(u)| <= 0.0025 (half a code) + 3e-4 (the epilogue's own
+    GELU' is a degree-6 fit evaluated in fp32: its error moves a value that sits on a code boundary to the neighbour),
+    for every bf16 u in [-9, 9] and 60,000 random ones; the forward's h = GELU(u) is bitwise what the bf16-derivative
+    launch returns.  u = X . I is produced exactly."""
+    import hipvg
+    grid = _all_bf16_values()
+    N = 256
+    g = torch.Generator().manual_seed(5)
+    extra = (torch.randn(256 * N - grid.numel() % (256 * N), generator=g) * 2.5).bfloat16().float()
+    u = torch.cat([grid, extra])
+    M = u.numel() // N
+    x = u[:M * N].view(M, N).to(dev()).bfloat16()
+    eye = torch.eye(N, device=dev()).bfloat16()
+    codes = torch.full((M, N), 255, dtype=torch.uint8, device=dev())
+    h8 = F.gemm(x, eye, M, N, N, act=F.ACT_GELU | F.ACT_SAVE_DERIV | hipvg.ACT_DERIV_U8, aux_out=codes, tile_cfg=tile_cfg)
+    d16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    h16 = F.gemm(x, eye, M, N, N, act=F.ACT_GELU | F.ACT_SAVE_DERIV, aux_out=d16, tile_cfg=tile_cfg)
+    assert torch.equal(h8, h16), "the GELU output must not depend on how the derivative is stored"
+    g_ref = _gelu_grad64(x.double())
+    err = (_decode(codes) - g_ref).abs()
+    worst = float(err.max())
+    assert worst <= 0.0025 + 3e-4, f"8-bit GELU' off by {worst:.5f} at u = {float(x.double().flatten()[err.argmax()])}"
+    # the code range is used as designed: 0 -> code 26, 1 -> code 226, nothing saturates
+    assert int(codes[x.double() < -8.5].max()) == 26 and int(codes[x.double() > 8.5].min()) == 226
+    assert 0 <= int(codes.min()) and int(codes.max()) <= 254
+    # and it is no worse than the bf16 form where that one is coarse (values in [0.5, 1.13]: bf16 ulp 0.0039 - 0.0078)
+    big = g_ref > 0.5
+    assert float(err[big].mean()) <= float((d16.double() - g_ref).abs()[big].mean()) * 1.6
+
+
+@pytest.mark.parametrize("N", [512, 520], ids=["N512", "N520-no-whole-lane-pairs"])
+def test_gelu_derivative_u8_lean_and_generic_epilogues_agree(F, N):
+    """The lean epilogues move 16 codes per lane pair (one 16-byte access), the generic one 8 per lane; N % 16 == 8 sends
+    every configuration through the generic one.  Same bytes in memory either way; the dgrad reads them back alike."""
+    import hipvg
+    M, K = 1000, 256
+    g = torch.Generator().manual_seed(11)
+    # small integers / 64: every product and partial sum is exact in fp32, so the tile configurations (different K orders)
+    # hand their epilogues bitwise the same pre-activations
+    x = torch.randint(-3, 4, (M, K), generator=g).float().to(dev()).bfloat16()
+    w = (torch.randint(-4, 5, (N, K), generator=g).float() / 64).to(dev()).bfloat16()
+    b = (torch.randint(-8, 9, (N,), generator=g).float() / 8).to(dev())
+    outs = []
+    for cfg in (13, 15, 1, 3):
+        c = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+        h = F.gemm(x, w, M, N, K, bias=b, act=F.ACT_GELU | F.ACT_SAVE_DERIV | hipvg.ACT_DERIV_U8, aux_out=c, tile_cfg=cfg)
+        outs.append((cfg, h, c))
+    for cfg, h, c in outs[1:]:
+        assert torch.equal(h, outs[0][1]), f"h differs between tile_cfg 13 and {cfg}"
+        assert torch.equal(c, outs[0][2]), f"codes differ between tile_cfg 13 and {cfg}"
+    dy = torch.randint(-3, 4, (M, K), generator=g).float().to(dev()).bfloat16()
+    wt = (torch.randint(-4, 5, (K, N), generator=g).float() / 64).to(dev()).bfloat16()
+    dus = [F.gemm(dy, wt, M, N, K, b_tr=True, dact=F.ACT_STORED | hipvg.ACT_DERIV_U8, aux_in=outs[0][2], tile_cfg=cfg)
+           for cfg in (13, 15, 1, 3)]
+    for du in dus[1:]:
+        assert torch.equal(du, dus[0])
+
+
+@pytest.mark.parametrize("tile_cfg", [13, 15, 1], ids=["lean-256", "lean-192", "generic"])
+def test_dgrad_times_u8_derivative(F, tile_cfg):
+    """du = (dy W) * decode(codes) (dact = STORED | DERIV_U8) against float64 on the same bf16 operands; ragged M (rows
+    past M are not touched), with and without the per-row-tile column sums."""
+    import hipvg
+    M, N, K = 1000, 512, 256
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(M, K, generator=g).to(dev()).bfloat16()
+    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(dev()).bfloat16()
+    codes = torch.randint(0, 256, (M, N), generator=g, dtype=torch.int32).to(torch.uint8).to(dev())
+    ref = (dy.double() @ w.double()) * _decode(codes)
+    for want_part in (False, True):
+        out = torch.full((M + 8, N), 7.0, dtype=torch.bfloat16, device=dev())
+        parts = [] if want_part else None
+        F.gemm(dy, w, M, N, K, b_tr=True, out=out[:M], dact=F.ACT_STORED | hipvg.ACT_DERIV_U8, aux_in=codes, tile_cfg=tile_cfg,
+               colpart=parts)
+        assert bool((out[M:] == 7.0).all())
+        err = (out[:M].double() - ref).abs()
+        tol = ref.abs() * 2.0 ** -8 + 1e-3
+        assert bool((err <= tol).all()), f"worst {float((err / tol).max()):.2f} tolerances"
+        if want_part and parts and parts[0] is not None:
+            cs = parts[0].double().sum(0)          # column sums of the fp32 values the epilogue stored (before their bf16 rounding)
+            assert float((cs - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max())
+
+
+def test_u8_derivative_refused_where_it_cannot_run(F):
+    import hipvg
+    M, N, K = 256, 256, 256
+    x = torch.randn(M, K, device=dev())
+    w = torch.randn(N, K, device=dev())
+    c = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+    with pytest.raises(RuntimeError):       # fp32 launches keep fp32 derivatives
+        F.gemm(x, w, M, N, K, act=F.ACT_GELU | F.ACT_SAVE_DERIV | hipvg.ACT_DERIV_U8, aux_out=c)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    with pytest.raises(RuntimeError):       # only GELU has an 8-bit code
+        F.gemm(xb, wb, M, N, K, act=F.ACT_SILU | F.ACT_SAVE_DERIV | hipvg.ACT_DERIV_U8, aux_out=c)
+    with pytest.raises(RuntimeError):       # the flag in dact goes with STORED
+        F.gemm(xb, wb, M, N, K, dact=F.ACT_GELU | hipvg.ACT_DERIV_U8, aux_in=c)
+
+
+def test_transformer_layer_gradients_with_u8_derivative(F):
+    """One full-width Transformer layer (d_model 1024, 16 heads, FFN 4096; modules/transformer/layers.py:41-93): forward +
+    backward in bf16 with the 8-bit derivative and with the bf16 derivative, both against the SAME layer on the fp32 parity
+    path.  The forward is bitwise the same; the 8-bit form's gradient error against fp32 is at most 1.15 x the bf16 form's
+    (+ 5e-4 of the norm) for dx and every parameter -- the stored derivative is one rounding among the many a bf16 layer
+    makes -- and the two bf16 runs differ from each other by < 8e-3 of the norm (measured 4.6e-3 on dx: two independent
+    roundings of GELU', 0.0025 absolute and 2^-9 relative)."""
+    import hipvg
+    from hparams.hp import Hparams
+    from modules.position.alibi import ALiBi
+    from modules.transformer.layers import TransformerLayer
+    from oracle.weights import fill_like
+    from utils.tensormask import TensorMask
+    prev_dt = hipvg.compute_dtype()
+    B, T, D, H = 2, 384, 1024, 16
+    lhp = Hparams.from_dict(dict(dim=D, ffd_size=4096, norm=dict(identifier="RMSNorm", eps=1e-6),
+                                 activation=dict(identifier="GELU"), self_attn=dict(nheads=H, causal=True)))
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, T, D, generator=g) * 0.7).to(dev())
+    lens = torch.tensor([T, T - 37], device=dev())
+    mask = torch.arange(T, device=dev())[None] < lens[:, None]
+    res = {}
+    try:
+        for name, prec, on in (("fp32", "fp32", False), ("bf16", "bf16", False), ("u8", "bf16", True)):
+            hipvg.set_precision(prec)
+            layer = TransformerLayer(lhp)
+            sd = layer.state_dict()
+            filled = fill_like([(k, tuple(v.shape)) for k, v in sd.items()], 21)
+            with torch.no_grad():
+                for k, arr in filled.items():
+                    sd[k].copy_(torch.from_numpy(arr))
+            layer = layer.to(dev())
+            alibi = ALiBi(H, 64).to(dev())
+            prev = F.set_deriv_u8(on)
+            try:
+                xi = x.clone().requires_grad_(True)
+                y = layer(TensorMask(xi, mask).apply_mask(), rpe_pair=("ALiBi", alibi))["output"].value
+                (y.float() ** 2).sum().backward()
+                if hasattr(F, "flush_wgrads"):
+                    F.flush_wgrads()
+                torch.cuda.synchronize()
+                res[name] = (y.detach().float().clone(), xi.grad.float().clone(),
+                             {n: p_.grad.float().clone() for n, p_ in layer.named_parameters() if p_.grad is not None})
+            finally:
+                F.set_deriv_u8(prev)
+    finally:
+        hipvg.set_precision(prev_dt)
+    (yr, dxr, gr), (y0, dx0, g0), (y1, dx1, g1) = res["fp32"], res["bf16"], res["u8"]
+    assert torch.equal(y0, y1)
+    assert len(gr) >= 8 and set(gr) == set(g0) == set(g1)
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+    pairs = [("dx", dxr, dx0, dx1)] + [(n, gr[n], g0[n], g1[n]) for n in gr]
+    for n, ref, b16, u8 in pairs:
+        e16, e8, d = rel(b16, ref), rel(u8, ref), rel(u8, b16)
+        assert e8 <= 1.15 * e16 + 5e-4, f"{n}: error against fp32 {e8:.2e} with the 8-bit derivative, {e16:.2e} with bf16"
+        assert d < 8e-3, f"{n}: the two bf16 runs differ by {d:.2e} of the norm"
+
+
+# ---------------------------------------------------------------- the packed step against the reference / the oracle
+def _bf16_step(model_cfg, g_or_batch, tcfg, pack):
+    """(out, loss, mask, model) of one bf16 forward / backward; pack = True forces the packed step (fill threshold 1)."""
+    from test_model_parity_gpu import build_model, make_inputs
+    model, _ = build_model(model_cfg, "bf16")
+    if pack:
+        model.pack_rows, model.pack_fill, model.pack_granule = "auto", 1.0, 64
+    x, utt, noise, mask = g_or_batch if isinstance(g_or_batch, tuple) else make_inputs(g_or_batch)
+    out = model(x, utterance=utt, noise=noise)
+    kw = tcfg["fixed_beta"]
+    loss = out["decoder_output"] + out["kld"] * kw + out["ce_loss"] * tcfg["token_kld_weight"] * kw
+    loss.backward()
+    torch.cuda.synchronize()
+    if pack:
+        assert model._pack_plans, "the packed step did not run"
+    return out, loss, mask, model
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+
+def test_packed_step_on_the_reference_golden(golden, full_cfg):
+    """tests/golden/step_c1.npz (REFERENCE outputs, lengths [200, 163]; models/speech/lvtr.py:143-225) through the packed
+    step, forced on: losses within the bf16 drift bounds of the padded step's own test, arg-max at clear margins, and
+    within 1e-5 of the padded bf16 step on the same inputs (valid frames of the returned tensors bitwise)."""
+    from test_model_parity_gpu import small_model_cfg
+    import hipvg
+    prev = hipvg.compute_dtype()
+    try:
+        g = golden("step_c1")
+        cfg, tcfg = small_model_cfg(full_cfg), full_cfg["training"]
+        assert [int(v) for v in g["in_lengths"]] == [200, 163]
+        outp, lossp, mask, mp = _bf16_step(cfg, g, tcfg, True)
+        outd, lossd, _, md = _bf16_step(cfg, g, tcfg, False)
+    finally:
+        hipvg.set_precision(prev)
+    report = {k: _rel(v, g[r]) for k, v, r in (("loss", lossp, "loss"), ("kld", outp["kld"], "kld"), ("ce", outp["ce_loss"], "ce_loss"),
+                                               ("rec", outp["decoder_output"], "rec_loss"))}
+    print("packed bf16 step vs fp32 reference:", report)
+    assert report["ce"] < 2e-2 and report["rec"] < 2e-2 and report["kld"] < 0.15 and report["loss"] < 0.1
+    m = mask.cpu().numpy() & (g["margin"] > 0.5)
+    assert (outp["token_argmax"].cpu().numpy()[m] == g["argmax"][m]).mean() > 0.98
+    for k in ("kld", "ce_loss", "decoder_output"):
+        assert _rel(outp[k], outd[k]) <= 1e-5, (k, float(outp[k]), float(outd[k]))
+    for k in ("log_p", "log_q", "transformer_latent"):
+        a, b = outp[k].value.float(), outd[k].value.float()
+        assert torch.equal(a[mask], b[mask]) and bool((a[~mask] == 0).all()), k
+    gp, gd = dict(mp.named_parameters()), dict(md.named_parameters())
+    for n in gd:
+        assert float((gp[n].grad.float() - gd[n].grad.float()).norm()) <= 1e-3 * float(gd[n].grad.float().norm()) + 1e-7, n
+
+
+def test_packed_step_at_half_fill_against_the_oracle(full_cfg):
+    """A batch at 0.43 fill (B = 4, T = 160, lengths 160 / 71 / 40 / 3) through the packed step against the CPU oracle's
+    fp32 losses (oracle/lvtr_oracle.py: training_loss, a restatement of models/speech/lvtr.py:143-225 pinned to the
+    reference's goldens): the bf16 drift bounds, and 1e-5 against the padded bf16 step."""
+    from oracle import lvtr_oracle as O
+    from oracle.weights import fill_like
+    from test_model_parity_gpu import SEED, small_model_cfg
+    from utils.tensormask import TensorMask
+    import hipvg
+    cfg, tcfg = small_model_cfg(full_cfg), full_cfg["training"]
+    rng = np.random.default_rng(17)
+    B, T, Tu = 4, 160, 64
+    lengths = np.array([160, 71, 40, 3], np.int64)
+    batch = dict(tokens=torch.from_numpy(rng.integers(0, 200, (B, T))),
+                 mel=torch.from_numpy(rng.standard_normal((B, T, 80)).astype(np.float32)),
+                 lengths=torch.from_numpy(lengths),
+                 utt=torch.from_numpy(rng.standard_normal((B, Tu, 80)).astype(np.float32)),
+                 utt_lengths=torch.full((B,), Tu))
+    noise = dict(eps_q=torch.from_numpy(rng.standard_normal((B, T, 4)).astype(np.float32)),
+                 init_state=torch.from_numpy(rng.random((B, 1, 64)).astype(np.float32)) * 2 - 1,
+                 eps_p=torch.zeros(B, T, 4),
+                 t_diff=torch.from_numpy(rng.integers(0, 1000, (B,))),
+                 eps_diff=torch.from_numpy(rng.standard_normal((B, T, 80)).astype(np.float32)))
+    sd = {k: torch.from_numpy(v) for k, v in fill_like(O.param_shapes(cfg), SEED).items()}
+    ref = O.training_loss(sd, cfg, tcfg, batch, noise)
+    d = dev()
+    mask = (torch.arange(T)[None] < batch["lengths"][:, None]).to(d)
+    x = TensorMask(batch["tokens"].to(d), mask).expand().cat(TensorMask(batch["mel"].to(d), mask))
+    inputs = (x, TensorMask(batch["utt"].to(d)), {k: v.to(d) for k, v in noise.items()}, mask)
+    prev = hipvg.compute_dtype()
+    try:
+        outp, _, _, mp = _bf16_step(cfg, inputs, tcfg, True)
+        outd, _, _, _ = _bf16_step(cfg, inputs, tcfg, False)
+    finally:
+        hipvg.set_precision(prev)
+    rows = [k[2] for k in mp._pack_plans]
+    assert rows and max(rows) <= 0.62 * B * T, rows            # (valid + halo rows in 64-row buckets: at most 0.62 of the padded rows)
+    drift = {k: _rel(outp[k], ref[k]) for k in ("kld", "ce_loss", "decoder_output")}
+    print("packed bf16 step vs fp32 oracle:", drift)
+    assert drift["ce_loss"] < 2e-2 and drift["decoder_output"] < 2e-2 and drift["kld"] < 0.15
+    for k in ("kld", "ce_loss", "decoder_output"):
+        assert _rel(outp[k], outd[k]) <= 1e-5, (k, float(outp[k]), float(outd[k]))
+    lat = outp["transformer_latent"].value.float()
+    assert bool((lat[~mask] == 0).all())
+    assert torch.equal(lat[mask], outd["transformer_latent"].value.float()[mask])

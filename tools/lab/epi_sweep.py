@@ -46,11 +46,19 @@ wt = [(torch.randn(K, N, generator=g) * K ** -0.5).to(dev).bfloat16() for _ in r
 bias = torch.randn(N, device=dev)
 ys = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(R)]
 ds = [torch.rand(M, N, device=dev).bfloat16() for _ in range(R)]
+d8 = [torch.randint(0, 256, (M, N), device=dev, dtype=torch.int32).to(torch.uint8) for _ in range(R)]
 for cfg in [int(v) for v in os.environ.get("CFGS", "13,14,15").split(",")]:
     t = {}
     t["fwd plain"] = run([(lambda i=i: F.gemm(xs[i], ws[i], M, N, K, out=ys[i], bias=bias, tile_cfg=cfg)) for i in range(R)])
     t["fwd gelu+deriv"] = run([(lambda i=i: F.gemm(xs[i], ws[i], M, N, K, out=ys[i], bias=bias, tile_cfg=cfg,
                                                     act=hipvg.ACT_GELU | hipvg.ACT_SAVE_DERIV, aux_out=ds[i])) for i in range(R)])
+    if os.environ.get("U8", "1") == "1":         # round 6: the derivative as one byte per element (VG_ACT_DERIV_U8)
+        t["fwd gelu+deriv u8"] = run([(lambda i=i: F.gemm(xs[i], ws[i], M, N, K, out=ys[i], bias=bias, tile_cfg=cfg,
+                                                           act=hipvg.ACT_GELU | hipvg.ACT_SAVE_DERIV | hipvg.ACT_DERIV_U8, aux_out=d8[i])) for i in range(R)])
+        t["dgrad x deriv u8"] = run([(lambda i=i: F.gemm(xs[i], wt[i], M, N, K, b_tr=True, out=ys[i], tile_cfg=cfg,
+                                                          dact=hipvg.ACT_STORED | hipvg.ACT_DERIV_U8, aux_in=d8[i])) for i in range(R)])
+        t["dgrad x deriv u8 + colpart"] = run([(lambda i=i: F.gemm(xs[i], wt[i], M, N, K, b_tr=True, out=ys[i], tile_cfg=cfg,
+                                                                    dact=hipvg.ACT_STORED | hipvg.ACT_DERIV_U8, aux_in=d8[i], colpart=[])) for i in range(R)])
     t["dgrad plain"] = run([(lambda i=i: F.gemm(xs[i], wt[i], M, N, K, b_tr=True, out=ys[i], tile_cfg=cfg)) for i in range(R)])
     t["dgrad x deriv"] = run([(lambda i=i: F.gemm(xs[i], wt[i], M, N, K, b_tr=True, out=ys[i], tile_cfg=cfg,
                                                    dact=hipvg.ACT_STORED, aux_in=ds[i])) for i in range(R)])

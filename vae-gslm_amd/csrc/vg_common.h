@@ -241,6 +241,8 @@ VG_DEVICE float gelu_erf_grad(float x) {
 // exp(-x^2/2) is shared with the density, the sign is put back with one v_bfi (no compare / select pair), no division.
 // The fp32 parity path (vg_gemm.hip) keeps erff.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef VG_LAB_GELU_R4
 #define VG_LAB_GELU_R4 0      // 1: the round-4 form (degree-8 erfcx in z = |x| / sqrt(2) on [0, 4.3], compare + select), A/B only
 #endif
@@ -293,6 +295,35 @@ VG_DEVICE float gelu_grad_fast(float x) {
   float cdf, px;
   gelu_parts_fast(x, cdf, px);
   return cdf + px;
+}
+
+// ---- the stored GELU derivative as one byte per element (round 6; VG_ACT_DERIV_U8 in include/vaegslm_hip.h).
+// GELU'(x) = Phi(x) + x phi(x) lies in [-0.128904, 1.128904] (extrema at x = -+sqrt 2): 256 codes of step 0.005 from -0.13
+// (code 26 = 0, code 226 = 1, code 255 = 1.145).  Absolute error <= 0.0025 -- what bf16 keeps for values in [0.5, 2) is
+// 0.002 - 0.004 -- at half the bytes.  Encode: one fma + v_cvt_pk_u8_f32 per value (the bf16 form: half a v_cvt_pk_bf16_f32);
+// decode: v_cvt_f32_ubyteN + one fma.  The forward's GELU output and the fp32 parity path are untouched.
+// v_cvt_pk_u8_f32 rounds to nearest even and saturates to [0, 255] (NaN -> 0) on gfx950: tools/lab/u8_cvt_probe.hip,
+// profiles/r06/labs/u8_cvt_probe.txt; the three builds below measured max |error| 0.00274 / 0.00274 / 0.00512 (mean
+// 0 / 0 / +0.0025) against float64 GELU' through the C ABI.
+#ifndef VG_U8_CVT
+#define VG_U8_CVT 1           // how the code is rounded: 0 = v_rndne_f32 in front of the conversion (does not depend on the
+#endif                        // conversion's own rounding), 1 = the conversion rounds to nearest (it does), 2 = it truncates (+0.5: lab)
+constexpr float DERIV_U8_INV_STEP = 200.0f, DERIV_U8_ZERO = 26.0f, DERIV_U8_STEP = 0.005f, DERIV_U8_LO = -0.13f;
+VG_DEVICE unsigned deriv_u8_put(float gp, int byte, unsigned word) {     // `byte` of `word` <- code of the derivative gp
+#if VG_U8_CVT == 0
+  const float t = __builtin_rintf(fmaf(gp, DERIV_U8_INV_STEP, DERIV_U8_ZERO));
+#elif VG_U8_CVT == 1
+  const float t = fmaf(gp, DERIV_U8_INV_STEP, DERIV_U8_ZERO);
+#else
+  const float t = fmaf(gp, DERIV_U8_INV_STEP, DERIV_U8_ZERO + 0.5f);
+#endif
+  return __builtin_amdgcn_cvt_pk_u8_f32(t, (unsigned)byte, word);          // saturates to [0, 255]
+}
+VG_DEVICE unsigned dpp_quad_swap1(unsigned v) {      // lane l <- lane l ^ 1 (quad_perm [1, 0, 3, 2]); every lane must be active
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+VG_DEVICE float deriv_u8_get(unsigned word, int byte) {                  // (v_cvt_f32_ubyteN: the byte select is free)
+  return fmaf((float)((word >> (8 * byte)) & 0xffu), DERIV_U8_STEP, DERIV_U8_LO);
 }
 
 VG_DEVICE float silu(float x) { return x / (1.0f + expf(-x)); }

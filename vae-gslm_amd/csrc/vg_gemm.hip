@@ -275,8 +275,8 @@ double gemm_algorithmic_bytes(const GemmParams& p, int esz) {
   double b = ((double)p.M * p.K + (double)p.K * p.N) * esz + mn * (p.out_f32 ? 4 : esz) * (p.accumulate ? 2 : 1);
   if (p.residual) b += mn * esz;
   if (p.pre_add) b += mn * esz;
-  if (p.aux_in) b += mn * esz;
-  if (p.aux_out) b += mn * esz;
+  if (p.aux_in) b += mn * (p.aux_u8 ? 1 : esz);
+  if (p.aux_out) b += mn * (p.aux_u8 ? 1 : esz);
   return b;
 }
 
@@ -446,7 +446,18 @@ int fill_params(const vg_gemm_desc* d, GemmParams& p, int& splits, const char* w
   p.bias = d->bias; p.residual = d->residual; p.aux_in = d->aux_in; p.aux_out = d->aux_out;
   p.pre_add = d->pre_add;
   p.lengths = d->lengths; p.T = d->T > 0 ? d->T : 1;
-  p.act = d->act; p.dact = d->dact; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
+  p.act = d->act & ~VG_ACT_DERIV_U8; p.dact = d->dact & ~VG_ACT_DERIV_U8; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
+  p.aux_u8 = ((d->act | d->dact) & VG_ACT_DERIV_U8) != 0;
+  if (p.aux_u8) {     // one byte per element of the stored GELU derivative (bf16 launches; include/vaegslm_hip.h)
+    VG_REQUIRE(d->dtype == VG_BF16 && splits == 1 && !d->a_tr, "%s: VG_ACT_DERIV_U8 needs a bf16 forward / dgrad product without split-K", who);
+    const bool save8 = (d->act & VG_ACT_DERIV_U8) != 0, load8 = (d->dact & VG_ACT_DERIV_U8) != 0;
+    VG_REQUIRE(!save8 || (p.act == (VG_ACT_GELU | VG_ACT_SAVE_DERIV) && d->aux_out != nullptr),
+               "%s: VG_ACT_DERIV_U8 in act goes with VG_ACT_GELU | VG_ACT_SAVE_DERIV and an aux_out", who);
+    VG_REQUIRE(!load8 || (p.dact == VG_ACT_STORED && d->aux_in != nullptr), "%s: VG_ACT_DERIV_U8 in dact goes with VG_ACT_STORED and an aux_in", who);
+    VG_REQUIRE(save8 != load8, "%s: one launch either stores or reads the 8-bit derivative", who);
+    VG_REQUIRE(d->ldc % 8 == 0 && d->N % 8 == 0 && (((uintptr_t)d->aux_in | (uintptr_t)d->aux_out) & 7) == 0,
+               "%s: VG_ACT_DERIV_U8 moves 8 codes at a time (ldc, N multiples of 8, 8-byte aligned aux)", who);
+  }
   p.alpha = d->alpha;
   p.colsum_out = d->colsum_out;
   static const int cs_rr = [] { const char* e = getenv("VG_COLSUM_RR"); return e ? atoi(e) : 1; }();
@@ -492,6 +503,7 @@ extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
       }
     }
   }
+  VG_REQUIRE(!p.aux_u8 || cfg > 0, "vg_gemm: VG_ACT_DERIV_U8 needs the bf16 LDS-DMA path (K %% 8 == 0, operands below 2 GiB)");
   VG_REQUIRE(d->colpart == nullptr || (cfg > 0 && splits == 1),
              "vg_gemm: colpart needs the bf16 LDS-DMA path without split-K (ask vg_gemm_tile_rows first)");
   if (d->dtype == VG_BF16) return launch<bf16_t>(p, d->a_tr, d->b_tr, splits, cfg, stream);

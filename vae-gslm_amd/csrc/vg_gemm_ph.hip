@@ -995,6 +995,8 @@ int launch_px2(const GemmParams& p, int splits, hipStream_t stream) {
       case EPI_GELU_SAVE: return launch_ph<A_TR, B_TR, 2, EPI_GELU_SAVE, BM>(p, splits, stream);
       case EPI_DACT: return launch_ph<A_TR, B_TR, 2, EPI_DACT, BM>(p, splits, stream);
       case EPI_SILU_SAVE: return launch_ph<A_TR, B_TR, 2, EPI_SILU_SAVE, BM>(p, splits, stream);
+      case EPI_GELU_SAVE8: return launch_ph<A_TR, B_TR, 2, EPI_GELU_SAVE8, BM>(p, splits, stream);
+      case EPI_DACT8: return launch_ph<A_TR, B_TR, 2, EPI_DACT8, BM>(p, splits, stream);
       default: break;
     }
   }

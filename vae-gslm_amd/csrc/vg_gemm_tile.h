@@ -89,6 +89,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
   if (p.act & VG_ACT_SAVE_DERIV) {
     // the activation and its derivative share their transcendental; the derivative goes to aux_out
     bf16x8 o;
+    u32x2_t w8 = {0u, 0u};        // VG_ACT_DERIV_U8 (GELU only, checked by the host side): one byte per derivative
     if (act == VG_ACT_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
@@ -96,6 +97,10 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
         gelu_parts_pk(f32x2_t{v[e], v[e + 1]}, cdf, px);
         o[e] = (bf16_t)(cdf[0] + px[0]);
         o[e + 1] = (bf16_t)(cdf[1] + px[1]);
+        if (p.aux_u8) {
+          if (e < 4) { w8.x = deriv_u8_put(cdf[0] + px[0], e, w8.x); w8.x = deriv_u8_put(cdf[1] + px[1], e + 1, w8.x); }
+          else { w8.y = deriv_u8_put(cdf[0] + px[0], e - 4, w8.y); w8.y = deriv_u8_put(cdf[1] + px[1], e - 3, w8.y); }
+        }
         v[e] *= cdf[0];
         v[e + 1] *= cdf[1];
       }
@@ -113,7 +118,8 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
         if (act == VG_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
       }
     }
-    if (p.aux_out) VG_EPI_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx), o);
+    if (p.aux_out && p.aux_u8) VG_EPI_STORE(reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned char*>(p.aux_out) + idx), w8);
+    else if (p.aux_out) VG_EPI_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux_out) + idx), o);
   } else {
     if (p.aux_out) {
       bf16x8 o;
@@ -137,7 +143,14 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
       for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
     }
   }
-  if (p.dact != VG_ACT_NONE) {
+  if (p.dact != VG_ACT_NONE && p.aux_u8) {    // x the 8-bit stored derivative
+    const u32x2_t w = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(p.aux_in) + idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] *= deriv_u8_get(w.x, e);
+      v[4 + e] *= deriv_u8_get(w.y, e);
+    }
+  } else if (p.dact != VG_ACT_NONE) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux_in) + idx);
     if (p.dact == VG_ACT_STORED) {
 #pragma unroll
@@ -362,7 +375,9 @@ VG_DEVICE void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN 
 // cost more than the instructions saved.
 // Host-side preconditions (gemm_ph_launch): bf16 C, alpha = 1, one K slice, no pre_add / accumulate / colsum_out,
 // N % 8 == 0, T >= 16 when lengths are given.  colpart is supported (the dgrad that also reduces the bias gradient).
-enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3, EPI_SILU_SAVE = 4 };
+//   EPI_GELU_SAVE8 / EPI_DACT8 (round 6): the stored derivative is one byte per element (VG_ACT_DERIV_U8; aux = uint8
+//                  [M][ldc]): 8 codes = one 8-byte access per lane and (row, pass) instead of 16 bytes
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3, EPI_SILU_SAVE = 4, EPI_GELU_SAVE8 = 5, EPI_DACT8 = 6 };
 
 
 template <int BM, int BN, int WM, int WN, bool ILV, bool ILVC, int EPI>
@@ -402,7 +417,23 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
   float cp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // the tile's global operands (residual / stored derivative: 16 x 16 bytes per lane) are all requested here, ahead
   // of the barrier and of the first LDS transpose: one exposed memory round trip per tile instead of one per band
-  bf16x8 g[TM][2];
+  bf16x8 g[EPI == EPI_DACT8 ? 1 : TM][2];
+  // 8-bit derivative (EPI_GELU_SAVE8 / EPI_DACT8): a lane's 8 codes of a (row, pass) are 8 bytes, and 8-byte accesses run at
+  // 0.54 - 0.70 of the 16-byte rate (measured here: x derivative 135.4 us with the bf16 stream, 138.6 us with 8-byte loads
+  // of half the bytes).  So the two lanes of a pair (cch even / odd: 16 consecutive columns) share the band's two rows:
+  // the even lane moves pass 0's row, the odd lane pass 1's row (8 rows further), 16 codes = ONE 16-byte access per band
+  // and lane, and the halves each lane needs from its partner cross with one DPP quad swap per dword.  N % 16 == 0
+  // (lean_epilogue_of); the layout in memory stays plain uint8 [M][ldc], so the generic epilogue reads / writes the same bytes.
+  const bool odd = (lane & 1) != 0;
+  u32x4_t g8[EPI == EPI_DACT8 ? TM : 1];
+  if constexpr (EPI == EPI_DACT8) {
+    const unsigned char* __restrict__ src8 = reinterpret_cast<const unsigned char*>(p.aux_in);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + band_row(i) + (odd ? RPP : 0) + crow;
+      if (col_ok && m < p.M) g8[i] = VG_EPI_LOAD(reinterpret_cast<const u32x4_t*>(src8 + (long)m * p.ldc + (odd ? n - 8 : n)));
+    }
+  }
   if constexpr (EPI == EPI_PLAIN || EPI == EPI_DACT || EPI == EPI_SILU_SAVE) {
     const bf16_t* __restrict__ src = EPI == EPI_PLAIN ? res : EPI == EPI_DACT ? ain : reinterpret_cast<const bf16_t*>(p.pre_add);
     if (src != nullptr) {
@@ -440,6 +471,13 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
         strip[(4 * (lane >> 4) + rr) * SW + j * 16 + (lane & 15)] = acc[i][j][rr];
+    u32x2_t c8[2] = {{0u, 0u}, {0u, 0u}};      // this lane's 8 codes of pass 0 / pass 1 (read: from the pair's two loads; written: below)
+    if constexpr (EPI == EPI_DACT8) {          // (every lane takes part: the swap reads the partner's registers)
+      const u32x4_t own = g8[i];
+      const unsigned rx = dpp_quad_swap1(odd ? own[0] : own[2]), ry = dpp_quad_swap1(odd ? own[1] : own[3]);
+      c8[0] = odd ? u32x2_t{rx, ry} : u32x2_t{own[0], own[1]};
+      c8[1] = odd ? u32x2_t{own[2], own[3]} : u32x2_t{rx, ry};
+    }
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int rloc = ps * RPP + crow;
@@ -461,6 +499,24 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
           v[e + 1] *= cdf[1];
         }
         VG_EPI_STORE(reinterpret_cast<bf16x8*>(aout + idx[ps]), o);
+      } else if constexpr (EPI == EPI_GELU_SAVE8) {
+        u32x2_t w = {0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          f32x2_t cdf, px;
+          gelu_parts_pk(f32x2_t{v[e], v[e + 1]}, cdf, px);
+          if (e < 4) { w.x = deriv_u8_put(cdf[0] + px[0], e, w.x); w.x = deriv_u8_put(cdf[1] + px[1], e + 1, w.x); }
+          else { w.y = deriv_u8_put(cdf[0] + px[0], e - 4, w.y); w.y = deriv_u8_put(cdf[1] + px[1], e - 3, w.y); }
+          v[e] *= cdf[0];
+          v[e + 1] *= cdf[1];
+        }
+        c8[ps] = w;                              // leaves after the pass loop, 16 codes per lane
+      } else if constexpr (EPI == EPI_DACT8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] *= deriv_u8_get(c8[ps][0], e);
+          v[4 + e] *= deriv_u8_get(c8[ps][1], e);
+        }
       } else if constexpr (EPI == EPI_SILU_SAVE) {
         if (p.pre_add != nullptr) {
 #pragma unroll
@@ -513,6 +569,12 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
 #pragma unroll
         for (int e = 0; e < 8; ++e) cp[e] += v[e];
       }
+    }
+    if constexpr (EPI == EPI_GELU_SAVE8) {      // (all lanes again: the even lane stores pass 0's row of the pair, the odd lane pass 1's)
+      const unsigned rx = dpp_quad_swap1(odd ? c8[0][0] : c8[1][0]), ry = dpp_quad_swap1(odd ? c8[0][1] : c8[1][1]);
+      const u32x4_t w16 = odd ? u32x4_t{rx, ry, c8[1][0], c8[1][1]} : u32x4_t{c8[0][0], c8[0][1], rx, ry};
+      if (odd ? ok[1] : ok[0])
+        VG_EPI_STORE(reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(p.aux_out) + (odd ? idx[1] - 8 : idx[0])), w16);
     }
   }
   if (p.colpart) {
@@ -611,14 +673,19 @@ inline int lean_epilogue_of(const GemmParams& p, int splits) {
   if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.lengths != nullptr && p.T < 16)) return EPI_GENERIC;
   // the lean epilogues move C / residual / aux / pre_add as bf16x8 and the bias as f32x4: an output view whose first
   // column is not a multiple of 8 (or a bias slice off a 4-float boundary) takes the element-wise generic epilogue
-  const uintptr_t ptrs16 = (uintptr_t)p.C | (uintptr_t)p.residual | (uintptr_t)p.aux_in | (uintptr_t)p.aux_out |
+  const uintptr_t ptrs16 = (uintptr_t)p.C | (uintptr_t)p.residual | (p.aux_u8 ? 0 : ((uintptr_t)p.aux_in | (uintptr_t)p.aux_out)) |
                            (uintptr_t)p.pre_add | (uintptr_t)p.bias;
   if (ptrs16 & 15) return EPI_GENERIC;
   const int act = p.act & 15;
   const bool save = (p.act & VG_ACT_SAVE_DERIV) != 0;
   if (p.pre_add && !(act == VG_ACT_SILU && save)) return EPI_GENERIC;
   if ((act == VG_ACT_NONE || act == VG_ACT_RELU) && !save && !p.aux_out && p.dact == VG_ACT_NONE) return EPI_PLAIN;
-  if (act == VG_ACT_GELU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE) return EPI_GELU_SAVE;
+  // (the 8-bit forms move 16 codes per lane pair: whole 16-column groups, 16-byte aligned rows)
+  const bool u8_ok = p.aux_u8 && p.N % 16 == 0 && p.ldc % 16 == 0 && (((uintptr_t)p.aux_in | (uintptr_t)p.aux_out) & 15) == 0;
+  if (act == VG_ACT_GELU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE && (!p.aux_u8 || u8_ok))
+    return p.aux_u8 ? EPI_GELU_SAVE8 : EPI_GELU_SAVE;
+  if (u8_ok && p.dact == VG_ACT_STORED && act == VG_ACT_NONE && !save && !p.aux_out && p.aux_in && !p.residual) return EPI_DACT8;
+  if (p.aux_u8) return EPI_GENERIC;
   if (act == VG_ACT_SILU && save && p.aux_out && !p.residual && p.dact == VG_ACT_NONE) return EPI_SILU_SAVE;
   if (act == VG_ACT_NONE && !save && !p.aux_out && (p.dact == VG_ACT_STORED || p.dact == VG_ACT_RELU) && p.aux_in && !p.residual)
     return EPI_DACT;

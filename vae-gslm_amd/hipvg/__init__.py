@@ -21,6 +21,8 @@ LIB_PATH = os.environ.get("VG_LIB") or os.path.join(os.path.dirname(_HERE), "csr
 VG_F32, VG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
 ACT_STORED, ACT_SAVE_DERIV = 4, 16     # dact: multiply by a stored derivative; act flag: store act'(pre) in aux_out
+ACT_DERIV_U8 = 32                      # flag (act with GELU | SAVE_DERIV, dact with STORED): the stored derivative is uint8 codes
+DERIV_U8_STEP, DERIV_U8_LO = 0.005, -0.13   # value = code * step + lo (VG_DERIV_U8_STEP / _LO of include/vaegslm_hip.h)
 ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "silu": ACT_SILU}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -116,6 +116,7 @@ class LVTR(nn.Module):
         self.pack_rows = None
         self.pack_granule = 1024
         self.pack_fill = 0.94              # packed rows / padded rows above which a batch is not worth packing
+        self.pack_return = "all"           # "scalars": the packed step returns its scalar losses / monitors only (the trainer)
         self._pack_plans = {}
         self.utterance_encoder = None
         if hp.has("utterance_encoder"):
@@ -241,9 +242,15 @@ class LVTR(nn.Module):
                 return {k: back(u) for k, u in t.items()}
             return t
 
+        if self.pack_return == "scalars" and out.get("log_p_mean") is not None and out.get("log_q_mean") is not None:
+            # the trainer's step reads the scalar losses and monitors only (scattering every per-frame tensor
+            # back to (B, T, .) was tens of MB of gather traffic and a dozen autograd nodes per training step for nothing)
+            res = {k: u for k, u in out.items() if u is None or (torch.is_tensor(u) and u.numel() == 1)}
+            res["valid_frames"] = plan.valid.sum()
+            return res
         res = {k: back(u) for k, u in out.items() if k not in ("token_argmax", "logits", "lengths")}
         res["token_argmax"] = back(TensorMask(out["token_argmax"].view(rows, 1, 1), mask_p)).value.view(B, T)
-        res["logits"] = back(TensorMask(out["logits"].view(rows, 1, -1), mask_p)).value
+        res["logits"] = back(TensorMask(out["logits"].view(rows, 1, -1), mask_p)).value.reshape(B * T, -1)   # [B * T, V] like the padded path
         return res
 
     # ------------------------------------------------------------------ training forward

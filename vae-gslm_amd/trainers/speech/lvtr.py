@@ -91,12 +91,20 @@ class LVTRTrainer(BaseTrainer):
         # LVTR._forward_packed); falls back to packed_rows / padded rows when a batch or the build cannot take it
         ps = hip.get("packed_step", False) if hip is not None else False
         if os.environ.get("VG_PACKED_STEP") is not None:
-            ps = {"1": True, "0": False}.get(os.environ["VG_PACKED_STEP"], os.environ["VG_PACKED_STEP"])
+            ps = os.environ["VG_PACKED_STEP"]
+        if isinstance(ps, str):              # ("false" / "off" used to switch the packed step ON)
+            key = ps.strip().lower()
+            if key not in ("0", "1", "true", "false", "auto"):
+                raise ValueError(f"hip.packed_step / VG_PACKED_STEP: expected 0, 1, true, false or auto, got {ps!r}")
+            ps = "auto" if key == "auto" else key in ("1", "true")
         # "auto": only where it pays -- the conv stacks' 256-row GEMM tiles need as many rounds at 13,312 rows as at 16,384,
         # so the packed step is level with packed_rows at 77 % fill and ahead from about half-full batches down
         # (bench.py --ragged --ragged-range: +3.7 % at U{0.2 T .. 0.7 T}, +7.5 % at U{0.1 T .. 0.5 T}, +10.6 % at U{0.05 T .. 0.3 T})
         self.packed_step = bool(ps)
-        self.packed_step_fill = float(hip.get("packed_step_fill", 0.62)) if (hip is not None and ps == "auto") else 0.94
+        # the fill threshold (packed rows / padded rows) below which a batch is packed: hip.packed_step_fill when given
+        # (forced on or auto), else 0.62 for auto and 0.94 when forced on
+        fill = hip.get("packed_step_fill", None) if hip is not None else None
+        self.packed_step_fill = float(fill) if fill is not None else (0.62 if ps == "auto" else 0.94)
         # hip.side_unet: the diffusion decoder runs beside the Transformer stack on the step's side branch (LVTR.forward)
         if hasattr(self.model, "pack_rows"):
             self.model.side_unet = bool(hip.get("side_unet", False)) if hip is not None else False
@@ -263,7 +271,13 @@ class LVTRTrainer(BaseTrainer):
         model_input = batch["mel"]
         if self.use_tokens:
             model_input = batch["tokens"].expand().cat(batch["mel"])
-        out = self.model(model_input, noise=noise, **kwargs)
+        if hasattr(self.model, "pack_return"):      # a packed step hands back what this function reads, nothing per frame
+            self.model.pack_return = "scalars" if (self.entropy_weight == 1.0 and self.model.training) else "all"
+        try:
+            out = self.model(model_input, noise=noise, **kwargs)
+        finally:
+            if hasattr(self.model, "pack_return"):
+                self.model.pack_return = "all"
         kld = out["kld"] if self.entropy_weight == 1.0 else None
         if kld is None:   # non-default entropy weighting: generic path
             from training_lib.losses import masked_loss
@@ -337,7 +351,7 @@ class LVTRTrainer(BaseTrainer):
         lq_mean = out.get("log_q_mean")
         result = {"kld": kld.detach(), "rec_loss": rec.detach(),
                   "log_p": -(lp_mean if lp_mean is not None else out["log_p"].mean()).detach(),
-                  "length": out["log_p"].length.sum(), "kld_weight": kld_weight,
+                  "length": out["log_p"].length.sum() if "log_p" in out else out["valid_frames"], "kld_weight": kld_weight,
                   "logstd": out["logstd"].detach(), "q_logstd": out["q_logstd"].detach(),
                   "log_q": -(lq_mean if lq_mean is not None else out["log_q"].mean()).detach(),
                   "q_mean_abs": out["q_mean_abs"].detach(),
@@ -417,8 +431,11 @@ class LVTRTrainer(BaseTrainer):
                     # (likelihood(), a user's forward) would pack a different batch into it
                     self._clear_pack_rows()
             else:
-                self._choose_pack_rows(batch, eager=True)
-                out = self._training_loop(batch, batch_idx, noise)
+                try:
+                    self._choose_pack_rows(batch, eager=True)
+                    out = self._training_loop(batch, batch_idx, noise)
+                finally:
+                    self._clear_pack_rows()        # (the eager branch left "auto" on the model for later direct calls)
         finally:
             self._wgrad_fresh = False
             self._clean_epoch = None               # a pass ran (eagerly, captured or replayed): the buffers hold gradients
@@ -490,6 +507,11 @@ class LVTRTrainer(BaseTrainer):
                     total = getattr(tm.mask, "_vg_valid", None)
                     if total is None:
                         total = int(tm.mask.sum().item())
+                    # need >= total, so a batch whose valid frames alone are past the threshold can never qualify: decline
+                    # without reading the per-sequence lengths back (the common 77 %-fill case paid a blocking
+                    # device -> host read and two small launches per step for nothing)
+                    if step_ok and HF.pack_rows_bucket(int(total), self.packed_granule) > int(self.packed_step_fill * B * T):
+                        step_ok = False
                     if step_ok:
                         # + the halo rows: min(len + halo, T) per sequence needs the lengths; the bound len + halo is
                         # within a granule of it and a bucket only has to be large enough
