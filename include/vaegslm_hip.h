@@ -104,6 +104,11 @@ typedef struct vg_gemm_desc {
 int vg_gemm(const vg_gemm_desc* desc, vg_stream_t stream);
 /* rows per output tile the launch for `desc` will use (128 or 256), 0 if it takes the register-staged kernel */
 int vg_gemm_tile_rows(const vg_gemm_desc* desc);
+/* rows of the fp32 [rows][N] array `colpart` a call with this descriptor fills (0: the call cannot produce it).  Round 6:
+ * a forward / dgrad product whose last round of 256 x 256 tiles would be badly filled runs as two launches over disjoint
+ * row ranges (whole rounds + the remaining row band on the tile shape that suits it), each writing its own row-tiles'
+ * column sums: the count is no longer ceil(M / vg_gemm_tile_rows). */
+int vg_gemm_colpart_rows(const vg_gemm_desc* desc);
 /* Several weight-gradient products in ONE launch.  Contract (anything else is refused with a message in
  * vg_last_error and nothing is launched -- run those through vg_gemm): every desc bf16, a_tr = b_tr = 1, fp32 C
  * (out_f32 = 1) in 16-byte aligned rows (N % 8 == 0, ldc % 4 == 0), K a multiple of 64, split_k = 1,

@@ -194,3 +194,43 @@ def test_reused_sunk_parameter_is_reduced_after_its_last_contribution():
     out = mgr.dict()
     mp.spawn(_reuse_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _wire_worker(rank, world, port, out):
+    """hip.comm_dtype = bf16 (round 6): the same two-rank accumulation window through the bf16 wire and the fp32 wire."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from training_lib.dp import GradReducer
+    res = {}
+    for wire in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+        red = GradReducer(model.parameters(), bucket_mb=0.004, wire_dtype=wire)       # several buckets
+        assert all((b["wire"] is not None) == (wire == "bf16") for b in red.buckets)
+        g = torch.Generator().manual_seed(100 + rank)
+        red.sync_now = False
+        model(torch.randn(4, 16, generator=g)).pow(2).sum().backward()
+        red.sync_now = True
+        model(torch.randn(4, 16, generator=g)).pow(2).sum().backward()
+        red.finish()
+        res[wire] = torch.cat([b["flat"].clone() for b in red.buckets])
+        # every rank holds the same averaged gradient, as fp32 values the optimizer reads in place
+        gathered = [torch.zeros_like(res[wire]) for _ in range(world)]
+        dist.all_gather(gathered, res[wire])
+        assert torch.equal(gathered[0], gathered[1]) and res[wire].dtype == torch.float32
+    a, b = res["fp32"], res["bf16"]
+    # each rank's gradient is rounded to bf16 (2^-9 relative), the sum of two again, the halving is exact: the difference
+    # is <= 2^-7 of the gradient's norm (element-wise the two ranks' terms may cancel), and not zero (the wire really was
+    # bf16: every value the optimizer reads is a bf16 number)
+    rel = float((a - b).norm() / a.norm())
+    out[rank] = (rel <= 2.0 ** -7, not torch.equal(a, b), bool((b == b.bfloat16().float()).all()), rel)
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_two_ranks_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_wire_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert tuple(out[r][:3]) == (True, True, True), dict(out)

@@ -58,6 +58,13 @@ constexpr float SCALE = 0.125f;   // 1 / sqrt(64)
 // is not what bounds these kernels (every request pointed at one L2-resident tile: 58.1 vs 59.6 us) and the lost
 // balance costs more than the hits return: forward 88 vs 65 us, backward 226 vs 210 us at B = 16, T = 1000.
 VG_DEVICE void pair_and_rank(int bid, int ntiles, int npairs, int sched, int& hb, int& rank) {
+  // sched & 4 (lab, round 6): the launch order scattered by a multiplicative permutation that keeps bid mod 8 (the XCD
+  // class of a pair) -- blocks of every sweep length start together instead of rank by rank.  Built to test whether the
+  // memory-bound prologue / epilogue phases and the compute-bound sweeps of equal-rank blocks run in step chip-wide
+  if ((sched & 4) && ((ntiles * npairs) & 7) == 0) {
+    const unsigned total = (unsigned)(ntiles * npairs);
+    bid = (int)(((unsigned long long)(unsigned)bid * 1001ull) % total);     // 1001 = 8 * 125 + 1; odd: a permutation when total is a power of two times ...
+  }
   sched &= 1;
   if (sched == 1 && (npairs & 7) == 0) {
     const int j = bid >> 3;
@@ -1382,7 +1389,15 @@ int launch_fwd(const void* qkv, void* out, float* lse, const float* slopes, int 
   if constexpr (sizeof(T) == 2) {
     if (!attn_v1(Tn, (long)B * H)) {
       dim3 grid2(((Tn + QB2 - 1) / QB2) * H * B);
-      VG_LAUNCH(attn2_fwd_kernel, grid2, dim3(256), NSTAGE2 * STAGE2, stream, (const bf16_t*)qkv, (bf16_t*)out,
+      // lab: VG_ATTN_LDS_EXTRA=<bytes> of unused dynamic LDS per block lowers the blocks a CU holds (occupancy A/B runs)
+      static const int extra = attn_env("VG_ATTN_LDS_EXTRA", 0);
+      static bool attr2 = false;
+      if (extra > 0 && !attr2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  NSTAGE2 * STAGE2 + extra);
+        attr2 = true;
+      }
+      VG_LAUNCH(attn2_fwd_kernel, grid2, dim3(256), NSTAGE2 * STAGE2 + extra, stream, (const bf16_t*)qkv, (bf16_t*)out,
                          lse, slopes, Tn, H, lengths, attn_skip_thr(), sched, cu, Mtot, stats);
       vg_host::prof_end(tok, stream);
       return vg_host::check_launch("vg_attn_fwd");
@@ -1407,12 +1422,18 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   dim3 grid(((Tn + QB - 1) / QB) * H * B);
   const int sched = attn_env("VG_ATTN_SCHED", 0);
   if (attn_env("VG_ATTN_WINDOW", 1) == 0) stats = nullptr;      // A/B switch: the round-4 sweep over every tile
-  const size_t lds_q = sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES) : 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES;
+  static const int extra = attn_env("VG_ATTN_LDS_EXTRA", 0);      // lab: see launch_fwd
+  const size_t lds_q = (sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES) : 2 * LdsPlan<T>::ROW_BYTES + LdsPlan<T>::TR_BYTES) + extra;
+  static bool attrq[2] = {false, false};
+  if (extra > 0 && !attrq[sizeof(T) == 2]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    attrq[sizeof(T) == 2] = true;
+  }
   const float skip = sizeof(T) == 2 ? attn_skip_thr() : INFINITY;     // the fp32 parity path keeps every tile
   VG_LAUNCH(attn_bwd_dq_kernel<T>, grid, dim3(256), lds_q, stream, (const T*)qkv, (const T*)dout, lse,
                      delta, (const T*)out, slopes, (T*)dqkv, Tn, H, lengths, skip, sched, cu, Mtot, stats);
-  const size_t lds_k = sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES + 2 * 64 * sizeof(float))
-                                      : 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float);
+  const size_t lds_k = (sizeof(T) == 2 ? 2 * (2 * LdsPlan<T>::ROW_BYTES + 2 * 64 * sizeof(float))
+                                       : 2 * LdsPlan<T>::ROW_BYTES + 2 * LdsPlan<T>::TR_BYTES + 2 * 64 * sizeof(float)) + extra;
   static bool attr[2] = {false, false};
   if (!attr[sizeof(T) == 2]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>),

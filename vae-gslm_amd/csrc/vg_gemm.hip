@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
       if (m >= p.M) continue;
-      const bool valid = row_valid(p.lengths, p.T, m);
+      const bool valid = row_valid(p.lengths, p.T, p.m_base + m);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + acc_col(lane);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void thin_gemm_kernel(GemmParams p, long sai, 
   else if (p.act == VG_ACT_GELU) v = gelu_erf(v);
   else if (p.act == VG_ACT_SILU) v = silu(v);
   if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[o]);
-  if (!row_valid(p.lengths, p.T, i)) v = 0.f;
+  if (!row_valid(p.lengths, p.T, p.m_base + i)) v = 0.f;
   if (p.out_f32) {
     float* c = reinterpret_cast<float*>(p.C) + o;
     *c = p.accumulate ? (*c + v) : v;
@@ -352,7 +352,8 @@ int launch(const GemmParams& p, int a_tr, int b_tr, int splits, int tile_cfg, hi
 
 namespace {
 // tile configuration the bf16 LDS-DMA path will use for this problem (-1: register-staged kernel)
-int pick_cfg(const vg_gemm_desc* d) {
+int pick_cfg(const vg_gemm_desc* d, double* cost_out = nullptr) {
+  if (cost_out) *cost_out = -1.0;          // (set below where the cost model chose between tile shapes)
   int cfg = d->tile_cfg;
   // K tails are zero-filled by the DMA (rows past K of a k-major operand, 16-byte chunks past the row end of a
   // k-contiguous one), so any K that keeps the 16-byte chunks whole qualifies
@@ -398,6 +399,7 @@ int pick_cfg(const vg_gemm_desc* d) {
       static const int no15 = [] { const char* e = getenv("VG_NO_CFG15"); return e ? atoi(e) : 0; }();
       const double c15 = cost(192, 256, 1, 0.70, 0.93);     // per-area factor from tools/tile_cold_sweep.py CFGS=1,13,15 at M = 8000 / 10240
       if (!no15 && c15 < 0.93 * fmin(c1, c13)) cfg = 15;
+      if (cost_out) *cost_out = cfg == 15 ? c15 : (cfg == 13 ? c13 : c1);
     } else {
       const double c1 = cost(128, 128, 2, 1.08 + longk_pen, 0.85), c3 = cost(256, 256, 1, 1.0, 0.85),
                    c9 = cost(192, 256, 1, 0.97, 0.85);
@@ -447,6 +449,7 @@ int fill_params(const vg_gemm_desc* d, GemmParams& p, int& splits, const char* w
   p.pre_add = d->pre_add;
   p.lengths = d->lengths; p.T = d->T > 0 ? d->T : 1;
   p.act = d->act & ~VG_ACT_DERIV_U8; p.dact = d->dact & ~VG_ACT_DERIV_U8; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
+  p.m_base = 0;
   p.aux_u8 = ((d->act | d->dact) & VG_ACT_DERIV_U8) != 0;
   if (p.aux_u8) {     // one byte per element of the stored GELU derivative (bf16 launches; include/vaegslm_hip.h)
     VG_REQUIRE(d->dtype == VG_BF16 && splits == 1 && !d->a_tr, "%s: VG_ACT_DERIV_U8 needs a bf16 forward / dgrad product without split-K", who);
@@ -483,12 +486,85 @@ int fill_params(const vg_gemm_desc* d, GemmParams& p, int& splits, const char* w
 }
 }  // namespace
 
+namespace {
+// Round 6: partial rounds -- split M, not K.  A forward / dgrad product on 256 x 256 tiles whose last
+// round of 256 CUs is badly filled (M = 13,312 packed rows x N = 4096: 832 tiles = 3.25 rounds, paid as 4) runs as TWO
+// launches: the row-tiles that make whole rounds on the 256 x 256 schedule, and the remaining row band as a product of its
+// own on whatever tile shape the cost model likes best for it (128 x 128 at two blocks per CU, 192 x 256, ...).  No slab,
+// no atomics; every output row is computed by one launch exactly as the one-launch form would compute it on that tile
+// shape.  Returns the rows of the first launch (a multiple of 256), or 0: no split.
+// MEASURED AND NOT ADOPTED (profiles/r06/labs/split_m_pieces_cold_operands.txt, one call, cold operands): the premise does
+// not hold on this kernel -- a quarter-full fourth round costs 18 us, not a round's 31 (the CUs that get no fourth tile
+// leave the memory system to the others), and the row band as a launch of its own costs the same 17 us:
+//   M = 13,312 x N = 4096 x K = 1024: one launch 110.5 us; 12,288 rows 92.5 + 1,024 rows 17.2 (128 x 128) = 109.7 us
+//   M = 13,312 x N = 3072:            one launch  82.3 us; 10,752 rows 61.5 + 2,560 rows 20.2             =  81.7 us
+//   M = 10,240 x N = 4096:            one launch  82.6 us;  8,192 rows 62.9 + 2,048 rows 21.5             =  84.4 us
+// and bench.py --ragged / --seq-len 640 measure the same with and without it.  VG_GEMM_SPLIT_M: 0 (default) off, 1 = by the
+// cost model below, 2 = whenever the last round is under 0.7 full (what tests/test_parity_round6_gpu.py forces).  Read
+// per call (not cached) so that one process can measure both.
+int split_rows(const vg_gemm_desc* d, int cfg, double cost_whole) {
+  const char* env = getenv("VG_GEMM_SPLIT_M");
+  const int on = env ? atoi(env) : 0;
+  if (!on || d->tile_cfg != 0 || cfg != 13 || d->a_tr || (d->split_k > 1) || cost_whole <= 0.0) return 0;
+  const long ntn = (d->N + 255) / 256, ntm = (d->M + 255) / 256, tiles = ntm * ntn;
+  const long full = tiles / 256, rem = tiles % 256;
+  if (full < 1 || rem == 0 || rem * 10 >= 256 * 7) return 0;             // the last round is at least 0.7 full: leave it
+  const long ntm1 = full * 256 / ntn;                                       // row-tiles of the whole rounds
+  if (ntm1 < 1 || ntm1 >= ntm) return 0;
+  vg_gemm_desc d1 = *d, d2 = *d;
+  d1.M = (int)(ntm1 * 256);
+  d2.M = d->M - d1.M;
+  double c1 = -1.0, c2 = -1.0;
+  (void)pick_cfg(&d1, &c1);
+  const int cfg2 = pick_cfg(&d2, &c2);
+  if (c1 <= 0.0 || c2 <= 0.0 || cfg2 <= 0) return 0;
+  // the second launch pays its own launch + prologue + epilogue (~6-9 us of a ~100 us product: 0.06 of a round's cost)
+  const double extra = 0.06 * 256.0 * 256.0 * 0.62;
+  return (on >= 2 || c1 + c2 + extra < 0.97 * cost_whole) ? d1.M : 0;
+}
+}  // namespace
+
+/* rows of the fp32 [rows][N] array a launch with `colpart` fills: one per row-tile of each of its (one or two) launches */
+extern "C" int vg_gemm_colpart_rows(const vg_gemm_desc* d) {
+  if (d == nullptr) return 0;
+  double cw = -1.0;
+  const int cfg = pick_cfg(d, &cw);
+  if (cfg <= 0) return 0;
+  const int m1 = split_rows(d, cfg, cw);
+  if (m1 == 0) return (d->M + cfg_tile_rows(cfg) - 1) / cfg_tile_rows(cfg);
+  vg_gemm_desc d2 = *d;
+  d2.M = d->M - m1;
+  const int r2 = cfg_tile_rows(pick_cfg(&d2));
+  return m1 / 256 + (d2.M + r2 - 1) / r2;
+}
+
 extern "C" int vg_gemm(const vg_gemm_desc* d, hipStream_t stream) {
   GemmParams p;
   int splits = 1;
   if (int e = fill_params(d, p, splits, "vg_gemm")) return e;
   // tile_cfg: 0 = auto, -1 = force the register-staged kernel, 1.. = LDS-DMA tile shapes
-  const int cfg = pick_cfg(d);
+  double cost_whole = -1.0;
+  const int cfg = pick_cfg(d, &cost_whole);
+  if (const int m1 = (d->dtype == VG_BF16 && splits == 1 && !d->split_ws) ? split_rows(d, cfg, cost_whole) : 0) {
+    // two launches over disjoint row ranges; the second one's row mask counts from the whole product's first row
+    vg_gemm_desc d2 = *d;
+    d2.M = d->M - m1;
+    const int cfg2 = pick_cfg(&d2);
+    GemmParams p1 = p, p2 = p;
+    p1.M = m1;
+    p2.M = d->M - m1;
+    p2.m_base = m1;
+    const size_t esz = 2;
+    p2.A = (const char*)p.A + (size_t)m1 * p.lda * esz;
+    p2.C = (char*)p.C + (size_t)m1 * p.ldc * (p.out_f32 ? 4 : esz);
+    if (p.residual) p2.residual = (const char*)p.residual + (size_t)m1 * p.ldc * esz;
+    if (p.pre_add) p2.pre_add = (const char*)p.pre_add + (size_t)m1 * p.ldc * esz;
+    if (p.aux_in) p2.aux_in = (const char*)p.aux_in + (size_t)m1 * p.ldc * (p.aux_u8 ? 1 : esz);
+    if (p.aux_out) p2.aux_out = (char*)p.aux_out + (size_t)m1 * p.ldc * (p.aux_u8 ? 1 : esz);
+    if (p.colpart) p2.colpart = p.colpart + (size_t)(m1 / 256) * p.N;
+    if (int e = launch<bf16_t>(p1, d->a_tr, d->b_tr, 1, cfg, stream)) return e;
+    return launch<bf16_t>(p2, d->a_tr, d->b_tr, 1, cfg2, stream);
+  }
   if (splits > 1 && cfg > 0 && d->split_ws != nullptr && d->split_cnt != nullptr) {
     // in-launch reduction of the K slices through fp32 slabs: needs splits * tiles * tile floats of workspace
     const int rows = cfg_tile_rows(cfg), cols = (cfg == 3 || cfg == 4 || (cfg >= 10 && cfg != 14)) ? 256 : 128;

@@ -25,6 +25,8 @@ struct GemmParams {
   int* split_cnt;           // [tiles] arrival counters, zeroed ahead of the launch
   int colsum_rr;            // 1: deal the row-sum MFMAs round-robin over the blocks of an m-panel
   int group_m;              // > 0: tiles are walked m-fastest inside bands of group_m row-tiles (L2 blocking)
+  int m_base;               // rows of the whole product above this launch's first row (0 unless vg_gemm split the rows over two
+                            // launches): only the row mask needs it (sequence index and frame of a row)
   int aux_u8;               // the stored derivative (aux_out of GELU | SAVE_DERIV, aux_in of dact = STORED) is uint8 [M][ldc]:
                             // VG_ACT_DERIV_U8 (the flag itself is stripped from act / dact)
 };

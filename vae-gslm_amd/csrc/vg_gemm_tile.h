@@ -171,7 +171,7 @@ VG_DEVICE void epilogue_emit(const GemmParams& p, bool split, int m, int n, floa
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
   }
-  if (!row_valid(p.lengths, p.T, m)) {
+  if (!row_valid(p.lengths, p.T, p.m_base + m)) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
   }
@@ -446,6 +446,20 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
         }
     }
   }
+  // packed rows (T == 1: every row is a one-frame pseudo sequence, lengths[m] > 0 is its predicate -- the layout of
+  // hip.packed_rows / hip.packed_step): the row flags of the tile, requested up front like the other operands (round 6:
+  // these launches used to fall back to the generic epilogue, ~3.5 us more per tile round)
+  const bool rows1 = p.lengths != nullptr && p.T == 1;
+  int live[TM][2];
+  if (rows1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int m = m0 + band_row(i) + ps * RPP + crow;
+        live[i][ps] = m < p.M ? p.lengths[p.m_base + m] : 0;
+      }
+  }
   __syncthreads();                         // every wave is done reading the last stage
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -458,13 +472,15 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
       ok[ps] = col_ok && m < p.M;
       idx[ps] = (long)m * p.ldc + n;
     }
-    // the band's rows sit in sequence b0 from frame t0 on and, past its end, in sequence b0 + 1
+    // the band's rows sit in sequence b0 from frame t0 on and, past its end, in sequence b0 + 1 (m_base: this launch is the
+    // lower row band of a product split over two launches, vg_gemm.hip: the row mask counts rows of the whole product)
     int t0 = 0, len0 = 0x7fffffff, len1 = 0x7fffffff;
-    if (p.lengths != nullptr) {
-      const int b0 = mband / p.T;
-      t0 = mband - b0 * p.T;
-      len0 = (long)b0 * p.T < p.M ? p.lengths[b0] : 0;
-      len1 = (long)(b0 + 1) * p.T < p.M ? p.lengths[b0 + 1] : 0;
+    if (p.lengths != nullptr && !rows1) {
+      const int mb = p.m_base + mband;
+      const int b0 = mb / p.T;
+      t0 = mb - b0 * p.T;
+      len0 = (long)b0 * p.T < (long)p.m_base + p.M ? p.lengths[b0] : 0;
+      len1 = (long)(b0 + 1) * p.T < (long)p.m_base + p.M ? p.lengths[b0 + 1] : 0;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -555,7 +571,7 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
       }
       if (p.lengths != nullptr) {          // wave-uniform: launches without a row mask skip the test and the selects
         const int t = t0 + rloc;
-        const bool keep = t < p.T ? t < len0 : t - p.T < len1;
+        const bool keep = rows1 ? live[i][ps] > 0 : (t < p.T ? t < len0 : t - p.T < len1);
         if (!keep) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -670,7 +686,7 @@ inline int lean_epilogue_of(const GemmParams& p, int splits) {
   static const int off = [] { const char* e = getenv("VG_NO_LEAN_EPI"); return e ? atoi(e) : 0; }();
   if (off) return EPI_GENERIC;
   if (p.out_f32 || p.accumulate || splits != 1 || p.alpha != 1.0f || p.split_ws || p.colsum_out) return EPI_GENERIC;
-  if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.lengths != nullptr && p.T < 16)) return EPI_GENERIC;
+  if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.lengths != nullptr && p.T < 16 && p.T != 1)) return EPI_GENERIC;
   // the lean epilogues move C / residual / aux / pre_add as bf16x8 and the bias as f32x4: an output view whose first
   // column is not a multiple of 8 (or a bias slice off a 4-float boundary) takes the element-wise generic epilogue
   const uintptr_t ptrs16 = (uintptr_t)p.C | (uintptr_t)p.residual | (p.aux_u8 ? 0 : ((uintptr_t)p.aux_in | (uintptr_t)p.aux_out)) |

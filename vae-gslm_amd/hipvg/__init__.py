@@ -59,6 +59,7 @@ SIGNATURES = {
     "vg_last_error": [C.c_char_p, _i],
     "vg_gemm": [C.POINTER(GemmDesc), _vp],
     "vg_gemm_tile_rows": [C.POINTER(GemmDesc)],
+    "vg_gemm_colpart_rows": [C.POINTER(GemmDesc)],
     "vg_gemm_grouped": [C.POINTER(GemmDesc), _i, _vp],
     "vg_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp],
     "vg_rmsnorm_bwd_blocks": [_i],
@@ -242,7 +243,7 @@ class _RoctxLib:
         fn = self._cache.get(name)
         if fn is None:
             raw = getattr(self._h, name)
-            if name.endswith("_blocks") or name in ("vg_version", "vg_last_error", "vg_comm_world", "vg_gemm_tile_rows"):
+            if name.endswith("_blocks") or name in ("vg_version", "vg_last_error", "vg_comm_world", "vg_gemm_tile_rows", "vg_gemm_colpart_rows"):
                 fn = raw
             else:
                 tag, push, pop = name.encode(), self._push, self._pop

@@ -50,3 +50,25 @@ def all_reduce_(flat: torch.Tensor, average: bool = True, stream=None) -> None:
 
 def destroy() -> None:
     check(lib().vg_comm_destroy(), "vg_comm_destroy")
+
+
+def masked_stream(device, n_cus: int, total_cus: int = 256):
+    """A HIP stream whose kernels may only run on ``n_cus`` of the GPU's compute units (hipExtStreamCreateWithCUMask), spread
+    evenly over the XCDs, as a ``torch.cuda.ExternalStream``.  Lab / tuning knob for the communication stream
+    (training_lib/dp.py, ``VG_COMM_CU_MASK``): collective kernels confined to a few CUs cannot take a GEMM tile's CU in the
+    middle of a round.  The stream is never destroyed (one per process)."""
+    import ctypes
+    n_cus = max(1, min(int(n_cus), total_cus))
+    words = (total_cus + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    step = total_cus / n_cus
+    for i in range(n_cus):
+        cu = int(i * step)
+        mask[cu // 32] |= 1 << (cu % 32)
+    hip = ctypes.CDLL("libamdhip64.so")
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=device)

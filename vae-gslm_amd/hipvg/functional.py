@@ -218,9 +218,11 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_tr=False, b_tr=False
     if colpart is not None and split_k <= 1:
         # per-row-tile column sums of the result from the same launch (the caller reduces the few rows): only
         # on the LDS-DMA path, whose tile height the library reports for this descriptor
-        rows = lib().vg_gemm_tile_rows(C.byref(d))
-        if rows > 0:
-            part = torch.empty(((M + rows - 1) // rows, N), dtype=torch.float32, device=A.device)
+        # (the library says how many row-tiles the call writes: a product it splits over two launches -- whole rounds of
+        # 256-row tiles + the remaining row band on another tile shape -- has more than ceil(M / tile rows))
+        nrows = lib().vg_gemm_colpart_rows(C.byref(d))
+        if nrows > 0:
+            part = torch.empty((nrows, N), dtype=torch.float32, device=A.device)
             d.colpart = ptr(part)
     if colpart is not None:
         colpart.append(part)

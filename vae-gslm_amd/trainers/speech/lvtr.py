@@ -191,8 +191,10 @@ class LVTRTrainer(BaseTrainer):
             boundaries += (list(stack.layers[nl - 1].parameters())[-1],)
             if late:
                 boundaries += (late[-1],)
+        wire = str(hip.get("comm_dtype", "fp32")) if hip is not None else "fp32"
+        wire = os.environ.get("VG_COMM_DTYPE", wire)
         self.reducer = GradReducer(params, bucket_mb=bucket, overlap=overlap, group=group, comm=comm,
-                                   boundaries=boundaries)
+                                   boundaries=boundaries, wire_dtype=wire)
         self._cut_layers, self._early_buckets = [], []
         if self._segmented:
             top = nl

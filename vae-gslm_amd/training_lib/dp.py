@@ -34,7 +34,7 @@ import torch.distributed as dist
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 50.0,
                  overlap: bool = True, group: Optional[dist.ProcessGroup] = None, comm: str = "torch",
-                 boundaries=()):
+                 boundaries=(), wire_dtype: str = "fp32"):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -43,6 +43,18 @@ class GradReducer:
         if comm not in ("torch", "abi"):
             raise ValueError(f"hip.comm must be 'torch' or 'abi', got {comm!r}")
         self.comm = comm
+        # hip.comm_dtype (round 6): "fp32" (default) sends the flat fp32 buckets as they are -- 908 MB per optimizer step
+        # at the full configuration; "bf16" sends a bf16 copy (454 MB): on the communication stream the bucket is cast
+        # into a bf16 staging buffer, that buffer is all-reduced (the collective adds and averages in bf16), and the
+        # result is written back over the fp32 bucket, which the optimizer reads as before.  xGMI is point-to-point
+        # (7 links x ~153 GB/s per GPU): a ring all-reduce moves 2 (N - 1) / N of the bytes over ONE link direction per
+        # step, so at N = 8 the fp32 wire is >= 10 ms of link time per step if RCCL ends up on one ring and the bf16
+        # wire half of it.  Cost: every rank's gradient is rounded to 8 significant bits before the sum and the partial
+        # sums again (tests/test_dp_gloo.py bounds the difference from the fp32 wire); two more elementwise launches
+        # per bucket on the communication stream.  Opt-in.
+        if wire_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"hip.comm_dtype must be 'fp32' or 'bf16', got {wire_dtype!r}")
+        self.wire_dtype = wire_dtype
         # Collectives run when there is more than one rank -- or, VG_DP_SINGLE_RANK=1, on a ONE-rank communicator: the
         # whole data-parallel step (segmented hipGraph replay, bucket launches on the communication stream, per-bucket
         # optimizer waits) through real RCCL on a one-GPU box.  The average over one rank is the identity, so the run
@@ -76,6 +88,12 @@ class GradReducer:
         self.last_launch_log = []
         dev = self.params[0].device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        cu_mask = int(os.environ.get("VG_COMM_CU_MASK", "0"))
+        if cu_mask > 0 and dev.type == "cuda" and self.exchange:
+            # lab: the communication stream confined to `cu_mask` CUs; measured on a one-rank RCCL
+            # communicator in profiles/r06/labs/ -- not the default
+            from hipvg.comm import masked_stream
+            self.comm_stream = masked_stream(dev, cu_mask)
         limit = int(bucket_mb * (1 << 20) / 4)
         # reverse order: the last-registered parameters receive gradients first.  Every parameter starts
         # on a 256-element boundary of its bucket (1 KiB): the flat optimizer kernel (vg_adamw) works on
@@ -112,7 +130,8 @@ class GradReducer:
             p.grad = flat[off: off + p.numel()].view_as(p)
             offsets.append(off)
             off += self._padded(p.numel())
-        self.buckets.append(dict(params=plist, offsets=offsets, flat=flat, pending=len(plist), need=len(plist)))
+        wire = torch.empty(n, dtype=torch.bfloat16, device=dev) if (self.wire_dtype == "bf16" and self.exchange) else None
+        self.buckets.append(dict(params=plist, offsets=offsets, flat=flat, wire=wire, pending=len(plist), need=len(plist)))
 
     def new_backward(self, signature=None) -> None:
         """Call before every backward pass.  A parameter can report "gradient ready" several times in one pass: once
@@ -204,8 +223,25 @@ class GradReducer:
             else:
                 break
 
-    def _timed_allreduce(self, flat):
+    def _timed_allreduce(self, flat, wire=None):
         if self.stub_collectives:
+            return None
+        if wire is not None:
+            # bf16 wire: cast, exchange, write back -- all on the stream this runs on (the communication stream); the
+            # handle of an asynchronous collective is waited for HERE (a stream-level wait) so that the write-back is
+            # ordered behind it, and the bucket then has no handle: wait_bucket() waits for the stream
+            wire.copy_(flat)
+            a = b = None
+            if self.time_collectives and flat.is_cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            h = self._allreduce(wire)
+            if h is not None:
+                h.wait()
+            if a is not None:
+                b.record()
+                self._comm_events.append((a, b, wire.numel() * wire.element_size()))
+            flat.copy_(wire)
             return None
         if not (self.time_collectives and flat.is_cuda):
             return self._allreduce(flat)
@@ -243,13 +279,13 @@ class GradReducer:
             for st in writers:
                 self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
-                h = self._timed_allreduce(b["flat"])
+                h = self._timed_allreduce(b["flat"], b.get("wire"))
         else:
             cur = torch.cuda.current_stream() if b["flat"].is_cuda else None
             for st in writers:
                 if st.cuda_stream != cur.cuda_stream:
                     cur.wait_stream(st)
-            h = self._timed_allreduce(b["flat"])
+            h = self._timed_allreduce(b["flat"], b.get("wire"))
         b["handle"], b["launched"] = h, True
         self.launch_log.append((next(i for i, x in enumerate(self.buckets) if x is b), self.phase))
         self._handles.append(h)
@@ -278,7 +314,7 @@ class GradReducer:
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         h.wait()
-        flat.div_(self.world)
+        flat.div_(self.world)          # (a bf16 wire divides in bf16 too: exact for a power-of-two world)
         return None
 
     def reduce_all(self) -> None:
