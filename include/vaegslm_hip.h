@@ -316,6 +316,24 @@ int vg_dwnorm_bwd_seg(const void* dy, const void* x, const float* w, const float
                       const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
                       float* norm_part, float* w_part, int M, int C, const int32_t* cu_rows, int nseq, int nbatch, int taps,
                       int shift, int dtype, vg_stream_t stream);
+/* Round 6: the conditioning of a conv block merged into its first 1x1 convolution.  The reference concatenates the
+ * condition channels to the normalised activations (modules/conv/layers.py:112-113, "concat" conditioning) and runs one
+ * Conv1d(k=1) over C + cond channels; until round 5 this build ran a K = C product with a pre-activation operand that a
+ * K = cond_cols (32) product had written first (65 MB out, 65 MB back in, two launches of 38 - 43 us for 2 GFLOP).
+ * vg_dwnorm_fwd_cat writes y rows `ldy` elements apart (ldy >= C + 64) and appends to every row its condition channels
+ * and zeros up to column C + 64 (cond: bf16 [M][ldcond], cond_cols <= 64, a multiple of 8; NULL: no tail), so the 1x1
+ * convolution is ONE vg_gemm over K = C + 64 against the weight zero-padded to the same width, and its dgrad
+ * (N = C + 64) yields d(norm output) and d(cond) side by side; vg_dwnorm_bwd_ld is vg_dwnorm_bwd / _seg reading the
+ * incoming gradient rows `ldy` elements apart.  bf16, C = 512, 7 taps; cu_rows = NULL: M / T sequences of T rows, else
+ * packed rows as in the _seg entry points. */
+int vg_dwnorm_fwd_cat(const void* x, const float* w, const float* cbias, const float* temb, const float* gamma,
+                      const float* beta, void* y, int64_t ldy, const void* cond, int64_t ldcond, int cond_cols,
+                      float* mean, float* rstd, int M, int C, int T, const int32_t* cu_rows, int nseq, int nbatch,
+                      int taps, int shift, float eps, int dtype, vg_stream_t stream);
+int vg_dwnorm_bwd_ld(const void* dy, int64_t ldy, const void* x, const float* w, const float* cbias, const float* temb,
+                     const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
+                     float* norm_part, float* w_part, int M, int C, int T, const int32_t* cu_rows, int nseq, int nbatch,
+                     int taps, int shift, int dtype, vg_stream_t stream);
 
 /* ---------------------------------------------------------------- autoregressive decode step
  * LVTR.step (models/speech/lvtr.py:227-286): one new frame per sequence.

@@ -211,6 +211,76 @@ def test_transformer_layer_gradients_with_u8_derivative(F):
         assert d < 8e-3, f"{n}: the two bf16 runs differ by {d:.2e} of the norm"
 
 
+# ---------------------------------------------------------------- conv block: the conditioning inside the first 1x1 convolution
+@pytest.mark.parametrize("M,T", [(2048, 512), (1400, 700)], ids=["grouped-wgrads", "small-wgrads"])
+def test_conv_block_condition_merged_into_the_product(F, M, T):
+    """hipvg.functional.conv_block (one BottleneckBlock of the UNet, modules/conv/layers.py:70-135 of the reference: 1x1
+    convolution over [norm(dwconv(x) + t_emb) ; cond]) with the condition channels appended by the norm kernel and ONE
+    K = 576 product (round 6) against the round-5 form (K = 512 product + a pre-activation operand from a K = 32 product),
+    and both against float64 arithmetic on the same bf16 inputs: the merged form must be at least as close (the
+    pre-activation operand was rounded to bf16 on its way), forward and every gradient."""
+    import hipvg
+    prev_dt = hipvg.compute_dtype()
+    hipvg.set_precision("bf16")
+    C, Hd, Kc, taps, shift = 512, 2048, 32, 7, 3
+    B = M // T
+    g = torch.Generator().manual_seed(4)
+
+    def rn(*s_, scale=1.0):
+        return (torch.randn(*s_, generator=g) * scale).to(dev())
+
+    x0 = rn(M, C).bfloat16()
+    cond0 = rn(M, Kc).bfloat16()
+    te0 = rn(B, C, scale=0.3)
+    params = dict(c1w=rn(C, 1, taps, scale=0.4), c1b=rn(C, scale=0.1), nw=1 + rn(C, scale=0.1), nb=rn(C, scale=0.1),
+                  c2w=rn(Hd, C + Kc, 1, scale=(C + Kc) ** -0.5), c2b=rn(Hd, scale=0.1), c3w=rn(C, Hd, 1, scale=Hd ** -0.5), c3b=rn(C, scale=0.1))
+    gy = rn(M, C).bfloat16()
+    res = {}
+    try:
+        for merged in (False, True):
+            old = F._COND_MERGE
+            F._COND_MERGE = merged
+            try:
+                leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+                x, cond, te = x0.clone().requires_grad_(True), cond0.clone().requires_grad_(True), te0.clone().requires_grad_(True)
+                y = F.conv_block(x, te, cond, leaves["c1w"], leaves["c1b"], leaves["nw"], leaves["nb"], leaves["c2w"], leaves["c2b"],
+                                 leaves["c3w"], leaves["c3b"], T=T, taps=taps, shift=shift, eps=1e-5, act="silu")
+                (y.float() * gy.float()).sum().backward()
+                if hasattr(F, "flush_wgrads"):
+                    F.flush_wgrads()
+                torch.cuda.synchronize()
+                gr = {k: v.grad.float().clone() for k, v in leaves.items()}
+                gr.update(x=x.grad.float().clone(), cond=cond.grad.float().clone(), te=te.grad.float().clone())
+                res[merged] = (y.detach().float().clone(), gr)
+            finally:
+                F._COND_MERGE = old
+    finally:
+        hipvg.set_precision(prev_dt)
+    # float64 reference of the block on the same bf16 inputs (channels-last rows; the depthwise conv reads frames
+    # t + k - shift of its own sequence, zeros outside)
+    xd, cd, ted = x0.double().requires_grad_(True), cond0.double().requires_grad_(True), te0.double().requires_grad_(True)
+    pd = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    xs = xd.view(B, T, C)
+    pad = torch.nn.functional.pad(xs, (0, 0, shift, taps - 1 - shift))
+    conv = sum(pad[:, k:k + T] * pd["c1w"][:, 0, k] for k in range(taps)) + pd["c1b"] + ted[:, None, :]
+    mu = conv.mean(-1, keepdim=True)
+    var = ((conv - mu) ** 2).sum(-1, keepdim=True) / (C - 1)
+    u = ((conv - mu) / torch.sqrt(var + 1e-5) * pd["nw"] + pd["nb"]).reshape(M, C)
+    pre = torch.cat([u, cd], 1) @ pd["c2w"][:, :, 0].t() + pd["c2b"]
+    yref = xd + torch.nn.functional.silu(pre) @ pd["c3w"][:, :, 0].t() + pd["c3b"]
+    (yref * gy.double()).sum().backward()
+    gref = {k: v.grad for k, v in pd.items()}
+    gref.update(x=xd.grad, cond=cd.grad, te=ted.grad)
+
+    def rel(a, b):
+        return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
+    e_old, e_new = rel(res[False][0], yref.detach()), rel(res[True][0], yref.detach())
+    assert e_new <= 1.05 * e_old + 1e-4 and e_new < 2e-2, (e_old, e_new)
+    for k in gref:
+        e_old, e_new = rel(res[False][1][k].reshape(gref[k].shape), gref[k]), rel(res[True][1][k].reshape(gref[k].shape), gref[k])
+        assert e_new <= 1.1 * e_old + 2e-3 and e_new < 4e-2, (k, e_old, e_new)
+
+
 # ---------------------------------------------------------------- partial rounds: the rows of a product over two launches
 @pytest.mark.parametrize("M,N,K", [(13312, 4096, 1024), (13312, 3072, 1024), (10240, 4096, 1024), (13000, 4096, 512)])
 def test_split_rows_equals_one_launch(F, M, N, K, monkeypatch):

@@ -69,6 +69,15 @@ struct DwArgs {
   // sequences of Tn rows each
   const int* cu = nullptr;
   int nseq = 0, nbatch = 0;
+  // round 6 (the run kernels only; vg_dwnorm_fwd_cat / vg_dwnorm_bwd_ld): the forward's output rows / the backward's
+  // incoming-gradient rows are `ldy` elements apart (0: C), and the forward appends the block's condition channels to
+  // every output row -- y[row][C + j] = cond[row][j] for j < cond_cols, 0 up to C + 64 -- so that the 1x1 convolution
+  // over [norm(dwconv(x)) ; cond] (modules/conv/layers.py:112-113) is ONE product over K = C + 64 instead of a K = C
+  // product with a pre-activation operand that a K = 32 product wrote first
+  long ldy = 0;
+  const bf16_t* cond = nullptr;
+  long ldcond = 0;
+  int cond_cols = 0;
 };
 
 // The frame-invariant parameters (taps x C weights, conv bias, norm affine) reach the lanes through LDS: one
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __res
   if (gamma) load8(gamma + lane * 8, gm);
   if (beta) load8(beta + lane * 8, bt);
   const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
+  const long ldy = a.ldy > 0 ? a.ldy : a.C;
   for (int run = blockIdx.x * (blockDim.x >> 6) + wave; run < sr.nruns; run += gridDim.x * (blockDim.x >> 6)) {
     int b, bte, t0, Tn;
     long rbase;
@@ -453,7 +463,12 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __res
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = fmaf(gm[e], (v[f][e] - mean[f]) * rstd[f], bt[e]);
-        V8<bf16_t>::store(y + (row0 + f) * a.C + lane * 8, o);
+        V8<bf16_t>::store(y + (row0 + f) * ldy + lane * 8, o);
+        if (a.cond != nullptr && lane < 8) {        // the row's 64-column tail: condition channels, then zeros
+          uint4 c = make_uint4(0u, 0u, 0u, 0u);
+          if (lane * 8 < a.cond_cols) c = *reinterpret_cast<const uint4*>(a.cond + (row0 + f) * a.ldcond + lane * 8);
+          *reinterpret_cast<uint4*>(y + (row0 + f) * ldy + a.C + lane * 8) = c;
+        }
         if (lane == 0) { mean_out[row0 + f] = mean[f]; rstd_out[row0 + f] = rstd[f]; }
       }
     }
@@ -486,6 +501,7 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
   if (cbias) load8(cbias + lane * 8, cb);
   if (gamma) load8(gamma + lane * 8, gm);
   const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
+  const long ldy = a.ldy > 0 ? a.ldy : a.C;
   for (int run = blockIdx.x * 4 + wave; run < sr.nruns; run += gridDim.x * 4) {
     int b, bte, t0, Tn;
     long rbase;
@@ -500,7 +516,7 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
     }
 #pragma unroll
     for (int f = 0; f < RF; ++f)
-      rdy[f] = *reinterpret_cast<const uint4*>(dy + (rbase + min(t0 + f, Tn - 1)) * a.C + lane * 8);
+      rdy[f] = *reinterpret_cast<const uint4*>(dy + (rbase + min(t0 + f, Tn - 1)) * ldy + lane * 8);
     float v[RF][8];
     {
       float te[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -989,4 +1005,56 @@ extern "C" int vg_dwnorm_bwd_seg(const void* dy, const void* x, const float* w, 
                                                                    (const bf16_t*)dx_add, (bf16_t*)dx, w_part, a);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_dwnorm_bwd_seg");
+}
+
+
+// ---- round 6: the conv block's conditioning merged into its first 1x1 convolution (DwArgs::ldy / cond).  bf16, C = 512,
+// 7 taps (the run kernels: every conditional block of vae-gslm.yaml); cu_rows == nullptr: M / T sequences of T rows,
+// else packed rows as in vg_dwnorm_fwd_seg.
+static int check_cat(const char* who, int M, int C, int T, const int* cu_rows, int nseq, int nbatch, int taps, int dtype, long ldy) {
+  VG_REQUIRE(dtype == VG_BF16 && C == 512 && taps == 7, "%s: needs bf16, C = 512, 7 taps (C=%d taps=%d dtype=%d)", who, C, taps, dtype);
+  VG_REQUIRE(M > 0 && ldy >= C && ldy % 8 == 0, "%s: M=%d ldy=%ld", who, M, ldy);
+  if (cu_rows != nullptr) VG_REQUIRE(nseq >= 1 && nseq <= 64 && nbatch >= 1 && nbatch <= nseq, "%s: nseq=%d (1..64) nbatch=%d", who, nseq, nbatch);
+  else VG_REQUIRE(T > 0 && M % T == 0, "%s: M=%d is not a multiple of T=%d", who, M, T);
+  return 0;
+}
+
+extern "C" int vg_dwnorm_fwd_cat(const void* x, const float* w, const float* cbias, const float* temb, const float* gamma,
+                                 const float* beta, void* y, int64_t ldy, const void* cond, int64_t ldcond, int cond_cols,
+                                 float* mean, float* rstd, int M, int C, int T, const int* cu_rows, int nseq, int nbatch,
+                                 int taps, int shift, float eps, int dtype, hipStream_t stream) {
+  if (int e = check_cat("vg_dwnorm_fwd_cat", M, C, T, cu_rows, nseq, nbatch, taps, dtype, (long)ldy)) return e;
+  VG_REQUIRE(cond == nullptr || (cond_cols > 0 && cond_cols <= 64 && cond_cols % 8 == 0 && ldcond % 8 == 0 && ldy >= C + 64 &&
+                                 ((uintptr_t)cond % 16) == 0),
+             "vg_dwnorm_fwd_cat: the condition tail is 64 columns of 16-byte pieces (cond_cols=%d ldcond=%ld ldy=%ld)", cond_cols,
+             (long)ldcond, (long)ldy);
+  DwArgs a{M, C, cu_rows ? M : T, taps, shift, eps, cu_rows, cu_rows ? nseq : 0, cu_rows ? nbatch : 0};
+  a.ldy = (long)ldy;
+  a.cond = (const bf16_t*)cond;
+  a.ldcond = (long)ldcond;
+  a.cond_cols = cond ? cond_cols : 0;
+  const int tok = vg_host::prof_begin(VG_PROF_DWNORM_FWD, (double)M * (2.0 * C * 2 + 8.0 + (cond ? 2.0 * cond_cols + 128.0 : 0.0)), stream);
+  const int nruns = cu_rows ? M / RUNF + nseq : (M / T) * ((T + RUNF - 1) / RUNF);
+  dwnorm_fwd_run_kernel<7><<<dim3(min((nruns + 3) / 4, 1024)), dim3(256), 0, stream>>>(
+      (const bf16_t*)x, w, cbias, temb, gamma, beta, (bf16_t*)y, mean, rstd, a);
+  vg_host::prof_end(tok, stream);
+  return vg_host::check_launch("vg_dwnorm_fwd_cat");
+}
+
+extern "C" int vg_dwnorm_bwd_ld(const void* dy, int64_t ldy, const void* x, const float* w, const float* cbias, const float* temb,
+                                const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
+                                float* norm_part, float* w_part, int M, int C, int T, const int* cu_rows, int nseq, int nbatch,
+                                int taps, int shift, int dtype, hipStream_t stream) {
+  if (int e = check_cat("vg_dwnorm_bwd_ld", M, C, T, cu_rows, nseq, nbatch, taps, dtype, (long)ldy)) return e;
+  DwArgs a{M, C, cu_rows ? M : T, taps, shift, 0.f, cu_rows, cu_rows ? nseq : 0, cu_rows ? nbatch : 0};
+  a.ldy = (long)ldy;
+  const int nb = vg_dwnorm_blocks(M);          // the caller sized the partial-sum arrays for it
+  const int tok = vg_host::prof_begin(VG_PROF_DWNORM_BWD, (double)M * ((dx_add ? 5.0 : 4.0) * C * 2 + 8.0), stream);
+  dwnorm_bwd_norm_run_kernel<7, 4><<<dim3(nb), dim3(256), 0, stream>>>((const bf16_t*)dy, (const bf16_t*)x, w, cbias, temb, gamma,
+                                                                   mean, rstd, (bf16_t*)du, norm_part, a);
+  a.ldy = 0;                                   // (the second kernel reads the first one's dense du)
+  dwnorm_bwd_conv_run_kernel<7, 4><<<dim3(nb), dim3(256), 0, stream>>>((const bf16_t*)du, (const bf16_t*)x, w,
+                                                                   (const bf16_t*)dx_add, (bf16_t*)dx, w_part, a);
+  vg_host::prof_end(tok, stream);
+  return vg_host::check_launch("vg_dwnorm_bwd_ld");
 }

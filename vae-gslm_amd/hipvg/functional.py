@@ -1686,6 +1686,66 @@ def dwnorm_bwd_raw(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
     return du, dx, npart[:, :Cc], npart[:, Cc:], (wpart if taps > 0 else None)
 
 
+# round 6: the conditioning of a conv block rides in its first 1x1 convolution (one K = C + 64 product instead of a K = C
+# product that adds what a K = 32 product wrote first; include/vaegslm_hip.h: vg_dwnorm_fwd_cat).  VG_COND_MERGE=0: the
+# round-5 form (pre-activation operand), for A/B runs.
+_COND_MERGE = _flag("VG_COND_MERGE", "1")
+
+
+def _cond_merge_ok(x: Tensor, cond, taps: int) -> bool:
+    return (_COND_MERGE and cond is not None and x.dtype == torch.bfloat16 and x.shape[1] == 512 and taps == 7
+            and cond.dtype == torch.bfloat16 and cond.dim() == 2 and cond.shape[1] % 8 == 0 and 0 < cond.shape[1] <= 64
+            and cond.stride(1) == 1 and cond.stride(0) % 8 == 0 and cond.data_ptr() % 16 == 0)
+
+
+def _padded_weight(s2: Tensor, Kx: int) -> Tensor:
+    """The bf16 [Hd, C + cond] weight of the 1x1 convolution over [activations ; condition] as [Hd, Kx] with zero columns
+    up to Kx = C + 64 (whole 64-deep K tiles for the phase-pipelined GEMM kernels).  A buffer per weight, its zero tail
+    written once; the live columns are re-copied on every call (one 2.4 MB launch: the optimizer rewrites the source, and
+    inside a hipGraph the copy is a node like any other)."""
+    Hd, Kw = s2.shape
+    buf = getattr(s2, "_vg_kpad", None)
+    if buf is None or buf.shape != (Hd, Kx) or buf.device != s2.device:
+        buf = torch.zeros((Hd, Kx), dtype=s2.dtype, device=s2.device)
+        try:
+            s2._vg_kpad = buf
+        except AttributeError:
+            pass
+    buf[:, :Kw].copy_(s2)
+    return buf
+
+
+def dwnorm_fwd_cat_raw(x, w, cb, te, gamma, beta, T, taps, shift, eps, cond, Kx):
+    """dwnorm_fwd_raw whose output rows are Kx wide: [norm(dwconv(x) + te) ; cond ; 0] (vg_dwnorm_fwd_cat)."""
+    M, Cc = x.shape
+    y = torch.empty((M, Kx), dtype=x.dtype, device=x.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    plan = T if isinstance(T, PackPlan) else None
+    check(lib().vg_dwnorm_fwd_cat(ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(beta), ptr(y), Kx, ptr(cond),
+                                  cond.stride(0), cond.shape[1], ptr(mean), ptr(rstd), M, Cc, 0 if plan else int(T),
+                                  ptr(plan.cu) if plan else None, plan.nseq if plan else 0, plan.B if plan else 0,
+                                  int(taps), int(shift), float(eps), dtype_id(x.dtype), stream()), "vg_dwnorm_fwd_cat")
+    return y, mean, rstd
+
+
+def dwnorm_bwd_ld_raw(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
+    """dwnorm_bwd_raw for an incoming gradient that is the first C columns of wider rows (vg_dwnorm_bwd_ld)."""
+    M, Cc = x.shape
+    assert dy.shape[0] == M and dy.stride(1) == 1 and dy.stride(0) >= Cc
+    nb = lib().vg_dwnorm_blocks(M)
+    du = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    npart = torch.empty((nb, 2 * Cc), dtype=torch.float32, device=x.device)
+    wpart = torch.empty((nb, Cc * taps), dtype=torch.float32, device=x.device)
+    plan = T if isinstance(T, PackPlan) else None
+    check(lib().vg_dwnorm_bwd_ld(ptr(dy), dy.stride(0), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
+                                 ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, 0 if plan else int(T),
+                                 ptr(plan.cu) if plan else None, plan.nseq if plan else 0, plan.B if plan else 0,
+                                 int(taps), int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd_ld")
+    return du, dx, npart[:, :Cc], npart[:, Cc:], wpart
+
+
 def conv_rows_packable(x: Tensor, taps: int) -> bool:
     """Can a conv block of this shape run on packed rows (``vg_dwnorm_*_seg``: bf16, 512 channels, 7 taps)?"""
     return x.dtype == torch.bfloat16 and x.shape[1] == 512 and taps == 7
@@ -1716,29 +1776,42 @@ class ConvBlockFn(torch.autograd.Function):
         cb = c1b.detach().float().contiguous()
         gamma, beta = nw.detach().float().contiguous(), nb_.detach().float().contiguous()
         te32 = None if te is None else te.detach().float().contiguous()
-        u, mean, rstd = dwnorm_fwd_raw(x, w1, cb, te32, gamma, beta, T, taps, shift, eps)
         s2 = shadow(c2w, dt).view(Hd, -1)
         s3 = shadow(c3w, dt).view(Cc, Hd)
-        Wa = s2[:, :Cc]
-        pre_add = None
-        if cond is not None:
-            Wc = s2[:, Cc:]
-            pre_add = gemm(cond, Wc, M, Hd, cond.shape[1])
         # pre receives act'(pre-activation) (ReLU: the output itself carries it)
         pre = torch.empty((M, Hd), dtype=dt, device=x.device) if act != ACT_RELU else None
-        h = gemm(u, Wa, M, Hd, Cc, bias=c2b.detach().float(), pre_add=pre_add,
-                 act=(act | ACT_SAVE_DERIV) if pre is not None else act, aux_out=pre)
+        merged = _cond_merge_ok(x, cond, taps)
+        if merged:
+            # one product over K = C + 64: the norm kernel appends the condition channels (and zeros) to its output rows,
+            # the weight is zero-padded to the same width (round 6; was: K = C product + a pre-activation operand written
+            # by a K = 32 product)
+            Kx = Cc + 64
+            u, mean, rstd = dwnorm_fwd_cat_raw(x, w1, cb, te32, gamma, beta, T, taps, shift, eps, cond, Kx)
+            # (kept on ctx, not among the saved tensors: the buffer is rewritten -- with the same values -- by the next
+            # forward of this block, which autograd's version check would take for a hazard)
+            ctx.wpad = _padded_weight(s2, Kx)
+            h = gemm(u, ctx.wpad, M, Hd, Kx, bias=c2b.detach().float(),
+                     act=(act | ACT_SAVE_DERIV) if pre is not None else act, aux_out=pre)
+        else:
+            u, mean, rstd = dwnorm_fwd_raw(x, w1, cb, te32, gamma, beta, T, taps, shift, eps)
+            Wa = s2[:, :Cc]
+            pre_add = None
+            if cond is not None:
+                Wc = s2[:, Cc:]
+                pre_add = gemm(cond, Wc, M, Hd, cond.shape[1])
+            h = gemm(u, Wa, M, Hd, Cc, bias=c2b.detach().float(), pre_add=pre_add,
+                     act=(act | ACT_SAVE_DERIV) if pre is not None else act, aux_out=pre)
         y = gemm(h, s3, M, Cc, Hd, bias=c3b.detach().float(), residual=x)
         ctx.save_for_backward(x, u, mean, rstd, h, pre, cond, s2, s3, w1, cb, te32, gamma)
         ctx.params = (c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b)
-        ctx.meta = (T, taps, shift, act, te is not None)
+        ctx.meta = (T, taps, shift, act, te is not None, merged)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, u, mean, rstd, h, pre, cond, s2, s3, w1, cb, te32, gamma = ctx.saved_tensors
         c1w, c1b, nw, nb_, c2w, c2b, c3w, c3b = ctx.params
-        T, taps, shift, act, has_te = ctx.meta
+        T, taps, shift, act, has_te, merged = ctx.meta
         M, Cc = x.shape
         Hd = s2.shape[0]
         dt = x.dtype
@@ -1779,14 +1852,26 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             g_c3 = wgrad_into(c3w, Cc, 0, Hd, dy, h, c3b)
         g_c3b = None if id(c3b) in fused_bias else vec_grad(c3b, dy)
-        du = gemm(dpre, Wa, M, Cc, Hd, b_tr=True)
-        if grouped:
-            ga = None
-            group.append((c2w, dpre, u, 0))
-        else:
-            ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u, c2b)
         dcond = gc = None
-        if cond is not None:
+        if merged:
+            # (ctx.wpad is the zero-padded [Hd, C + 64] weight, u the [M, C + 64] rows [norm output ; cond ; 0]): one dgrad gives
+            # d(norm output) and d(cond) side by side, one weight gradient covers both column ranges of c2w
+            Kc = cond.shape[1]
+            du_x = gemm(dpre, ctx.wpad, M, Cc + 64, Hd, b_tr=True)
+            du, dcond = du_x[:, :Cc], du_x[:, Cc:Cc + Kc]
+            if grouped:
+                ga = None
+                group.append((c2w, dpre, u[:, :Cc + Kc], 0))
+            else:
+                ga = wgrad_into(c2w, Hd, 0, Cc + Kc, dpre, u[:, :Cc + Kc], c2b)
+        else:
+            du = gemm(dpre, Wa, M, Cc, Hd, b_tr=True)
+            if grouped:
+                ga = None
+                group.append((c2w, dpre, u, 0))
+            else:
+                ga = wgrad_into(c2w, Hd, 0, Cc, dpre, u, c2b)
+        if cond is not None and not merged:
             Wc = s2[:, Cc:]
             Kc = cond.shape[1]
             dcond = gemm(dpre, Wc, M, Kc, Hd, b_tr=True)
@@ -1809,7 +1894,10 @@ class ConvBlockFn(torch.autograd.Function):
                 _fire(c3w)
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
-        dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
+        if merged:
+            dv, dx, pg, pb, pw = dwnorm_bwd_ld_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
+        else:
+            dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
         if isinstance(T, PackPlan):
             dte = segment_colsum(dv, T)[:T.B]          # per-sequence sums; the pseudo sequences' rows carry no gradient
         else:
