@@ -1062,6 +1062,31 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     kinit[i] = slope * 8.0f * (float)acc_row(i, lane);
     dinit[i] = -dl;
   }
+  // Round 6 (bf16): everything that was added to or multiplied into the products per element now rides in the products
+  // themselves, as in the forward (attn2_fwd_kernel).  Q is pre-scaled by log2(e) / sqrt(d) -- the very rounding the
+  // forward applied, so the recomputed scores are the forward's -- and a FIFTH k-step carries the additive terms:
+  //   S':  K side (1, 1, row term hi, lo), Q side (c hi, c lo, 1, 1) with c = slope2 (tile start - first query) - L_q
+  //   dP': K side the same registers,      dO side (-delta hi, -delta lo, 0, 0) -- loop-invariant
+  // (two bf16 per constant: 16 significant bits).  Per 32 x 32 block that is 2 more MFMAs on a pipe that was 18 % busy and
+  // 16 fma + 16 v_mov (the compiler rebuilt the 16-register -delta vector for every block) fewer on the issue port that
+  // bounds the kernel: the census (tools/isa_census.py) went from 146 to 110 vector instructions per block.
+  [[maybe_unused]] bf16x8 kext, dext;
+  [[maybe_unused]] float Lfin = 0.f;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf.f[st][j] = (bf16_t)((float)qf.f[st][j] * c2);
+    const float rt = slope2 * (float)(lane & 31);
+    const bf16_t rhi = (bf16_t)rt, rlo = (bf16_t)(rt - (float)rhi);
+    const float nd = -dl;
+    const bf16_t dhi = (bf16_t)nd, dlo = (bf16_t)(nd - (float)dhi);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kext[j] = (bf16_t)0.0f; dext[j] = (bf16_t)0.0f; }
+    kext[0] = (bf16_t)1.0f; kext[1] = (bf16_t)1.0f; kext[2] = rhi; kext[3] = rlo;
+    if (lane < 32) { dext[0] = dhi; dext[1] = dlo; }
+    Lfin = qvalid ? Lq : 1.0e30f;          // (finite: the hi / lo split of an infinity is a NaN; 2^-1e30 is 0 all the same)
+  }
 
   f32x16 dq[2] = {zero16(), zero16()};
   for (int kt = nkt - 1; kt >= kt_lo; --kt) {
@@ -1087,7 +1112,18 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     const bool diag = kv0 + TB - 1 > qw0;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, kinit);
+      f32x16 s, dp;
+      if constexpr (sizeof(T) == 2) {
+        const float cst = slope2 * (float)(kv0 + kb * 32 - qw0) - Lfin;
+        const bf16_t hi = (bf16_t)cst, lo = (bf16_t)(cst - (float)hi);
+        bf16x8 qext;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qext[j] = (bf16_t)0.0f;
+        if (lane < 32) { qext[0] = hi; qext[1] = lo; qext[2] = (bf16_t)1.0f; qext[3] = (bf16_t)1.0f; }
+        s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, Traits<T>::mfma(kext, qext, zero16()));
+      } else {
+        s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, kinit);
+      }
       if (diag) {
         const int lim = query - kv0 - kb * 32;
 #pragma unroll
@@ -1096,10 +1132,17 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       const float off = slope2 * (float)(kv0 + kb * 32 - qw0) - Lq;
       // every probability of this 32-key block below 2^-skip_thr (of a row that sums to 1) for all 32 queries of the
       // wave: its dS is dropped -- no dP product, no exp2, no dQ product (ALiBi: the far keys of the steep heads)
-      if (VG_ATTN_TILESKIP && !__any(fmaf(max16(s), c2, off) > -skip_thr)) continue;
-      f32x16 dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, dinit);
+      if constexpr (sizeof(T) == 2) {
+        if (VG_ATTN_TILESKIP && !__any(max16(s) > -skip_thr)) continue;
+        dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, Traits<T>::mfma(kext, dext, zero16()));
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(fmaf(s[i], c2, off)) * dp[i];
+        for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(s[i]) * dp[i];
+      } else {
+        if (VG_ATTN_TILESKIP && !__any(fmaf(max16(s), c2, off) > -skip_thr)) continue;
+        dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, dinit);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(fmaf(s[i], c2, off)) * dp[i];
+      }
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         if constexpr (DMA) dq[db] = mma_tr_acc_rowimg(k_row, kb * 32, db, s, lane, dq[db]);
@@ -1205,10 +1248,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     a = lse_bh[qq];
     d = dl_bh[qq];
   };
-  auto st_store = [&](int qs, float a_raw, float d_raw, float* dst) {
+  auto st_store = [&](int qs, float a_raw, float d_raw, float* dst) {      // (the bf16 / LDS-DMA path only)
     const int qq = qs + tid;
     const bool ok = qq < len;
-    dst[tid] = ok ? -(a_raw * LOG2E + slope2 * (float)(qq - k0)) / c2 : -INFINITY;
+    // round 6: K is pre-scaled by c2 (below), so the row constant is in log2 units already
+    dst[tid] = ok ? -(a_raw * LOG2E + slope2 * (float)(qq - k0)) : -INFINITY;
     dst[64 + tid] = ok ? -d_raw : 0.f;
   };
   float st_a = 0.f, st_d = 0.f;    // wave 0: raw lse / delta of the NEXT tile, fetched one iteration ahead
@@ -1232,6 +1276,30 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf.f[0]), "+v"(kf.f[1]), "+v"(kf.f[2]), "+v"(kf.f[3]), "+v"(vf.f[0]),
                  "+v"(vf.f[1]), "+v"(vf.f[2]), "+v"(vf.f[3]), "+v"(st_a), "+v"(st_d), "+v"(st_a0), "+v"(st_d0) :: "memory");
     if (tid < 64) st_store(qt_beg * TB, st_a0, st_d0, reinterpret_cast<float*>(smem + IMG));
+  }
+  // Round 6 (bf16), as in the dQ kernel: K pre-scaled by log2(e) / sqrt(d) and the per-key ALiBi term slope2 (key - k0) in a
+  // fifth k-step of the S product (query side 1, 1; key side hi, lo -- both loop-invariant), so that the score leaves the
+  // MFMA chain ready for exp2: 16 fma per 32 x 32 block fewer (84 -> 68 vector instructions next to 17 MFMAs).
+  // (the all-lanes constant (1, 1, 0 ...) operand is rebuilt from immediates at each use -- four v_mov -- instead of held:
+  // with it the kernel needs 170 registers, two more than three blocks per CU allow, and a spilled register is reloaded
+  // through a counted vmcnt wait that drains the LDS-DMA ring)
+  auto one_ext_now = [&]() {
+    unsigned a, z0, z1, z2;
+    asm volatile("v_mov_b32 %0, 0x3f803f80\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(a), "=v"(z0), "=v"(z1), "=v"(z2));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 w = {a, z0, z1, z2};
+    return __builtin_bit_cast(bf16x8, w);
+  };
+  [[maybe_unused]] bf16x8 kl_ext;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int st_ = 0; st_ < 4; ++st_)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf.f[st_][j] = (bf16_t)((float)kf.f[st_][j] * c2);
+    const bf16_t khi = (bf16_t)kl, klo = (bf16_t)(kl - (float)khi);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kl_ext[j] = (bf16_t)0.0f;
+    if (lane < 32) { kl_ext[0] = khi; kl_ext[1] = klo; }
   }
   const int nq = qt_first - qt_beg + 1;
   for (int it = 0; it < nq; ++it) {
@@ -1266,18 +1334,27 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       const int qb0 = qs0 + qb * 32;
       if (qb0 + 31 < kw0) continue;   // all queries precede this wave's keys
       if (VG_LAB_ATTN & 256) continue;
-      f32x16 s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, rows16(st, qb * 32, lane));
+      f32x16 s;
+      if constexpr (sizeof(T) == 2)
+        s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, Traits<T>::mfma(one_ext_now(), kl_ext, rows16(st, qb * 32, lane)));
+      else
+        s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, rows16(st, qb * 32, lane));
       if (qb0 < kw0 + 31) {            // diagonal block: mask query < key
         const int lim = key - qb0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = acc_row(i, lane) >= lim ? s[i] : -INFINITY;
       }
       // all 32 x 32 probabilities of this block below 2^-skip_thr: no dP product, no exp2, no dV / dK products
-      if (VG_ATTN_TILESKIP && !__any(fmaf(max16(s), c2, kl) > -skip_thr)) continue;
+      if constexpr (sizeof(T) == 2) {
+        if (VG_ATTN_TILESKIP && !__any(max16(s) > -skip_thr)) continue;
+      } else {
+        if (VG_ATTN_TILESKIP && !__any(fmaf(max16(s), c2, kl) > -skip_thr)) continue;
+      }
       f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, rows16(st + 64, qb * 32, lane));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        s[i] = fexp2<T>(fmaf(s[i], c2, kl));
+        if constexpr (sizeof(T) == 2) s[i] = fexp2<T>(s[i]);
+        else s[i] = fexp2<T>(fmaf(s[i], c2, kl));
         dp[i] *= s[i];
       }
 #pragma unroll
