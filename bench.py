@@ -401,6 +401,14 @@ def main():
             if n:
                 hbm_kernels[k] = {"launches": n, "avg_us": 1e3 * ms / n, "gb_per_s": nbytes / (ms * 1e-3) / 1e9}
         achieved = tot_work / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
+        attn_hbm = {}
+        rows_bytes = float(B * accum if args.coalesce else B) * T_SEQ * 1024 * 2        # one [rows, d_model] bf16 stream
+        for k, streams in (("attn_fwd", 4.0), ("attn_bwd", 8.0)):
+            ms, _, n = hipvg.prof_read(k)
+            if n and not args.ragged:
+                nbytes = streams * rows_bytes
+                attn_hbm[k] = {"compulsory_mb": nbytes / 1e6, "avg_us": 1e3 * ms / n, "gb_per_s": nbytes / (ms / n * 1e-3) / 1e9,
+                               "frac_of_8tb": nbytes / (ms / n * 1e-3) / 8e12}
         # attention kernels: causal-exact FLOP, the backward counted as 2 x forward (no recompute credit)
         a_ms = a_work = 0.0
         for k in ("attn_fwd", "attn_bwd"):
@@ -423,9 +431,9 @@ def main():
         # this is the figure of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (corrected as
         # MI355X_MICROARCH.md prescribes; profiles/r01/pmc_traffic_v9.json), valid for the default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r06", "pmc_traffic.json")
         if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
         if os.path.exists(pmc) and T_SEQ == SEQ_LEN and args.precision == "bf16" and args.coalesce and not args.ragged:
             with open(pmc) as f:
                 traffic = json.load(f)["bf16_gemm_family"]["traffic_bytes_per_launch"]
@@ -471,6 +479,11 @@ def main():
                          "measured_on": ("one optimizer step launched eagerly (HIP event pair around every launch) behind "
                                          "queued hipGraph replays right after the timed region: its kernels run back to "
                                          "back, as in the replays" if args.graph else "the timed region"),
+                         # round 6: the attention kernels against the bound that actually sits closest at this shape.
+                         # Head dimension 64 at T = 1000: 250 causal-exact FLOP per compulsory byte (forward: q, k, v in, o
+                         # out; backward: q, k, v, o, do in, dq, dk, dv out, each once), under the chip's ridge of 312 (2.5
+                         # PFLOP/s / 8 TB/s) -- these launches are HBM-side kernels first
+                         "attn_hbm": attn_hbm,
                          "step_model_tflops": value / world * flop_per_token / 1e12,
                          "step_model_frac": value / world * flop_per_token / PEAK_BF16,
                          "kernels": kinds},

@@ -65,6 +65,14 @@ VG_DEVICE void pair_and_rank(int bid, int ntiles, int npairs, int sched, int& hb
     const unsigned total = (unsigned)(ntiles * npairs);
     bid = (int)(((unsigned long long)(unsigned)bid * 1001ull) % total);     // 1001 = 8 * 125 + 1; odd: a permutation when total is a power of two times ...
   }
+  // sched & 8 (lab, round 6): rank-major like the default, but the ranks leave in the order packed into bits 8.. (three
+  // bits per position, up to 8 tiles per pair): e.g. 0, 7, 1, 6 ... mixes long and short sweeps in the first round
+  if ((sched & 8) && ntiles <= 8) {
+    hb = bid % npairs;
+    rank = (sched >> (8 + 3 * (bid / npairs))) & 7;
+    if (rank >= ntiles) rank = ntiles - 1;
+    return;
+  }
   sched &= 1;
   if (sched == 1 && (npairs & 7) == 0) {
     const int j = bid >> 3;
