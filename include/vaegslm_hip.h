@@ -383,7 +383,13 @@ int vg_gemm_rows(const void* x, int64_t ldx, const void* w, int64_t ldw, const f
  * fp32 residual, the reduction split over `splits` groups of blocks that meet in y through fp32 atomics: the two
  * N = d_model products of a decode layer (modules/attention/attention.py:79, modules/transformer/layers.py:82-86) at the
  * reference's inference batch, where one block per 16 columns would pull every input row through a single CU.  zero_buf
- * (zero_n floats, not y): cleared by the launch -- the accumulator of a LATER launch. */
+ * (zero_n floats, not y): cleared by the launch -- the accumulator of a LATER launch.
+ * NOT bitwise repeatable: the K slices meet in y through fp32 atomics, whose order varies from run to run, so
+ * two runs of one session differ in the last bits of the residual stream and a near-tie of the token draw can flip.
+ * vg_gemm_rows / vg_gemm_rows_mixed are repeatable; a decode session uses them for these products with VG_DECODE_ACC=0
+ * (inference/speech/session.py, "reproducible mode").  Also: with bf16 weights and M >= VG_ROWS_MFMA rows (default 1),
+ * vg_gemm_rows_mixed rounds its fp32 input rows -- times the norm scale -- to bf16 for the matrix-core kernel before the
+ * product (VG_ROWS_MFMA=17 keeps fp32 input rows on the exact dot-product kernel up to 16 rows). */
 int vg_gemm_rows_acc(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* residual,
                      int64_t ldr, float* y, int64_t ldy, int M, int N, int K, int splits, float* zero_buf, int zero_n,
                      vg_stream_t stream);

@@ -442,3 +442,38 @@ def test_packed_step_at_half_fill_against_the_oracle(full_cfg):
     lat = outp["transformer_latent"].value.float()
     assert bool((lat[~mask] == 0).all())
     assert torch.equal(lat[mask], outd["transformer_latent"].value.float()[mask])
+
+
+# ---------------------------------------------------------------- decode: the reproducible mode
+def test_decode_reproducible_mode_is_bitwise_repeatable(full_cfg, monkeypatch):
+    """bf16 DecodeSession with VG_DECODE_ACC=0 (the two N = d_model products of a layer on vg_gemm_rows instead of the
+    split-K form whose K slices meet through fp32 atomics): two sessions over the same prompt and forced frames return
+    BITWISE the same latents and logits.  The default (split) form is only required to agree within bf16 drift -- its
+    atomics add in a run-dependent order (include/vaegslm_hip.h: vg_gemm_rows_acc)."""
+    import copy
+    import hipvg
+    from oracle import lvtr_oracle as O
+    from oracle.weights import fill_like
+    from test_parity_round5_gpu import _session_decode
+    prev = hipvg.compute_dtype()
+    cfg = O.small_config(copy.deepcopy(full_cfg["model"]))
+    rng = np.random.default_rng(5)
+    B, Tp, n = 8, 16, 5
+    x = torch.cat([torch.from_numpy(rng.integers(0, 200, (B, Tp + n, 1))).float(),
+                   torch.from_numpy(rng.standard_normal((B, Tp + n, 4)).astype(np.float32))], -1)
+    init = torch.from_numpy(rng.random((B, 1, 64)).astype(np.float32)) * 2 - 1
+    sd = {k: torch.from_numpy(v) for k, v in fill_like(O.param_shapes(cfg), 20250620).items()}
+    try:
+        monkeypatch.setenv("VG_DECODE_ACC", "0")
+        a, sa = _session_decode(cfg, sd, x, init, Tp, n, "bf16")
+        b, _ = _session_decode(cfg, sd, x, init, Tp, n, "bf16")
+        assert sa._acc == 0
+        for k in a:
+            assert torch.equal(a[k], b[k]), f"{k}: the reproducible mode is not bitwise repeatable"
+        monkeypatch.setenv("VG_DECODE_ACC", "4")
+        c, sc = _session_decode(cfg, sd, x, init, Tp, n, "bf16")
+        assert sc._acc == 4
+        for k, tol in (("lat", 0.12), ("logits", 0.25)):
+            assert float((c[k] - a[k]).abs().max()) <= tol, k
+    finally:
+        hipvg.set_precision(prev)

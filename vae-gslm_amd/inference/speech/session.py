@@ -101,7 +101,10 @@ class DecodeSession:
         # VG_DECODE_ACC=<splits> (0 = off: five launches on a bf16 stream, every Linear one block per 16 columns)
         acc_min_b = int(os.environ.get("VG_DECODE_ACC_MINB", "1"))        # 17: rounds 1-5a (the split form from 17 sequences up only)
         self._acc = 0 if (self._fused or self.B < acc_min_b or self.dt != torch.bfloat16) else int(os.environ.get("VG_DECODE_ACC", "4"))
-        # seed of this session's draws (vg_decode_noise), taken from torch's CPU generator: torch.manual_seed reproduces a run
+        # seed of this session's draws (vg_decode_noise), taken from torch's CPU generator: torch.manual_seed reproduces the
+        # DRAWS of a run.  The frames are bitwise repeatable only in the reproducible mode VG_DECODE_ACC=0 (the
+        # split products add their K slices with fp32 atomics in a run-dependent order; tests/test_parity_round6_gpu.py
+        # checks both statements)
         self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         # draw epoch: a device word the captured graph READS (the seed itself is baked into the graph by value); every
         # prefill() bumps it, so a second generation on this session -- the frame counter starts over -- does not replay
