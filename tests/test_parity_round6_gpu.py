@@ -136,6 +136,30 @@ def test_dgrad_times_u8_derivative(F, tile_cfg):
             assert float((cs - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max())
 
 
+@pytest.mark.parametrize("K", [128, 192, 256, 320, 384, 1024])
+@pytest.mark.parametrize("M", [1000, 2304])
+def test_dgrad_u8_derivative_through_the_ring_every_slot_phase(F, K, M):
+    """On the long-phase 256 x 256 schedule the dgrad's 8-bit derivative tile arrives through the LDS-DMA ring as the K tile
+    past the end (csrc/vg_gemm_ph.hip: TileCtx::init_aux): its four images land in ring slots (4 nkt + h) mod 10 and the
+    strips move out of their way, so every K-tile count modulo 5 is its own layout (K = 128 .. 384: nkt = 2 .. 6; 1024: 16).
+    Exact operands: bitwise the generic epilogue's result (tile_cfg 1: global loads), ragged last row tile included."""
+    import hipvg
+    N = 512
+    g = torch.Generator().manual_seed(K + M)
+    dy = torch.randint(-3, 4, (M, K), generator=g).float().to(dev()).bfloat16()
+    wt = (torch.randint(-4, 5, (K, N), generator=g).float() / 64).to(dev()).bfloat16()
+    codes = torch.randint(0, 256, (M, N), generator=g, dtype=torch.int32).to(torch.uint8).to(dev())
+    flags = F.ACT_STORED | hipvg.ACT_DERIV_U8
+    a = F.gemm(dy, wt, M, N, K, b_tr=True, dact=flags, aux_in=codes, tile_cfg=13)
+    b = F.gemm(dy, wt, M, N, K, b_tr=True, dact=flags, aux_in=codes, tile_cfg=1)
+    assert torch.equal(a, b)
+    pa, pb = [], []
+    a2 = F.gemm(dy, wt, M, N, K, b_tr=True, dact=flags, aux_in=codes, tile_cfg=13, colpart=pa)
+    assert torch.equal(a2, a)
+    b2 = F.gemm(dy, wt, M, N, K, b_tr=True, dact=flags, aux_in=codes, tile_cfg=1, colpart=pb)
+    assert float((pa[0].double().sum(0) - pb[0].double().sum(0)).abs().max()) <= 1e-6 * float(pb[0].double().sum(0).abs().max() + 1)
+
+
 def test_u8_derivative_refused_where_it_cannot_run(F):
     import hipvg
     M, N, K = 256, 256, 256

@@ -451,6 +451,10 @@ int fill_params(const vg_gemm_desc* d, GemmParams& p, int& splits, const char* w
   p.act = d->act & ~VG_ACT_DERIV_U8; p.dact = d->dact & ~VG_ACT_DERIV_U8; p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
   p.m_base = 0;
   p.aux_u8 = ((d->act | d->dact) & VG_ACT_DERIV_U8) != 0;
+  // (needs whole 16-byte chunks of codes per row image: N % 16 == 0 and 16-byte aligned rows -- what the lean 8-bit
+  // epilogue needs anyway -- and the 32-bit piece offsets of the ring: the code array below 2 GiB)
+  static const int aux_ring = [] { const char* e = getenv("VG_AUX_RING"); return e ? atoi(e) : 1; }();
+  p.aux_ring = aux_ring && p.aux_u8 && (long)d->M * d->ldc < 0x7ffffff0L;
   if (p.aux_u8) {     // one byte per element of the stored GELU derivative (bf16 launches; include/vaegslm_hip.h)
     VG_REQUIRE(d->dtype == VG_BF16 && splits == 1 && !d->a_tr, "%s: VG_ACT_DERIV_U8 needs a bf16 forward / dgrad product without split-K", who);
     const bool save8 = (d->act & VG_ACT_DERIV_U8) != 0, load8 = (d->dact & VG_ACT_DERIV_U8) != 0;

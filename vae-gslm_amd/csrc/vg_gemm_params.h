@@ -27,6 +27,8 @@ struct GemmParams {
   int group_m;              // > 0: tiles are walked m-fastest inside bands of group_m row-tiles (L2 blocking)
   int m_base;               // rows of the whole product above this launch's first row (0 unless vg_gemm split the rows over two
                             // launches): only the row mask needs it (sequence index and frame of a row)
+  int aux_ring;             // EPI_DACT8 on the long-phase 256 x 256 schedule: the 8-bit derivative tile arrives through the LDS-DMA
+                            // ring as "K tile nkt" instead of by global loads at the end of the main loop (VG_AUX_RING=0: off)
   int aux_u8;               // the stored derivative (aux_out of GELU | SAVE_DERIV, aux_in of dact = STORED) is uint8 [M][ldc]:
                             // VG_ACT_DERIV_U8 (the flag itself is stripped from act / dact)
 };

@@ -122,6 +122,27 @@ struct TileCtx {
   const char* a_cur;
   const char* b_cur;
   unsigned va[2][2], vb[2][2];
+  // Round 6 (EPI_DACT8 on the long-phase 256 x 256 schedule): the tile's 8-bit stored derivative -- 256 rows x 256 bytes =
+  // four 128-row x 128-byte images, exactly one K tile's worth of ring slots -- travels through the LDS-DMA ring as "K tile
+  // nkt": the requests that would address the K tile past the end (zero fills of slots nobody reads) fetch it instead, two
+  // K tiles before the main loop ends, and the epilogue reads it out of LDS.  Before, the epilogue requested it from global
+  // memory at the end of the loop and waited out one round trip to (cold) HBM per tile: 4 rounds x ~4.7 us of the FFN-in
+  // dgrad's 20 us over the plain product.  Image h = (row half h >> 1, byte-column half h & 1), row-image swizzle.
+  const char* x_cur = nullptr;
+  int x_left = 0;
+  unsigned vx[2][2];
+  VG_DEVICE void init_aux(const GemmParams& p, int wave, int lane) {
+    const long ld = p.ldc;                                   // one byte per element
+    x_cur = reinterpret_cast<const char*>(p.aux_in) + n0;
+    x_left = (int)((long)(p.M - 1) * ld + p.N - n0);           // rows past M fall outside: zero fill
+    piece_offsets<false>(vx, ld, m0, wave, lane);
+  }
+  VG_DEVICE void request_aux(int h, char* dst) const {
+    const int ch = (h & 1) * 128;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x_cur + ch), 0, max(x_left - ch, 0), 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst), 16, vx[h >> 1][0], 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst + 8 * 1024), 16, vx[h >> 1][1], 0, 0, 0);
+  }
 
   // `tile` = this block's tile index before the XCD-aware remap, `z` = its K slice
   VG_DEVICE void init(const GemmParams& p, int tile, int z, int wave, int lane) {
@@ -192,6 +213,8 @@ struct TileCtx {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst + 8 * 1024), 16, o1, 0, 0, 0);
   }
 };
+
+VG_DEVICE bool ph_aux_lds_enabled(const GemmParams& p) { return p.aux_ring != 0; }
 
 using P0 = std::integral_constant<int, 0>;
 using P1 = std::integral_constant<int, 1>;
@@ -429,7 +452,7 @@ VG_DEVICE void ring_main_loop(TileCtx<A_TR, B_TR>& c, f32x4 (&acc)[8][4], char* 
 // without s_setprio around the MFMAs: no difference.
 // NTA = 16-row A tiles a wave owns in each row half: 4 (256-row tile) or 3 (192-row tile, tile_cfg 15: 24 MFMAs per
 // phase instead of 32 against the same B fragments and the same barrier / request structure).
-template <bool A_TR, bool B_TR, int NTA = 4>
+template <bool A_TR, bool B_TR, int NTA = 4, bool AUXL = false>
 VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR, 64 * NTA>& c, f32x4 (&acc)[2 * NTA][4], char* smem, int wave, int lane) {
   constexpr int NSLOT = 10;
   constexpr bool UNROLL5 = !A_TR && !B_TR;
@@ -481,6 +504,11 @@ VG_DEVICE void px2_main_loop(TileCtx<A_TR, B_TR, 64 * NTA>& c, f32x4 (&acc)[2 * 
   // requests of interval k: images 2 k + 8, 2 k + 9 = K tile t + 2, h = 0, 1 (phase A) / 2, 3 (phase B); ws0 = slot of 4 t + 8
   auto req = [&](auto halfc, int t, int ws0) {
     constexpr int H0 = decltype(halfc)::value * 2;
+    if (AUXL && t + 2 == nkt) {          // (wave-uniform) the "K tile" past the end is the epilogue's 8-bit operand tile
+      c.request_aux(H0, smem + wrap(ws0 + H0) * HALF_BYTES + wave * 1024);
+      c.request_aux(H0 + 1, smem + wrap(ws0 + H0 + 1) * HALF_BYTES + wave * 1024);
+      return;
+    }
     request(t + 2, H0, wrap(ws0 + H0));
     request(t + 2, H0 + 1, wrap(ws0 + H0 + 1));
   };
@@ -596,14 +624,38 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(GemmParams p) {
   // tile's prologue sit behind the finished tile's stores (vector-memory operations retire in order).)
   f32x4 acc[BM / 32][4];           // [a * 4 + i][b * 2 + j]; SCHED 2: [a * (BM / 64) + i][j]
   zero_acc(acc);
+  // the 8-bit derivative through the ring (see TileCtx::init_aux): the k-major-B dgrad on 256-row tiles with >= 2 K tiles
+  constexpr bool AUXL = SCHED == 2 && EPI == EPI_DACT8 && BM == 256 && !A_TR && B_TR;
+  bool aux_lds = false;
+  if constexpr (AUXL) {
+    aux_lds = c.nkt >= 2 && ph_aux_lds_enabled(p);
+    if (aux_lds) c.init_aux(p, wave, lane);
+  }
   if constexpr (SCHED == 1) ring_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
-  else if constexpr (SCHED == 2) px2_main_loop<A_TR, B_TR, BM / 64>(c, acc, smem, wave, lane);
+  else if constexpr (SCHED == 2) {
+    if constexpr (AUXL) {
+      if (aux_lds) px2_main_loop<A_TR, B_TR, BM / 64, true>(c, acc, smem, wave, lane);
+      else px2_main_loop<A_TR, B_TR, BM / 64, false>(c, acc, smem, wave, lane);
+    } else {
+      px2_main_loop<A_TR, B_TR, BM / 64>(c, acc, smem, wave, lane);
+    }
+  }
   else px_main_loop<A_TR, B_TR>(c, acc, smem, wave, lane);
 #ifdef VG_LAB_STAMPS
   long long st1 = wall_clock64();
 #endif
   constexpr bool ILVC = SCHED != 2;
   if constexpr (EPI == EPI_GENERIC) tile_epilogue<BM, 256, 2, 4, true, ILVC>(p, acc, smem, c.m0, c.n0, c.wg, c.nwg);
+  else if constexpr (AUXL) {
+    if (aux_lds) {
+      // images 4 nkt + h of the ring sit in slots (4 nkt + h) mod 10; the strips (35 KB) go where those four are not
+      const int s0 = (4 * c.nkt) % 10;
+      const int strip_slot = s0 == 0 ? 4 : (s0 == 8 ? 2 : (s0 == 2 ? 6 : 0));
+      tile_epilogue_lean<BM, 256, 2, 4, true, ILVC, EPI>(p, acc, smem + strip_slot * HALF_BYTES, c.m0, c.n0, smem, s0);
+    } else {
+      tile_epilogue_lean<BM, 256, 2, 4, true, ILVC, EPI>(p, acc, smem, c.m0, c.n0);
+    }
+  }
   else tile_epilogue_lean<BM, 256, 2, 4, true, ILVC, EPI>(p, acc, smem, c.m0, c.n0);
 #ifdef VG_LAB_STAMPS
   if (g_lab_stamps && tid == 0 && blockIdx.x < 4096) {

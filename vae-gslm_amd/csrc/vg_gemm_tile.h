@@ -381,7 +381,8 @@ enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_SAVE = 2, EPI_DACT = 3, EPI_SILU
 
 
 template <int BM, int BN, int WM, int WN, bool ILV, bool ILVC, int EPI>
-VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0) {
+VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0,
+                                   const char* ring = nullptr, int aux_s0 = -1) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int WCOLS = TN * 16;
@@ -426,12 +427,16 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
   // (lean_epilogue_of); the layout in memory stays plain uint8 [M][ldc], so the generic epilogue reads / writes the same bytes.
   const bool odd = (lane & 1) != 0;
   u32x4_t g8[EPI == EPI_DACT8 ? TM : 1];
+  // (ring != nullptr: the tile's codes already sit in four ring slots of LDS -- gemm_ph_kernel fetched them through the
+  // LDS-DMA ring as the K tile past the end, vg_gemm_ph.hip TileCtx::init_aux -- and each band reads its 8 + 8 bytes there)
   if constexpr (EPI == EPI_DACT8) {
-    const unsigned char* __restrict__ src8 = reinterpret_cast<const unsigned char*>(p.aux_in);
+    if (ring == nullptr) {
+      const unsigned char* __restrict__ src8 = reinterpret_cast<const unsigned char*>(p.aux_in);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + band_row(i) + (odd ? RPP : 0) + crow;
-      if (col_ok && m < p.M) g8[i] = VG_EPI_LOAD(reinterpret_cast<const u32x4_t*>(src8 + (long)m * p.ldc + (odd ? n - 8 : n)));
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + band_row(i) + (odd ? RPP : 0) + crow;
+        if (col_ok && m < p.M) g8[i] = VG_EPI_LOAD(reinterpret_cast<const u32x4_t*>(src8 + (long)m * p.ldc + (odd ? n - 8 : n)));
+      }
     }
   }
   if constexpr (EPI == EPI_PLAIN || EPI == EPI_DACT || EPI == EPI_SILU_SAVE) {
@@ -488,11 +493,25 @@ VG_DEVICE void tile_epilogue_lean(const GemmParams& p, f32x4 (&acc)[BM / WM / 16
       for (int rr = 0; rr < 4; ++rr)
         strip[(4 * (lane >> 4) + rr) * SW + j * 16 + (lane & 15)] = acc[i][j][rr];
     u32x2_t c8[2] = {{0u, 0u}, {0u, 0u}};      // this lane's 8 codes of pass 0 / pass 1 (read: from the pair's two loads; written: below)
-    if constexpr (EPI == EPI_DACT8) {          // (every lane takes part: the swap reads the partner's registers)
-      const u32x4_t own = g8[i];
-      const unsigned rx = dpp_quad_swap1(odd ? own[0] : own[2]), ry = dpp_quad_swap1(odd ? own[1] : own[3]);
-      c8[0] = odd ? u32x2_t{rx, ry} : u32x2_t{own[0], own[1]};
-      c8[1] = odd ? u32x2_t{own[2], own[3]} : u32x2_t{rx, ry};
+    if constexpr (EPI == EPI_DACT8) {
+      if (ring != nullptr) {
+        // code bytes of (tile row r, tile byte-column cb): image (r >> 7) * 2 + (cb >> 7) in ring slot (aux_s0 + image) mod 10,
+        // row image with the 16-byte chunk XOR of the row (RowTile / dma_tile: position = chunk ^ ((row >> 1) & 7))
+        const int cb = strip_col(cch * 8);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int r = band_row(i) + ps * RPP + crow, rr = r & 127;
+          int slot = aux_s0 + (r >> 7) * 2 + (cb >> 7);
+          slot = slot >= 10 ? slot - 10 : slot;
+          const char* at = ring + slot * 16384 + rr * 128 + (((((cb & 127) >> 4) ^ ((rr >> 1) & 7))) << 4) + (cb & 15);
+          c8[ps] = *reinterpret_cast<const u32x2_t*>(at);
+        }
+      } else {                                   // (every lane takes part: the swap reads the partner's registers)
+        const u32x4_t own = g8[i];
+        const unsigned rx = dpp_quad_swap1(odd ? own[0] : own[2]), ry = dpp_quad_swap1(odd ? own[1] : own[3]);
+        c8[0] = odd ? u32x2_t{rx, ry} : u32x2_t{own[0], own[1]};
+        c8[1] = odd ? u32x2_t{own[2], own[3]} : u32x2_t{rx, ry};
+      }
     }
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
