@@ -115,7 +115,7 @@ def main():
         if c["mfma"] < min_mfma:
             continue
         valu = sum(v for k, v in c.items() if k in VALU)
-        print(f"\n== block {label}: {c['mfma']} MFMA, {valu} VALU ({valu / c['mfma']:.1f} per MFMA), "
+        print(f"\n== block {label}: {c['mfma']} MFMA, {valu} VALU ({valu / max(c['mfma'], 1):.1f} per MFMA), "
               f"{sum(c.values())} instructions")
         for k, _ in CLASSES:
             if c[k]:

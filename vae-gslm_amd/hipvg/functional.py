@@ -1698,19 +1698,17 @@ def _cond_merge_ok(x: Tensor, cond, taps: int) -> bool:
             and cond.stride(1) == 1 and cond.stride(0) % 8 == 0 and cond.data_ptr() % 16 == 0)
 
 
-def _padded_weight(s2: Tensor, Kx: int) -> Tensor:
+def _padded_weight(owner: Tensor, s2: Tensor, Kx: int) -> Tensor:
     """The bf16 [Hd, C + cond] weight of the 1x1 convolution over [activations ; condition] as [Hd, Kx] with zero columns
-    up to Kx = C + 64 (whole 64-deep K tiles for the phase-pipelined GEMM kernels).  A buffer per weight, its zero tail
-    written once; the live columns are re-copied on every call (one 2.4 MB launch: the optimizer rewrites the source, and
-    inside a hipGraph the copy is a node like any other)."""
+    up to Kx = C + 64 (whole 64-deep K tiles for the phase-pipelined GEMM kernels).  One buffer per weight, kept on the
+    PARAMETER (`owner`: the bf16 view handed in is a fresh tensor object on every call), its zero tail written once; the
+    live columns are re-copied on every call (one 2.4 MB launch: the optimizer rewrites the source, and inside a hipGraph
+    the copy is a node like any other)."""
     Hd, Kw = s2.shape
-    buf = getattr(s2, "_vg_kpad", None)
-    if buf is None or buf.shape != (Hd, Kx) or buf.device != s2.device:
+    buf = getattr(owner, "_vg_kpad", None)
+    if buf is None or buf.shape != (Hd, Kx) or buf.device != s2.device or buf.dtype != s2.dtype:
         buf = torch.zeros((Hd, Kx), dtype=s2.dtype, device=s2.device)
-        try:
-            s2._vg_kpad = buf
-        except AttributeError:
-            pass
+        owner._vg_kpad = buf
     buf[:, :Kw].copy_(s2)
     return buf
 
@@ -1789,7 +1787,7 @@ class ConvBlockFn(torch.autograd.Function):
             u, mean, rstd = dwnorm_fwd_cat_raw(x, w1, cb, te32, gamma, beta, T, taps, shift, eps, cond, Kx)
             # (kept on ctx, not among the saved tensors: the buffer is rewritten -- with the same values -- by the next
             # forward of this block, which autograd's version check would take for a hazard)
-            ctx.wpad = _padded_weight(s2, Kx)
+            ctx.wpad = _padded_weight(c2w, s2, Kx)
             h = gemm(u, ctx.wpad, M, Hd, Kx, bias=c2b.detach().float(),
                      act=(act | ACT_SAVE_DERIV) if pre is not None else act, aux_out=pre)
         else:
