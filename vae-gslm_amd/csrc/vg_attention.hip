@@ -42,6 +42,10 @@ constexpr float SCALE = 0.125f;   // 1 / sqrt(64)
 #ifndef VG_ATTN_HEADMIX
 #define VG_ATTN_HEADMIX 1   // heads x and 15 - x share an XCD (0: x and x + 8, lab)
 #endif
+#ifndef VG_ATTN_BSW
+#define VG_ATTN_BSW 1       // swizzle of the bf16 backward kernels' row images (see row_swz): 1 = the dual-use one (round 6), 0 = RowTile's (lab)
+#endif
+constexpr int BSW = VG_ATTN_BSW;
 #ifndef VG_ATTN_OCC_FWD
 #define VG_ATTN_OCC_FWD 3
 #endif
@@ -153,7 +157,38 @@ VG_DEVICE void dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff
 }
 VG_DEVICE unsigned lds_addr_of(const char* p) { return (unsigned)(uintptr_t)LDS_PTR(const char, p); }
 
-template <bool TR>
+// SW (round 6): which 16-byte-chunk swizzle a ROW image carries.  0: chunk ^ ((row >> 1) & 7) (RowTile: conflict-free
+// ds_read_b128 row reads; the transposed reads of the backward kernels -- four rows x 64 bytes per half-wave -- put rows q
+// and q + 2 on the same banks: 2-way, 25 % of the LDS-active cycles by the counters, rounds 3 - 5).  1: the same XOR with
+// bit 2 flipped for odd row pairs, x(row) = ((row >> 1) & 7) ^ (((row >> 1) & 1) << 2): still a bijection of (row >> 1) & 7,
+// so the row reads stay conflict-free, and rows q + 2, q + 3 of a transposed read move to the other 64-byte half of
+// their 128-byte row -- the half-wave's four rows x 64 bytes tile one 256-byte bank row exactly.  Used by the images of
+// the bf16 backward kernels (both kinds of read on one image).
+VG_DEVICE int row_swz(int row, int sw) {
+  const int v = (row >> 1) & 7;
+  return sw ? (v ^ ((v & 1) << 2)) : v;
+}
+template <int SW>
+VG_DEVICE bf16x8 row_frag_sw(const char* base, int row, int s, int lane) {       // RowTile<bf16, 64>::frag with swizzle SW
+  return *reinterpret_cast<const bf16x8*>(base + row * 128 + (((2 * s + (lane >> 5)) ^ row_swz(row, SW)) << 4));
+}
+template <int SW>
+VG_DEVICE bf16x8 tr_frag_sw(const char* base, int k0, int col0, int s, int lane) {   // RowTile<bf16, 64>::tr_frag<true>
+  // k0 % 16 == 0 and col0 % 32 == 0 (both are multiples of 32 at every call site): the swizzle term of row k0 + 16 s + r
+  // is that of r, the second row (+8) has bit 2 of it flipped, and col0 only flips bit 2 of the chunk -- one lane-constant
+  // offset, XORs and adds of immediates per read.
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+  const int r = 4 * h + q;
+  const int lane_off = r * 128 + (((2 * (g & 1) + (p >> 1)) ^ row_swz(r, SW)) << 4) + ((p & 1) << 3);
+  const int sel = (col0 >> 5) & 1;
+  const int oa = (sel ? (lane_off ^ 64) : lane_off) + (k0 + 16 * s) * 128;
+  const int ob = (sel ? lane_off : (lane_off ^ 64)) + (k0 + 16 * s) * 128 + 1024;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + oa));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + ob));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <bool TR, int SW = 0>
 VG_DEVICE void slab_dma(__amdgpu_buffer_rsrc_t rsrc, char* img, long row_stride, int t0, int wave, int lane) {
   const unsigned img_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(img));
   const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -163,7 +198,7 @@ VG_DEVICE void slab_dma(__amdgpu_buffer_rsrc_t rsrc, char* img, long row_stride,
     const int row = piece * 8 + (lane >> 3);
     const int pos = lane & 7;               // 16-byte position inside the 128-byte LDS row
     int col;
-    if constexpr (!TR) col = (pos ^ ((row >> 1) & 7)) * 8;
+    if constexpr (!TR) col = (pos ^ row_swz(row, SW)) * 8;
     else col = (((pos >> 2) ^ ((row >> 1) & 1)) * 32) + (pos & 3) * 8;
     const unsigned voff = (unsigned)(((long)(t0 + row) * row_stride + col) * 2);
     dma16(rsrc, img_lds + piece * 1024, voff);
@@ -191,21 +226,24 @@ template <> struct RowRegs<float> {
   }
 };
 
-template <typename T>
+template <typename T, int SW = 0>
 VG_DEVICE f32x16 mma_row_regs(const char* row_img, int row, const RowRegs<T>& b, int lane, f32x16 acc) {
   constexpr int STEPS = DH / Traits<T>::KSTEP;
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) acc = Traits<T>::mfma(RowTile<T, DH>::frag(row_img, row, s, lane), b.f[s], acc);
+  for (int s = 0; s < STEPS; ++s) {
+    if constexpr (sizeof(T) == 2 && SW != 0) acc = Traits<T>::mfma(row_frag_sw<SW>(row_img, row, s, lane), b.f[s], acc);
+    else acc = Traits<T>::mfma(RowTile<T, DH>::frag(row_img, row, s, lane), b.f[s], acc);
+  }
   return acc;
 }
 
 // the same product with the transposed fragments read out of a ROW image (bf16 backward kernels: K, Q and dO are
 // staged once instead of twice -- a third less LDS-DMA traffic for dQ, half for dK / dV)
+template <int SW = 0>
 VG_DEVICE f32x16 mma_tr_acc_rowimg(const char* row_img, int k0, int db, const f32x16& x, int lane, f32x16 acc) {
 #pragma unroll
   for (int s = 0; s < AccOperand<bf16_t>::STEPS; ++s)
-    acc = Traits<bf16_t>::mfma(RowTile<bf16_t, DH>::template tr_frag<true>(row_img, k0, db * 32, s, lane),
-                               AccOperand<bf16_t>::get(x, s), acc);
+    acc = Traits<bf16_t>::mfma(tr_frag_sw<SW>(row_img, k0, db * 32, s, lane), AccOperand<bf16_t>::get(x, s), acc);
   return acc;
 }
 
@@ -1011,8 +1049,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   uint4 rk[DMA ? 1 : NVec<T>::v], rv[DMA ? 1 : NVec<T>::v];
   __amdgpu_buffer_rsrc_t rsk, rsv;
   auto issue = [&](int t0, char* st) {
-    slab_dma<false>(rsk, st, rs, t0, wave, lane);
-    slab_dma<false>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);      // (K^T fragments come out of the K row image)
+    slab_dma<false, BSW>(rsk, st, rs, t0, wave, lane);
+    slab_dma<false, BSW>(rsv, st + LdsPlan<T>::ROW_BYTES, rs, t0, wave, lane);      // (K^T fragments come out of the K row image)
   };
   // Round 5: key tiles are swept from the block's diagonal DOWN, and the first tile is requested before anything else is
   // loaded: the row fragments, the statistics of the window and the first K / V tile share ONE memory round trip per
@@ -1128,7 +1166,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
 #pragma unroll
         for (int j = 0; j < 8; ++j) qext[j] = (bf16_t)0.0f;
         if (lane < 32) { qext[0] = hi; qext[1] = lo; qext[2] = (bf16_t)1.0f; qext[3] = (bf16_t)1.0f; }
-        s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, Traits<T>::mfma(kext, qext, zero16()));
+        s = mma_row_regs<T, BSW>(k_row, kb * 32 + (lane & 31), qf, lane, Traits<T>::mfma(kext, qext, zero16()));
       } else {
         s = mma_row_regs<T>(k_row, kb * 32 + (lane & 31), qf, lane, kinit);
       }
@@ -1142,7 +1180,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       // wave: its dS is dropped -- no dP product, no exp2, no dQ product (ALiBi: the far keys of the steep heads)
       if constexpr (sizeof(T) == 2) {
         if (VG_ATTN_TILESKIP && !__any(max16(s) > -skip_thr)) continue;
-        dp = mma_row_regs<T>(v_row, kb * 32 + (lane & 31), dof, lane, Traits<T>::mfma(kext, dext, zero16()));
+        dp = mma_row_regs<T, BSW>(v_row, kb * 32 + (lane & 31), dof, lane, Traits<T>::mfma(kext, dext, zero16()));
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = fexp2<T>(s[i]) * dp[i];
       } else {
@@ -1153,7 +1191,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       }
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        if constexpr (DMA) dq[db] = mma_tr_acc_rowimg(k_row, kb * 32, db, s, lane, dq[db]);
+        if constexpr (DMA) dq[db] = mma_tr_acc_rowimg<BSW>(k_row, kb * 32, db, s, lane, dq[db]);
         else dq[db] = mma_tr_acc<T>(k_tr, kb * 32, db, s, lane, dq[db]);
       }
     }
@@ -1222,8 +1260,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   uint4 rq[DMA ? 1 : NVec<T>::v], rd[DMA ? 1 : NVec<T>::v];
   __amdgpu_buffer_rsrc_t rsq, rsd;
   auto issue = [&](int t0, char* sg) {
-    slab_dma<false>(rsq, sg, rs, t0, wave, lane);
-    slab_dma<false>(rsd, sg + LdsPlan<T>::ROW_BYTES, D, t0, wave, lane);       // (Q^T / dO^T fragments come out of the row images)
+    slab_dma<false, BSW>(rsq, sg, rs, t0, wave, lane);
+    slab_dma<false, BSW>(rsd, sg + LdsPlan<T>::ROW_BYTES, D, t0, wave, lane);       // (Q^T / dO^T fragments come out of the row images)
   };
   if constexpr (DMA) {
     rsq = slab_rsrc(reinterpret_cast<const bf16_t*>(base), rs, Tr);
@@ -1344,7 +1382,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       if (VG_LAB_ATTN & 256) continue;
       f32x16 s;
       if constexpr (sizeof(T) == 2)
-        s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, Traits<T>::mfma(one_ext_now(), kl_ext, rows16(st, qb * 32, lane)));
+        s = mma_row_regs<T, BSW>(q_row, qb * 32 + (lane & 31), kf, lane, Traits<T>::mfma(one_ext_now(), kl_ext, rows16(st, qb * 32, lane)));
       else
         s = mma_row_regs<T>(q_row, qb * 32 + (lane & 31), kf, lane, rows16(st, qb * 32, lane));
       if (qb0 < kw0 + 31) {            // diagonal block: mask query < key
@@ -1358,7 +1396,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
       } else {
         if (VG_ATTN_TILESKIP && !__any(fmaf(max16(s), c2, kl) > -skip_thr)) continue;
       }
-      f32x16 dp = mma_row_regs<T>(do_row, qb * 32 + (lane & 31), vf, lane, rows16(st + 64, qb * 32, lane));
+      f32x16 dp = mma_row_regs<T, (sizeof(T) == 2 ? BSW : 0)>(do_row, qb * 32 + (lane & 31), vf, lane, rows16(st + 64, qb * 32, lane));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if constexpr (sizeof(T) == 2) s[i] = fexp2<T>(s[i]);
@@ -1368,8 +1406,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         if constexpr (DMA) {
-          dv[db] = mma_tr_acc_rowimg(do_row, qb * 32, db, s, lane, dv[db]);
-          dk[db] = mma_tr_acc_rowimg(q_row, qb * 32, db, dp, lane, dk[db]);
+          dv[db] = mma_tr_acc_rowimg<BSW>(do_row, qb * 32, db, s, lane, dv[db]);
+          dk[db] = mma_tr_acc_rowimg<BSW>(q_row, qb * 32, db, dp, lane, dk[db]);
         } else {
           dv[db] = mma_tr_acc<T>(do_tr, qb * 32, db, s, lane, dv[db]);
           dk[db] = mma_tr_acc<T>(q_tr, qb * 32, db, dp, lane, dk[db]);
