@@ -501,3 +501,26 @@ def test_decode_reproducible_mode_is_bitwise_repeatable(full_cfg, monkeypatch):
             assert float((c[k] - a[k]).abs().max()) <= tol, k
     finally:
         hipvg.set_precision(prev)
+
+
+# ---------------------------------------------------------------- the few-row fp32 Linears of the diffusion-step embedding
+@pytest.mark.parametrize("R,K,N", [(16, 256, 3072), (16, 256, 256), (2, 256, 1536), (32, 256, 3072), (5, 64, 200)])
+def test_small_linear_matches_the_stock_linear(F, R, K, N):
+    """SmallLinearFn (reference modules/diffusion/unet.py:20-29 and the time projections of modules/conv/layers.py:93-96
+    as one batched Linear): value and all three gradients against torch.nn.functional.linear in float64.  The HIP
+    products accumulate in fp32 (split-K atomics for the input gradient): 2e-6 of the largest gradient entry."""
+    g = torch.Generator().manual_seed(R * 1000 + N)
+    a = torch.randn(R, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(R, N, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (a, W, b)]
+    yr = torch.nn.functional.linear(*ref)
+    yr.backward(dy.double())
+    got = [t.to(dev()).requires_grad_(True) for t in (a, W, b)]
+    y = F.small_linear(*got)
+    y.backward(dy.to(dev()))
+    assert float((y.double().cpu() - yr).abs().max()) <= 1e-5 * float(yr.abs().max())
+    for name, t, r in zip(("da", "dW", "db"), got, ref):
+        err = float((t.grad.double().cpu() - r.grad).abs().max())
+        assert err <= 2e-6 * float(r.grad.abs().max()) + 1e-6, f"{name}: {err}"

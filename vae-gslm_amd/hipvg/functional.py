@@ -729,6 +729,44 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act=None
                           out_f32)
 
 
+class SmallLinearFn(torch.autograd.Function):
+    """y = a W^T + b in fp32 for a FEW rows (the diffusion-step embedding, one row per sequence: the time-embedding MLP
+    and the blocks' batched projection of it, reference modules/diffusion/unet.py:20-29 and modules/conv/layers.py:93-96).
+    The forward is the stock addmm (6 - 14 µs).  The stock BACKWARD is not usable: `mm([16, 3072], [3072, 256])`, the
+    input gradient of the batched projection, lands on a vendor kernel (MT32x16x256, 16 workgroups walking K = 3072
+    with 16-wide fp32 MFMAs) that takes 0.46 ms inside the replayed graph and 1.07 ms in an eager step for 25 MFLOP
+    (tools/lab/mm_shapes.py) -- the longest single launch of the step after the grouped weight gradient.  Here the
+    input gradient is the split-K fp32 HIP product and the weight gradient the thin kernel (K = rows <= 16) or the
+    same split-K product."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias):
+        a = a.float().contiguous()
+        w = weight.detach().float()
+        y = torch.addmm(bias.detach().float(), a, w.t()) if bias is not None else a @ w.t()
+        ctx.save_for_backward(a, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        R, N, K = a.shape[0], w.shape[0], w.shape[1]
+        da = dW = db = None
+        if ctx.needs_input_grad[0]:
+            da = gemm(dy, w, R, K, N, b_tr=True, out_f32=True, split_k=max(1, min(16, N // 256)))
+        if ctx.needs_input_grad[1]:
+            dW = gemm(dy, a, N, K, R, a_tr=True, b_tr=True, out_f32=True)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return da, dW, db
+
+
+def small_linear(a: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    return SmallLinearFn.apply(a, weight, bias)
+
+
 class SliceLinearFn(torch.autograd.Function):
     """y = x W[:, col0:col0 + K]^T (+ b) (+ residual) for a column slice of a PARAMETER (a k = 1 Conv1d whose input is
     a concatenation computed piece by piece: the UNet's skip convolutions, modules/conv/layers.py of the reference).

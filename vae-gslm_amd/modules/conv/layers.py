@@ -182,7 +182,8 @@ class BottleNeckResNet(nn.Module):
             W = torch.cat([self.layers[i].time_emb.weight for i in timed], 0)
             bvec = torch.cat([self.layers[i].time_emb.bias for i in timed], 0)
             sizes = [self.layers[i].time_emb.out_features for i in timed]
-            for i, piece in zip(timed, F.linear(a, W, bvec).split(sizes, dim=1)):
+            proj = HF.small_linear(a, W, bvec) if (a.is_cuda and os.environ.get("VG_SMALL_LINEAR", "1") != "0") else F.linear(a, W, bvec)
+            for i, piece in zip(timed, proj.split(sizes, dim=1)):
                 tes[i] = piece
         return tes
 

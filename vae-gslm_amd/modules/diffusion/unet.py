@@ -3,6 +3,8 @@ modules/diffusion/unet.py:10-27,67-93): sinusoidal time embedding -> 2-layer
 MLP, a Linear that squeezes the frame condition, and the conditional
 bottleneck ResNet.  Runs on stock PyTorch-ROCm ops (not part of the HIP list).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -25,7 +27,12 @@ class TimeEmbedding(nn.Module):
         self.embedding = SinCos(hp.dim, maxpos=hp.maxpos)
 
     def forward(self, t: torch.Tensor) -> torch.Tensor:
-        return self.lin2(self.act(self.lin1(self.embedding.get(t))))
+        e = self.embedding.get(t)
+        if e.is_cuda and e.dim() == 2 and os.environ.get("VG_SMALL_LINEAR", "1") != "0":
+            # fp32 rows, one per sequence: the stock backward of these Linears is vendor-library launches of 15 - 40 µs each
+            from hipvg import functional as HF
+            return HF.small_linear(self.act(HF.small_linear(e, self.lin1.weight, self.lin1.bias)), self.lin2.weight, self.lin2.bias)
+        return self.lin2(self.act(self.lin1(e)))
 
 
 class ConditionalBottleNeckUNet(nn.Module):
