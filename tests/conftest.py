@@ -39,3 +39,23 @@ def golden():
     def _load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return _load
+
+
+@pytest.fixture(autouse=True)
+def _resource_trace(request):
+    """VG_DEBUG_RESOURCES=1: native threads, open files and device memory after every test (stderr; run with -s)."""
+    yield
+    if os.environ.get("VG_DEBUG_RESOURCES", "0") != "1":
+        return
+    try:
+        with open("/proc/self/status") as f:
+            st = {l.split(":")[0]: l.split(":")[1].strip() for l in f if ":" in l}
+        nfd = len(os.listdir("/proc/self/fd"))
+        import gc
+        import torch
+        graphs = sum(1 for o in gc.get_objects() if type(o).__name__ == "CUDAGraph")
+        mem = torch.cuda.memory_reserved() >> 20 if torch.cuda.is_available() else 0
+        print(f"[vg_res] {request.node.nodeid[-70:]:70s} threads={st.get('Threads')} fds={nfd} rss={st.get('VmRSS')} graphs={graphs} reserved={mem}MiB",
+              file=sys.stderr, flush=True)
+    except Exception as exc:      # noqa: BLE001
+        print(f"[vg_res] {exc!r}", file=sys.stderr)

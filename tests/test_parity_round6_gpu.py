@@ -524,3 +524,133 @@ def test_small_linear_matches_the_stock_linear(F, R, K, N):
     for name, t, r in zip(("da", "dW", "db"), got, ref):
         err = float((t.grad.double().cpu() - r.grad).abs().max())
         assert err <= 2e-6 * float(r.grad.abs().max()) + 1e-6, f"{name}: {err}"
+
+
+# ---------------------------------------------------------------- conv block: (depthwise conv -> norm) backward in one launch
+@pytest.mark.parametrize("B,T,shift,wide,with_add,with_te", [
+    (16, 1000, 3, False, True, True), (3, 26, 6, False, True, False), (2, 27, 0, True, False, True),
+    (5, 5, 3, False, True, True), (4, 333, 6, True, True, True), (1, 52, 0, False, False, False)])
+def test_dwnorm_backward_in_one_launch_equals_the_two_launches(F, monkeypatch, B, T, shift, wide, with_add, with_te):
+    """vg_dwnorm_bwd_fused (du stays in LDS) against vg_dwnorm_bwd / vg_dwnorm_bwd_ld (du through HBM), reference
+    modules/conv/layers.py:93-110 + modules/norm.py:43-47 under autograd: du and dx BITWISE (same arithmetic in the same
+    order per frame), the parameter partial sums -- other frames per block -- to fp32 rounding.  Tile edges: T = 26 / 27 / 52
+    (one tile, one tile + 1 frame, two whole tiles), T = 5 < the 6-frame halo."""
+    torch.manual_seed(B * 100 + T)
+    d = dev()
+    C, M = 512, B * T
+    x = torch.randn(M, C, device=d).bfloat16()
+    w = torch.randn(C, 7, device=d) * 0.3
+    cb, gamma, beta = torch.randn(C, device=d) * 0.1, 1 + 0.1 * torch.randn(C, device=d), 0.1 * torch.randn(C, device=d)
+    te = torch.randn(B, C, device=d) * 0.2 if with_te else None
+    _, mean, rstd = F.dwnorm_fwd_raw(x, w, cb, te, gamma, beta, T, 7, shift, 1e-6)
+    dyw = torch.randn(M, C + 64 if wide else C, device=d).bfloat16()
+    dy = dyw[:, :C]
+    dxa = torch.randn(M, C, device=d).bfloat16() if with_add else None
+    call = F.dwnorm_bwd_ld_raw if wide else F.dwnorm_bwd_raw
+    monkeypatch.setattr(F, "_DW_FUSED", False)
+    du0, dx0, pg0, pb0, pw0 = call(dy, x, w, cb, te, gamma, mean, rstd, dxa, T, 7, shift)
+    monkeypatch.setattr(F, "_DW_FUSED", True)
+    du1, dx1, pg1, pb1, pw1 = call(dy, x, w, cb, te, gamma, mean, rstd, dxa, T, 7, shift)
+    assert pg1.shape[0] == B * -(-T // 26)
+    assert torch.equal(du0, du1), "du"
+    assert torch.equal(dx0, dx1), "dx"
+    for name, a, b in (("gamma", pg0, pg1), ("beta", pb0, pb1), ("taps", pw0, pw1)):
+        want, got = a.double().sum(0), b.double().sum(0)
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6, name
+    # without the du store (nobody reads it): dx and the sums unchanged
+    _, dx2, pg2, _, pw2 = F._dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dxa, T, 7, shift, want_du=False)
+    assert torch.equal(dx2, dx1) and torch.equal(pg2, pg1) and torch.equal(pw2, pw1)
+
+
+def test_dwnorm_backward_in_one_launch_on_packed_rows(F, monkeypatch):
+    """The same on ragged sequences laid end to end (vg_dwnorm_bwd_seg's layout: one empty sequence, one shorter than a tile,
+    pseudo sequences over the bucket's spare rows)."""
+    torch.manual_seed(7)
+    d = dev()
+    Bq, T, C, shift = 5, 333, 512, 6
+    lens = torch.tensor([333, 7, 0, 200, 129], dtype=torch.int32, device=d)
+    rows = F.pack_rows_bucket(int(torch.clamp(lens + 18, max=T).sum()), 256)
+    plan = F.PackPlan(Bq, T, rows, d, 256, halo=18).fill(lens)
+    xp = torch.randn(rows, C, device=d).bfloat16()
+    w = torch.randn(C, 7, device=d) * 0.3
+    cb, gamma, beta = torch.randn(C, device=d) * 0.1, 1 + 0.1 * torch.randn(C, device=d), 0.1 * torch.randn(C, device=d)
+    te = torch.randn(Bq, C, device=d) * 0.2
+    _, mean, rstd = F.dwnorm_fwd_raw(xp, w, cb, te, gamma, beta, plan, 7, shift, 1e-6)
+    dy, dxa = torch.randn(rows, C, device=d).bfloat16(), torch.randn(rows, C, device=d).bfloat16()
+    monkeypatch.setattr(F, "_DW_FUSED", False)
+    du0, dx0, pg0, pb0, pw0 = F.dwnorm_bwd_raw(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift)
+    monkeypatch.setattr(F, "_DW_FUSED", True)
+    du1, dx1, pg1, pb1, pw1 = F.dwnorm_bwd_raw(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift)
+    assert pg1.shape[0] == plan.nseq * -(-T // 26)
+    assert torch.equal(du0, du1) and torch.equal(dx0, dx1)
+    for name, a, b in (("gamma", pg0, pg1), ("beta", pb0, pb1), ("taps", pw0, pw1)):
+        want, got = a.double().sum(0), b.double().sum(0)
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6, name
+
+
+# ---------------------------------------------------------------- hipGraph launches: the launch-stream rule
+_UNEVEN_STREAMS = r"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.join({root!r}, "vae-gslm_amd"))
+import torch
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+x = torch.zeros(1 << 16, device=dev)
+keep = [torch.cuda.Stream() for _ in range(3)]
+hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+raw = []
+for i in range(32):
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+    raw.append(s)
+for s in raw:                               # a stream takes its hardware queue at first use
+    with torch.cuda.stream(torch.cuda.ExternalStream(s.value)):
+        x.add_(1)
+torch.cuda.synchronize()
+for i, s in enumerate(raw):                 # one hardware queue is now 8 streams lighter than the other three
+    if i % 4 == 0:
+        assert hip.hipStreamDestroy(s) == 0
+thread_stream = ctypes.c_void_p()           # the caller's stream: normal priority, lands on the light queue
+assert hip.hipStreamCreateWithFlags(ctypes.byref(thread_stream), 1) == 0
+torch.cuda.set_stream(torch.cuda.ExternalStream(thread_stream.value))
+"""
+
+_GRAPH_STEP = r"""
+import copy, yaml
+import hipvg
+from hparams.hp import Hparams
+from oracle.lvtr_oracle import small_config
+from trainers.speech.lvtr import LVTRTrainer
+from training_lib.synthetic import make_batch
+sys.path.insert(0, {root!r})
+cfg = yaml.safe_load(open(os.path.join({root!r}, "vae-gslm_amd/configs/train/speech/vae-gslm.yaml")))
+cfg["model"] = small_config(cfg["model"])
+cfg["hip"].update(precision="bf16", graph=True, coalesce_accumulation=False)
+cfg["training"]["gradient_accumulation"] = 1
+torch.manual_seed(3)
+tr = LVTRTrainer(Hparams.from_dict(cfg)).to(dev)
+tr.configure_optimizers()
+tr.attach_reducer()
+tr.global_step = 10 ** 9
+batch = make_batch(4, 256, dev, seed=9)
+for i in range(3):
+    out = tr._graphed_micro_step(batch, i, True)
+torch.cuda.synchronize()
+assert tr.use_graph, "the capture fell back to eager launches"
+assert torch.cuda.current_stream().priority < 0
+print("graph step ok", float(out["loss"]))
+"""
+
+
+def test_graph_launch_survives_an_uneven_stream_population():
+    """ROCm 7.0's first hipGraphLaunch of an exec with parallel branches walks off the exec's internal stream list when two
+    of those streams share the launch stream's hardware queue (hip::Graph::UpdateStreams; met as a SIGSEGV at the 306th test
+    of this suite, reproduced by tools/lab/hipgraph_queue_collision.py).  The trainer therefore launches its graphs from a
+    HIGH-priority stream (other queue pool: no internal stream can match).  Here: a process whose stream population is made
+    uneven on purpose -- the next streams created all land on one light hardware queue, the calling thread's stream among
+    them -- then captures and replays a training micro-step."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _UNEVEN_STREAMS.format(root=root) + "sys.path.insert(0, %r)\n" % root + _GRAPH_STEP.format(root=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "graph step ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])

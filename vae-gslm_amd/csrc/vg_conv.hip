@@ -475,6 +475,35 @@ __global__ __launch_bounds__(256) void dwnorm_fwd_run_kernel(const bf16_t* __res
   }
 }
 
+// The arithmetic of one frame's du = d loss / d v, shared by the run kernel and the one-launch kernel below so that both
+// round identically: floating-point contraction is pinned off here (only the written fmaf is fused) -- left to the
+// compiler, `a1 += dy * gamma` and `r * (dy * gamma - s1) - s2 * d` contract differently in the two kernels and one
+// element in ~10^5 lands on the other side of a bf16 rounding boundary.
+//   du_sums : d = v - mean (returned in v), a1 = sum g, a2 = sum g d with g = dy gamma   (this lane's 8 channels)
+//   du_value: du = r (g - s1) - s2 d with s1 = mean_c g, s2 = r^3 / (C - 1) sum_c g d
+VG_DEVICE void du_sums(const float (&dyv)[8], const float (&gm)[8], float mean, float (&v)[8], float& a1, float& a2) {
+#pragma clang fp contract(off)
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float d = v[e] - mean;
+    const float g = dyv[e] * gm[e];
+    v[e] = d;
+    s = s + g;
+    q = fmaf(g, d, q);
+  }
+  a1 = s;
+  a2 = q;
+}
+VG_DEVICE void du_value(const float (&dyv)[8], const float (&gm)[8], const float (&d)[8], float r, float s1, float s2, float (&o)[8]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float g = dyv[e] * gm[e];
+    o[e] = r * (g - s1) - s2 * d[e];
+  }
+}
+
 // run-based backward through the norm (same shapes as dwnorm_fwd_run_kernel; RF frames per run -- 4: the extra dy rows and
 // partial sums leave no registers for 8 at two waves per SIMD): recomputes v for the frames of a run from one
 // (RF + 6)-row window, the two reductions of the frames interleave; the per-lane gamma / beta partial sums of
@@ -552,20 +581,13 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
       rr[f] = r;
       float dyv[8];
       V8<bf16_t>::expand(rdy[f], dyv);
-      float a1 = 0.f, a2 = 0.f;
+      du_sums(dyv, gm, mean, v[f], s1[f], s2[f]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float d = v[f][e] - mean;
         const float dd = dyv[e] * on;
-        const float g = dd * gm[e];
-        v[f][e] = d;
-        a1 += g;
-        a2 = fmaf(g, d, a2);
-        sg[e] = fmaf(dd * d, r, sg[e]);
+        sg[e] = fmaf(dd * v[f][e], r, sg[e]);
         sb[e] += dd;
       }
-      s1[f] = a1;
-      s2[f] = a2;
     }
 #pragma unroll
     for (int f = 0; f < RF; ++f) s1[f] = wave_sum(s1[f]) * inv_c;
@@ -576,8 +598,7 @@ __global__ __launch_bounds__(256) void dwnorm_bwd_norm_run_kernel(const bf16_t* 
       if (t0 + f < Tn) {
         float dyv[8], o[8];
         V8<bf16_t>::expand(rdy[f], dyv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rr[f] * (dyv[e] * gm[e] - s1[f]) - s2[f] * v[f][e];
+        du_value(dyv, gm, v[f], rr[f], s1[f], s2[f], o);
         V8<bf16_t>::store(du + (row0 + f) * a.C + lane * 8, o);
       }
     }
@@ -713,6 +734,270 @@ __global__ __launch_bounds__(256, VG_DW_BWDCONV_OCC) void dwnorm_bwd_conv_run_ke
   __syncthreads();
   for (int i = threadIdx.x; i < 512 * TAPS; i += 256)
     wpart[(long)blockIdx.x * a.C * a.taps + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: the whole backward of (depthwise conv -> channel norm) in ONE launch (the tile DESIGN has
+// named since round 3).  The two run kernels above meet through HBM: the first writes du = d loss / d v for every frame,
+// the second reads it back three times (its 10-row window, the run's own rows, and -- in the caller -- the per-sequence
+// column sums).  Here a block owns FT = 26 consecutive frames of ONE sequence:
+//   phase 0  the FT + 12 rows of x the tile touches go to LDS once (zero rows outside the sequence: no masks later);
+//   phase 1  every wave recomputes v for 8 of the FT + 6 frames whose du the tile's dx needs (two runs of four, windows
+//            out of LDS), turns them into du with the saved statistics and parks du (bf16, the rounding the two-launch
+//            form stores) in LDS; the gamma / beta sums count the tile's own frames only;
+//   phase 2  every wave takes 7 of the tile's frames: dx from a 13-row du window, tap gradients from a 13-row x window,
+//            both out of LDS;
+//   the four waves' partial sums meet in LDS (the x / du images are dead by then).
+// Arithmetic and its order per frame are those of dwnorm_bwd_norm_run_kernel / dwnorm_bwd_conv_run_kernel: du and dx come
+// out bitwise equal; the partial sums group other frames per block (fp32, reduced by the same vg_colsum_multi).
+// HBM: dy, x, dx_add read once (+ 6 / 12 halo rows per 26, mostly L2 hits of the neighbouring block), dx (and du, when the
+// caller wants it) written once.  70 KB of LDS, two blocks per CU.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FT = 26;              // frames a block owns
+constexpr int FD = FT + 6;          // du frames in LDS
+constexpr int FX = FT + 12;         // x rows in LDS
+constexpr int FUSED_LDS = (FX + FD) * 1024;
+constexpr int FRUN = 7;             // frames per wave in phase 2 (4 x 7 >= FT)
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ w, const float* __restrict__ cbias,
+                                                                  const float* __restrict__ temb, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                  const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ du_out,
+                                                                  bf16_t* __restrict__ dx, float* __restrict__ part,
+                                                                  float* __restrict__ wpart, DwArgs a, int bps) {
+  static_assert(TAPS == 7, "FD / FX are laid out for 7 taps");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                     // x rows T0 - 6 .. T0 + FT + 5
+  char* dsm = smem + FX * 1024;        // du frames A .. A + FD - 1
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = blockIdx.x / bps, tile = blockIdx.x - s * bps;
+  int Tn, bte;
+  long rbase;
+  if (a.cu) {
+    rbase = a.cu[s];
+    Tn = a.cu[s + 1] - (int)rbase;
+    bte = min(s, a.nbatch - 1);
+  } else {
+    Tn = a.Tn;
+    rbase = (long)s * a.Tn;
+    bte = s;
+  }
+  const int T0 = tile * FT;
+  float* part_b = part + (long)blockIdx.x * 2 * a.C;
+  float* wpart_b = wpart + (long)blockIdx.x * a.C * TAPS;
+  if (T0 >= Tn) {                      // no frame of this sequence here: the reducers still read the block's rows
+    for (int i = threadIdx.x; i < 2 * 512; i += 256) part_b[i] = 0.f;
+    for (int i = threadIdx.x; i < 512 * TAPS; i += 256) wpart_b[i] = 0.f;
+    return;
+  }
+  const int Tend = min(T0 + FT, Tn);   // own frames: [T0, Tend)
+  const int A = T0 + a.shift - (TAPS - 1);
+  const long ldy = a.ldy > 0 ? a.ldy : a.C;
+  const bf16_t* xb = x + rbase * a.C + lane * 8;
+  // ---- phase 0: every global read of the block is requested here
+  uint4 xr[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const int r = wave + 4 * q;
+    if (r < FX) xr[q] = *reinterpret_cast<const uint4*>(xb + (long)min(max(T0 - 6 + r, 0), Tn - 1) * a.C);
+  }
+  uint4 rdy[4];                        // the dy rows of the first run of four; the second run's are requested when these are done
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    rdy[i] = *reinterpret_cast<const uint4*>(dy + (rbase + min(max(A + 8 * wave + i, 0), Tn - 1)) * ldy + lane * 8);
+  const long srow = rbase + min(max(A + 8 * wave + (lane & 7), 0), Tn - 1);
+  const float st_mean = mean_in[srow], st_rstd = rstd_in[srow];       // lane i < 8: statistics of the wave's du frame i
+  RunParams<TAPS> P;
+  P.load(w, lane);
+  float cbt[8], gm[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cbt[e] = 0.f; gm[e] = 1.f; }
+  if (cbias) load8(cbias + lane * 8, cbt);
+  if (gamma) load8(gamma + lane * 8, gm);
+  if (temb) {
+    float te[8];
+    load8(temb + (long)bte * a.C + lane * 8, te);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cbt[e] += te[e];
+  }
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const int r = wave + 4 * q;
+    if (r < FX) {
+      const int tx = T0 - 6 + r;
+      const bool in = tx >= 0 && tx < Tn;
+      *reinterpret_cast<uint4*>(xs + r * 1024 + lane * 16) = in ? xr[q] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: du of frames A + 8 wave .. + 7
+  const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
+  float sg[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
+#pragma unroll
+  for (int rn = 0; rn < 2; ++rn) {
+    const int i0 = 8 * wave + 4 * rn;
+    float v[4][8];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[f][e] = cbt[e];
+#pragma unroll
+    for (int j = 0; j < 4 + TAPS - 1; ++j) {
+      float xv[8];
+      V8<bf16_t>::expand(*reinterpret_cast<const uint4*>(xs + (i0 + j) * 1024 + lane * 16), xv);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int k = j - f;
+        if (k >= 0 && k < TAPS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[f][e] = fmaf(P.w[e][k], xv[e], v[f][e]);
+        }
+      }
+    }
+    float s1[4], s2[4], rr[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int td = A + i0 + f;
+      // (the builtin moves 32-bit integers: a float argument would be converted, not copied)
+      const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st_mean), 4 * rn + f));
+      const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st_rstd), 4 * rn + f));
+      const float own = (td >= T0 && td < Tend) ? 1.f : 0.f;       // the partial sums count a frame once: in its own tile
+      rr[f] = r;
+      float dyv[8];
+      V8<bf16_t>::expand(rdy[f], dyv);
+      du_sums(dyv, gm, mean, v[f], s1[f], s2[f]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dd = dyv[e] * own;
+        sg[e] = fmaf(dd * v[f][e], r, sg[e]);
+        sb[e] += dd;
+      }
+      // pin the sums here: left free, the compiler sinks all eight frames' accumulation below the last barrier and keeps
+      // every frame's dy and d alive until then (96 spilled registers)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(sg[e]), "+v"(sb[e]));
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) s1[f] = wave_sum(s1[f]) * inv_c;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) s2[f] = wave_sum(s2[f]) * rr[f] * rr[f] * rr[f] * inv_c1;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int td = A + i0 + f;
+      const bool in = td >= 0 && td < Tn;                           // du outside the sequence: the convolution's zero padding
+      float dyv[8], o[8];
+      V8<bf16_t>::expand(rdy[f], dyv);
+      du_value(dyv, gm, v[f], rr[f], s1[f], s2[f], o);
+      bf16x8 ob;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ob[e] = in ? (bf16_t)o[e] : (bf16_t)0.0f;
+      *reinterpret_cast<bf16x8*>(dsm + (i0 + f) * 1024 + lane * 16) = ob;
+      if (du_out != nullptr && td >= T0 && td < Tend) *reinterpret_cast<bf16x8*>(du_out + (rbase + td) * a.C + lane * 8) = ob;
+    }
+    if (rn == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rdy[i] = *reinterpret_cast<const uint4*>(dy + (rbase + min(max(A + 8 * wave + 4 + i, 0), Tn - 1)) * ldy + lane * 8);
+    }
+  }
+  // (requested here, not in phase 0: 28 more live registers through phase 1 spill; the other block of the CU covers the wait)
+  uint4 radd[FRUN];
+  if (dx_add) {
+#pragma unroll
+    for (int f = 0; f < FRUN; ++f)
+      radd[f] = *reinterpret_cast<const uint4*>(dx_add + (rbase + min(T0 + FRUN * wave + f, Tn - 1)) * a.C + lane * 8);
+  }
+  __syncthreads();
+  // ---- phase 2: own frames T0 + 7 wave .. + 6, in sub-runs of 4 + 3 (seven at once: 56 + 56 registers of frames next to the
+  // 56 of the weights -- the compiler then parks the gamma / beta sums in scratch)
+  const int f0 = FRUN * wave;
+  float gw[8][TAPS];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) gw[e][k] = 0.f;
+  auto sub_run = [&](auto fb_c, auto nf_c) __attribute__((always_inline)) {
+    constexpr int FB = decltype(fb_c)::value, NF = decltype(nf_c)::value;      // frames f0 + FB .. + NF - 1
+    {
+      float o[NF][8];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (dx_add) V8<bf16_t>::expand(radd[FB + f], o[f]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[f][e] = 0.f;
+        }
+      }
+      // du frame t + shift - k sits in LDS row (t - T0) + 6 - k: window row j = f + 6 - k of the sub-run's NF + 6
+#pragma unroll
+      for (int j = 0; j < NF + TAPS - 1; ++j) {
+        float dv[8];
+        V8<bf16_t>::expand(*reinterpret_cast<const uint4*>(dsm + min(f0 + FB + j, FD - 1) * 1024 + lane * 16), dv);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int k = f + TAPS - 1 - j;
+          if (k >= 0 && k < TAPS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[f][e] = fmaf(P.w[e][k], dv[e], o[f][e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        if (T0 + f0 + FB + f < Tend) V8<bf16_t>::store(dx + (rbase + T0 + f0 + FB + f) * a.C + lane * 8, o[f]);
+    }
+    {
+      // own du frame t: LDS row (t - T0) + 6 - shift; x frame t + k - shift: LDS row (t - T0) + 6 - shift + k
+      const int base = f0 + FB + (TAPS - 1) - a.shift;
+      float duv[NF][8];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        V8<bf16_t>::expand(*reinterpret_cast<const uint4*>(dsm + min(base + f, FD - 1) * 1024 + lane * 16), duv[f]);
+        const float on = T0 + f0 + FB + f < Tend ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) duv[f][e] *= on;
+      }
+#pragma unroll
+      for (int j = 0; j < NF + TAPS - 1; ++j) {
+        float xv[8];
+        V8<bf16_t>::expand(*reinterpret_cast<const uint4*>(xs + min(base + j, FX - 1) * 1024 + lane * 16), xv);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int k = j - f;
+          if (k >= 0 && k < TAPS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gw[e][k] = fmaf(duv[f][e], xv[e], gw[e][k]);
+          }
+        }
+      }
+    }
+  };
+  sub_run(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+  __builtin_amdgcn_sched_barrier(0);
+  sub_run(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+  // ---- the four waves' partial sums
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) red[wave * 512 * TAPS + (lane * 8 + e) * TAPS + k] = gw[e][k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512 * TAPS; i += 256)
+    wpart_b[i] = red[i] + red[512 * TAPS + i] + red[2 * 512 * TAPS + i] + red[3 * 512 * TAPS + i];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[wave * 1024 + lane * 8 + e] = sg[e];
+    red[wave * 1024 + 512 + lane * 8 + e] = sb[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 512; i += 256) part_b[i] = red[i] + red[1024 + i] + red[2048 + i] + red[3072 + i];
 }
 
 // du = r * (g - mean(g)) - r^3 / (C - 1) * d * sum(g * d),  g = dy * gamma, d = v - mean
@@ -1057,4 +1342,34 @@ extern "C" int vg_dwnorm_bwd_ld(const void* dy, int64_t ldy, const void* x, cons
                                                                    (const bf16_t*)dx_add, (bf16_t*)dx, w_part, a);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_dwnorm_bwd_ld");
+}
+
+// ---- round 6: the one-launch backward (dwnorm_bwd_fused_kernel).  bf16, C = 512, 7 taps; cu_rows == nullptr: M / T
+// sequences of T rows (max_len = T), else packed rows whose sequences have at most max_len rows.  The partial-sum arrays
+// have vg_dwnorm_bwd_fused_blocks(nseq, max_len) rows; du may be nullptr (nobody reads it).
+extern "C" int vg_dwnorm_bwd_fused_blocks(int nseq, int max_len) { return nseq * ((max_len + FT - 1) / FT); }
+
+extern "C" int vg_dwnorm_bwd_fused(const void* dy, int64_t ldy, const void* x, const float* w, const float* cbias, const float* temb,
+                                   const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
+                                   float* norm_part, float* w_part, int M, int C, int T, const int* cu_rows, int nseq, int nbatch,
+                                   int max_len, int taps, int shift, int dtype, hipStream_t stream) {
+  if (int e = check_cat("vg_dwnorm_bwd_fused", M, C, T, cu_rows, nseq, nbatch, taps, dtype, (long)ldy)) return e;
+  VG_REQUIRE(shift >= 0 && shift <= 6, "vg_dwnorm_bwd_fused: shift=%d (0..6)", shift);
+  const int ns = cu_rows ? nseq : M / T, ml = cu_rows ? max_len : T;
+  VG_REQUIRE(ml > 0 && ns > 0, "vg_dwnorm_bwd_fused: nseq=%d max_len=%d", ns, ml);
+  DwArgs a{M, C, cu_rows ? M : T, taps, shift, 0.f, cu_rows, cu_rows ? nseq : 0, cu_rows ? nbatch : 0};
+  a.ldy = (long)ldy;
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwnorm_bwd_fused_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FUSED_LDS);
+    return true;
+  }();
+  (void)once;
+  const int bps = (ml + FT - 1) / FT;
+  const int tok = vg_host::prof_begin(VG_PROF_DWNORM_BWD, (double)M * ((dx_add ? 4.0 : 3.0) * C * 2 + (du ? 2.0 * C : 0.0) + 8.0), stream);
+  dwnorm_bwd_fused_kernel<7><<<dim3(ns * bps), dim3(256), FUSED_LDS, stream>>>(
+      (const bf16_t*)dy, (const bf16_t*)x, w, cbias, temb, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)du, (bf16_t*)dx, norm_part,
+      w_part, a, bps);
+  vg_host::prof_end(tok, stream);
+  return vg_host::check_launch("vg_dwnorm_bwd_fused");
 }

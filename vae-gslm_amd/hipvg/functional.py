@@ -157,6 +157,29 @@ def on_side_stream() -> bool:
 
 _MAIN_OF_SIDE = {}
 
+# ---- the stream a hipGraph with parallel branches is launched on.  ROCm 7.0's hip::Graph::UpdateStreams (first hipGraphLaunch
+# of an exec) hands branch i the next of the exec's max_streams internal streams whose virtual device differs from the launch
+# stream's, and walks past the end of that vector when two of them sit where the launch stream sits: SIGSEGV inside
+# hipGraphLaunch.  Streams share the device's few hardware queues (least-loaded first), so it takes a long-lived process with an
+# uneven stream population -- the GPU test suite hit it at its 306th test, deterministically for a given tree, and
+# tools/lab/hipgraph_queue_collision.py reproduces it in 40 lines.  The internal streams are of normal priority and the queue
+# pools are per priority: a HIGH-priority launch stream can never match one, so the walk takes the first max_streams - 1
+# streams and stops.  Every graph of this package is launched from such a stream.
+_LAUNCH_STREAMS = {}
+
+
+def graph_launch_stream(device) -> "torch.cuda.Stream":
+    """The calling thread's current stream if it is a created high-priority stream, else this process's high-priority
+    launch stream of ``device`` (created once)."""
+    dev = torch.device(device)
+    cur = torch.cuda.current_stream(dev)
+    if cur != torch.cuda.default_stream(dev) and getattr(cur, "priority", 0) < 0:
+        return cur
+    st = _LAUNCH_STREAMS.get(dev)
+    if st is None:
+        st = _LAUNCH_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
+    return st
+
 
 def fork_side(device):
     """-> (side, main): the side stream now waits for everything queued on the current stream."""
@@ -1704,8 +1727,37 @@ def dwnorm_fwd_raw(x, w, cb, te, gamma, beta, T, taps, shift, eps):
     return y, mean, rstd
 
 
+# round 6: the backward of a conv block's (depthwise conv -> norm) pair as ONE launch that keeps du in LDS
+# (include/vaegslm_hip.h: vg_dwnorm_bwd_fused).  VG_DW_FUSED=0: the two run kernels, for A/B runs.
+_DW_FUSED = _flag("VG_DW_FUSED", "1")
+
+
+def _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift, want_du=True):
+    M, Cc = x.shape
+    plan = T if isinstance(T, PackPlan) else None
+    nseq, max_len = (plan.nseq, plan.T) if plan else (M // int(T), int(T))
+    nb = lib().vg_dwnorm_bwd_fused_blocks(nseq, max_len)
+    du = torch.empty_like(x) if want_du else None
+    dx = torch.empty_like(x)
+    npart = torch.empty((nb, 2 * Cc), dtype=torch.float32, device=x.device)
+    wpart = torch.empty((nb, Cc * taps), dtype=torch.float32, device=x.device)
+    check(lib().vg_dwnorm_bwd_fused(ptr(dy), dy.stride(0), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
+                                    ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, 0 if plan else int(T),
+                                    ptr(plan.cu) if plan else None, plan.nseq if plan else 0, plan.B if plan else 0, max_len,
+                                    int(taps), int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd_fused")
+    return du, dx, npart[:, :Cc], npart[:, Cc:], wpart
+
+
+def _dw_fused_ok(dy, x, T, taps, shift) -> bool:
+    return (_DW_FUSED and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.shape[1] == 512 and taps == 7
+            and 0 <= shift <= 6 and dy.stride(1) == 1 and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0
+            and (isinstance(T, PackPlan) or (int(T) > 0 and x.shape[0] % int(T) == 0)))
+
+
 def dwnorm_bwd_raw(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
     M, Cc = x.shape
+    if _dw_fused_ok(dy, x, T, taps, shift):
+        return _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift)
     nb = lib().vg_dwnorm_blocks(M)
     du = torch.empty_like(x)
     dx = torch.empty_like(x) if taps > 0 else du
@@ -1769,6 +1821,8 @@ def dwnorm_bwd_ld_raw(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shif
     """dwnorm_bwd_raw for an incoming gradient that is the first C columns of wider rows (vg_dwnorm_bwd_ld)."""
     M, Cc = x.shape
     assert dy.shape[0] == M and dy.stride(1) == 1 and dy.stride(0) >= Cc
+    if _dw_fused_ok(dy, x, T, taps, shift):
+        return _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift)
     nb = lib().vg_dwnorm_blocks(M)
     du = torch.empty_like(x)
     dx = torch.empty_like(x)

@@ -261,7 +261,16 @@ class DecodeSession:
             self._graph, self._graph_last = graph, self._last     # the capture's output buffers
             self._last = eager_last
             return first
-        self._graph.replay()
+        # The captured step is one chain of launches (no parallel branch: hip::Graph::UpdateStreams has nothing to assign) unless
+        # the lab prefetch branch is on; then the launch-stream rule of hipvg.functional.graph_launch_stream applies.
+        launch, cur = (HF.graph_launch_stream(self.dev) if self._side is not None else None), torch.cuda.current_stream(self.dev)
+        if launch is None or launch == cur:
+            self._graph.replay()
+        else:
+            launch.wait_stream(cur)
+            with torch.cuda.stream(launch):
+                self._graph.replay()
+            cur.wait_stream(launch)
         self._last = self._graph_last
         return result()
 

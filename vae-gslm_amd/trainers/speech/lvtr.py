@@ -400,10 +400,13 @@ class LVTRTrainer(BaseTrainer):
         step costs 1 ms of cross-stream waits per step), so the caller's later work is ordered after the step as
         before."""
         cur = torch.cuda.current_stream(dev)
-        if cur != torch.cuda.default_stream(dev):
+        prio = int(os.environ.get("VG_MAIN_PRIO", "-1"))      # (0: lab -- a normal-priority compute stream, the hazard below open)
+        # The stream must also be of HIGH priority: the first launch of a graph with parallel branches from a normal-priority
+        # stream can walk off the exec's internal stream list inside hipGraphLaunch (hipvg.functional.graph_launch_stream).
+        if cur != torch.cuda.default_stream(dev) and (prio >= 0 or getattr(cur, "priority", 0) < 0):
             return
         if self._compute_stream is None:
-            self._compute_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("VG_MAIN_PRIO", "0")))
+            self._compute_stream = torch.cuda.Stream(device=dev, priority=prio)
         self._compute_stream.wait_stream(cur)
         torch.cuda.set_stream(self._compute_stream)
 
@@ -571,6 +574,7 @@ class LVTRTrainer(BaseTrainer):
         during warm-up), inputs are copied into static buffers, gradients accumulate into the
         reducer's static buckets.  With N > 1 ranks the bucket all-reduces are issued after the
         last replay of the window (bulk, not overlapped with backward)."""
+        self.enter_compute_stream(batch["mel"].value.device)     # (callers that come here directly: the launch-stream rule)
         batch = self._pad_for_graph(batch)
         key = tuple((k, tuple(v.value.shape), getattr(v.mask, "_vg_full", False)) for k, v in sorted(batch.items()))
         # packed rows: the number of packed rows is part of the graph's shape.  It is chosen here, on the host, from
