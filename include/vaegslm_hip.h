@@ -339,13 +339,15 @@ int vg_dwnorm_bwd_ld(const void* dy, int64_t ldy, const void* x, const float* w,
  * in LDS and takes dx and the tap gradients from there (the two-launch form writes du to HBM and reads it back).  du and dx
  * are bitwise those of vg_dwnorm_bwd / _seg / _ld; norm_part [nblk][2C] and w_part [nblk][C * taps] have
  * nblk = vg_dwnorm_bwd_fused_blocks(nseq, max_len) rows (other frames per row than the two-launch form: same column sums up
- * to fp32 rounding).  du may be NULL (not stored).  bf16, C = 512, 7 taps, 0 <= shift <= 6; cu_rows = NULL: nseq = M / T
+ * to fp32 rounding).  du may be NULL (not stored); du_part (or NULL): fp32 [nblk][C], the column sums of each block's own du
+ * rows as stored (bf16) -- blocks [s * nblk / nseq, (s + 1) * nblk / nseq) belong to sequence s, so the per-sequence sums the
+ * time-embedding and conv-bias gradients need (modules/conv/layers.py:96) come from nblk small rows instead of a pass over du.  bf16, C = 512, 7 taps, 0 <= shift <= 6; cu_rows = NULL: nseq = M / T
  * sequences of T rows (max_len ignored), else packed rows, every sequence at most max_len rows. */
 int vg_dwnorm_bwd_fused_blocks(int nseq, int max_len);
 int vg_dwnorm_bwd_fused(const void* dy, int64_t ldy, const void* x, const float* w, const float* cbias, const float* temb,
                         const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
-                        float* norm_part, float* w_part, int M, int C, int T, const int32_t* cu_rows, int nseq, int nbatch,
-                        int max_len, int taps, int shift, int dtype, vg_stream_t stream);
+                        float* norm_part, float* w_part, float* du_part, int M, int C, int T, const int32_t* cu_rows, int nseq,
+                        int nbatch, int max_len, int taps, int shift, int dtype, vg_stream_t stream);
 
 /* ---------------------------------------------------------------- autoregressive decode step
  * LVTR.step (models/speech/lvtr.py:227-286): one new frame per sequence.

@@ -557,9 +557,13 @@ def test_dwnorm_backward_in_one_launch_equals_the_two_launches(F, monkeypatch, B
     for name, a, b in (("gamma", pg0, pg1), ("beta", pb0, pb1), ("taps", pw0, pw1)):
         want, got = a.double().sum(0), b.double().sum(0)
         assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6, name
-    # without the du store (nobody reads it): dx and the sums unchanged
-    _, dx2, pg2, _, pw2 = F._dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dxa, T, 7, shift, want_du=False)
-    assert torch.equal(dx2, dx1) and torch.equal(pg2, pg1) and torch.equal(pw2, pw1)
+    # without the du store (nobody reads it): dx and the sums unchanged; the per-sequence column sums of du the conv block
+    # needs (time-embedding / conv-bias gradient) out of the same launch, against a pass over the stored du
+    none, dx2, pg2, _, pw2, dte = F._dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dxa, T, 7, shift, want_du=False,
+                                                      du_sums=True)
+    assert none is None and torch.equal(dx2, dx1) and torch.equal(pg2, pg1) and torch.equal(pw2, pw1)
+    want = du1.double().view(B, T, C).sum(1)
+    assert dte.shape == (B, C) and float((dte.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
 
 
 def test_dwnorm_backward_in_one_launch_on_packed_rows(F, monkeypatch):
@@ -583,6 +587,10 @@ def test_dwnorm_backward_in_one_launch_on_packed_rows(F, monkeypatch):
     du1, dx1, pg1, pb1, pw1 = F.dwnorm_bwd_raw(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift)
     assert pg1.shape[0] == plan.nseq * -(-T // 26)
     assert torch.equal(du0, du1) and torch.equal(dx0, dx1)
+    dx2, dte, _, _, _ = F.dwnorm_bwd_block(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift)
+    want = F.segment_colsum(du1, plan)[:Bq].double()
+    assert torch.equal(dx2, dx1) and dte.shape == (Bq, C)
+    assert float((dte.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
     for name, a, b in (("gamma", pg0, pg1), ("beta", pb0, pb1), ("taps", pw0, pw1)):
         want, got = a.double().sum(0), b.double().sum(0)
         assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6, name

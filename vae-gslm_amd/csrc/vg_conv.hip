@@ -766,7 +766,8 @@ __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* 
                                                                   const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                                   const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ du_out,
                                                                   bf16_t* __restrict__ dx, float* __restrict__ part,
-                                                                  float* __restrict__ wpart, DwArgs a, int bps) {
+                                                                  float* __restrict__ wpart, float* __restrict__ dupart, DwArgs a,
+                                                                  int bps) {
   static_assert(TAPS == 7, "FD / FX are laid out for 7 taps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                     // x rows T0 - 6 .. T0 + FT + 5
@@ -790,6 +791,7 @@ __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* 
   if (T0 >= Tn) {                      // no frame of this sequence here: the reducers still read the block's rows
     for (int i = threadIdx.x; i < 2 * 512; i += 256) part_b[i] = 0.f;
     for (int i = threadIdx.x; i < 512 * TAPS; i += 256) wpart_b[i] = 0.f;
+    if (dupart) for (int i = threadIdx.x; i < 512; i += 256) dupart[(long)blockIdx.x * a.C + i] = 0.f;
     return;
   }
   const int Tend = min(T0 + FT, Tn);   // own frames: [T0, Tend)
@@ -834,9 +836,9 @@ __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* 
   __syncthreads();
   // ---- phase 1: du of frames A + 8 wave .. + 7
   const float inv_c = 1.0f / (float)a.C, inv_c1 = 1.0f / (float)(a.C - 1);
-  float sg[8], sb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
+  float sg[8], sb[8], sdu[8];          // sdu: column sums of the tile's own du rows (as stored: bf16) -- the caller's per-sequence
+#pragma unroll                         // sums (time-embedding / conv-bias gradient) without a pass over du
+  for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; sdu[e] = 0.f; }
 #pragma unroll
   for (int rn = 0; rn < 2; ++rn) {
     const int i0 = 8 * wave + 4 * rn;
@@ -896,7 +898,16 @@ __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* 
 #pragma unroll
       for (int e = 0; e < 8; ++e) ob[e] = in ? (bf16_t)o[e] : (bf16_t)0.0f;
       *reinterpret_cast<bf16x8*>(dsm + (i0 + f) * 1024 + lane * 16) = ob;
-      if (du_out != nullptr && td >= T0 && td < Tend) *reinterpret_cast<bf16x8*>(du_out + (rbase + td) * a.C + lane * 8) = ob;
+      if (td >= T0 && td < Tend) {
+        if (du_out != nullptr) *reinterpret_cast<bf16x8*>(du_out + (rbase + td) * a.C + lane * 8) = ob;
+        if (dupart != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            sdu[e] += (float)ob[e];
+            asm volatile("" : "+v"(sdu[e]));       // (pinned like sg / sb above)
+          }
+        }
+      }
     }
     if (rn == 0) {
       __builtin_amdgcn_sched_barrier(0);
@@ -998,6 +1009,13 @@ __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* 
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * 512; i += 256) part_b[i] = red[i] + red[1024 + i] + red[2048 + i] + red[3072 + i];
+  if (dupart != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[4096 + wave * 512 + lane * 8 + e] = sdu[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256)
+      dupart[(long)blockIdx.x * a.C + i] = red[4096 + i] + red[4096 + 512 + i] + red[4096 + 1024 + i] + red[4096 + 1536 + i];
+  }
 }
 
 // du = r * (g - mean(g)) - r^3 / (C - 1) * d * sum(g * d),  g = dy * gamma, d = v - mean
@@ -1346,13 +1364,14 @@ extern "C" int vg_dwnorm_bwd_ld(const void* dy, int64_t ldy, const void* x, cons
 
 // ---- round 6: the one-launch backward (dwnorm_bwd_fused_kernel).  bf16, C = 512, 7 taps; cu_rows == nullptr: M / T
 // sequences of T rows (max_len = T), else packed rows whose sequences have at most max_len rows.  The partial-sum arrays
-// have vg_dwnorm_bwd_fused_blocks(nseq, max_len) rows; du may be nullptr (nobody reads it).
+// have vg_dwnorm_bwd_fused_blocks(nseq, max_len) rows; du may be nullptr (nobody reads it); du_part (nullable): [blocks][C]
+// column sums of the du rows of each block (block b belongs to sequence b / (blocks / nseq)).
 extern "C" int vg_dwnorm_bwd_fused_blocks(int nseq, int max_len) { return nseq * ((max_len + FT - 1) / FT); }
 
 extern "C" int vg_dwnorm_bwd_fused(const void* dy, int64_t ldy, const void* x, const float* w, const float* cbias, const float* temb,
                                    const float* gamma, const float* mean, const float* rstd, const void* dx_add, void* du, void* dx,
-                                   float* norm_part, float* w_part, int M, int C, int T, const int* cu_rows, int nseq, int nbatch,
-                                   int max_len, int taps, int shift, int dtype, hipStream_t stream) {
+                                   float* norm_part, float* w_part, float* du_part, int M, int C, int T, const int* cu_rows, int nseq,
+                                   int nbatch, int max_len, int taps, int shift, int dtype, hipStream_t stream) {
   if (int e = check_cat("vg_dwnorm_bwd_fused", M, C, T, cu_rows, nseq, nbatch, taps, dtype, (long)ldy)) return e;
   VG_REQUIRE(shift >= 0 && shift <= 6, "vg_dwnorm_bwd_fused: shift=%d (0..6)", shift);
   const int ns = cu_rows ? nseq : M / T, ml = cu_rows ? max_len : T;
@@ -1369,7 +1388,7 @@ extern "C" int vg_dwnorm_bwd_fused(const void* dy, int64_t ldy, const void* x, c
   const int tok = vg_host::prof_begin(VG_PROF_DWNORM_BWD, (double)M * ((dx_add ? 4.0 : 3.0) * C * 2 + (du ? 2.0 * C : 0.0) + 8.0), stream);
   dwnorm_bwd_fused_kernel<7><<<dim3(ns * bps), dim3(256), FUSED_LDS, stream>>>(
       (const bf16_t*)dy, (const bf16_t*)x, w, cbias, temb, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)du, (bf16_t*)dx, norm_part,
-      w_part, a, bps);
+      w_part, du_part, a, bps);
   vg_host::prof_end(tok, stream);
   return vg_host::check_launch("vg_dwnorm_bwd_fused");
 }

@@ -119,8 +119,8 @@ SIGNATURES = {
     "vg_dwnorm_bwd_ld": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i,
                          _i, _vp],
     "vg_dwnorm_bwd_fused_blocks": [_i, _i],
-    "vg_dwnorm_bwd_fused": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i,
-                            _i, _i, _vp],
+    "vg_dwnorm_bwd_fused": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i,
+                            _i, _i, _i, _vp],
     "vg_embed_fuse_blocks": [_i],
     "vg_embed_fuse_fwd": [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "vg_embed_fuse_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _i, _vp],

@@ -1732,7 +1732,8 @@ def dwnorm_fwd_raw(x, w, cb, te, gamma, beta, T, taps, shift, eps):
 _DW_FUSED = _flag("VG_DW_FUSED", "1")
 
 
-def _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift, want_du=True):
+def _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift, want_du=True, du_sums=False):
+    """-> (du or None, dx, gamma partials, beta partials, tap partials[, per-sequence column sums of du: fp32 [nseq, C]])."""
     M, Cc = x.shape
     plan = T if isinstance(T, PackPlan) else None
     nseq, max_len = (plan.nseq, plan.T) if plan else (M // int(T), int(T))
@@ -1741,11 +1742,30 @@ def _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shif
     dx = torch.empty_like(x)
     npart = torch.empty((nb, 2 * Cc), dtype=torch.float32, device=x.device)
     wpart = torch.empty((nb, Cc * taps), dtype=torch.float32, device=x.device)
+    dupart = torch.empty((nb, Cc), dtype=torch.float32, device=x.device) if du_sums else None
     check(lib().vg_dwnorm_bwd_fused(ptr(dy), dy.stride(0), ptr(x), ptr(w), ptr(cb), ptr(te), ptr(gamma), ptr(mean), ptr(rstd),
-                                    ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), M, Cc, 0 if plan else int(T),
+                                    ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), ptr(dupart), M, Cc, 0 if plan else int(T),
                                     ptr(plan.cu) if plan else None, plan.nseq if plan else 0, plan.B if plan else 0, max_len,
                                     int(taps), int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd_fused")
+    if du_sums:
+        # blocks [s * bps, (s + 1) * bps) are sequence s: nseq segments of bps rows each
+        return du, dx, npart[:, :Cc], npart[:, Cc:], wpart, segment_colsum(dupart, nseq)
     return du, dx, npart[:, :Cc], npart[:, Cc:], wpart
+
+
+def dwnorm_bwd_block(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
+    """The (depthwise conv -> norm) backward as a conv block needs it: (dx, per-sequence column sums of du [B, C], gamma /
+    beta / tap partial sums).  One launch without a du tensor where vg_dwnorm_bwd_fused runs; else the two run kernels, du
+    through HBM and a pass over it for the sums."""
+    nb_seq = T.B if isinstance(T, PackPlan) else x.shape[0] // int(T)
+    if _dw_fused_ok(dy, x, T, taps, shift):
+        _, dx, pg, pb, pw, dte = _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift, want_du=False,
+                                                   du_sums=True)
+        return dx, dte[:nb_seq], pg, pb, pw
+    wide = dy.stride(0) != x.shape[1]
+    dv, dx, pg, pb, pw = (dwnorm_bwd_ld_raw if wide else dwnorm_bwd_raw)(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift)
+    dte = segment_colsum(dv, T)[:nb_seq] if isinstance(T, PackPlan) else segment_colsum(dv, nb_seq)
+    return dx, dte, pg, pb, pw
 
 
 def _dw_fused_ok(dy, x, T, taps, shift) -> bool:
@@ -1984,14 +2004,8 @@ class ConvBlockFn(torch.autograd.Function):
                 _fire(c3w)
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
-        if merged:
-            dv, dx, pg, pb, pw = dwnorm_bwd_ld_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
-        else:
-            dv, dx, pg, pb, pw = dwnorm_bwd_raw(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
-        if isinstance(T, PackPlan):
-            dte = segment_colsum(dv, T)[:T.B]          # per-sequence sums; the pseudo sequences' rows carry no gradient
-        else:
-            dte = segment_colsum(dv, dv.shape[0] // T)
+        # dte: per-sequence column sums of d loss / d v (the pseudo sequences' rows of a packed layout carry no gradient)
+        dx, dte, pg, pb, pw = dwnorm_bwd_block(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
         # the five small reductions of this block (conv weight / bias, norm weight / bias, c2's bias) in one launch
         g_c2b, g_c1w, g_c1b, g_nw, g_nb = vec_grads([
             (None if id(c2b) in fused_bias else c2b, parts[0] if parts and parts[0] is not None else dpre),
