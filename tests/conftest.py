@@ -13,6 +13,13 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+# The GPU suite is one long-lived process that creates and destroys hundreds of graphs and streams: the stream population
+# ROCm 7.0's hipGraphLaunch needs to walk off an exec's internal stream list (hipvg.functional.graph_launch_stream; the suite
+# died of it at its 306th test).  Graphs are launched from a high-priority stream here; the product default stays an ordinary
+# stream (tests/test_parity_round6_gpu.py::test_graph_launch_survives_an_uneven_stream_population covers the kinds).
+os.environ.setdefault("VG_LAUNCH_STREAM", "prio")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

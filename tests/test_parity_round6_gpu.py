@@ -645,20 +645,24 @@ for i in range(3):
     out = tr._graphed_micro_step(batch, i, True)
 torch.cuda.synchronize()
 assert tr.use_graph, "the capture fell back to eager launches"
-assert torch.cuda.current_stream().priority < 0
+from hipvg import functional as HF
+assert HF.is_safe_launch_stream(torch.cuda.current_stream())
 print("graph step ok", float(out["loss"]))
 """
 
 
-def test_graph_launch_survives_an_uneven_stream_population():
-    """ROCm 7.0's first hipGraphLaunch of an exec with parallel branches walks off the exec's internal stream list when two
-    of those streams share the launch stream's hardware queue (hip::Graph::UpdateStreams; met as a SIGSEGV at the 306th test
-    of this suite, reproduced by tools/lab/hipgraph_queue_collision.py).  The trainer therefore launches its graphs from a
-    HIGH-priority stream (other queue pool: no internal stream can match).  Here: a process whose stream population is made
-    uneven on purpose -- the next streams created all land on one light hardware queue, the calling thread's stream among
-    them -- then captures and replays a training micro-step."""
+@pytest.mark.parametrize("kind", ["prio", "mask"])
+def test_graph_launch_survives_an_uneven_stream_population(kind):
+    """ROCm 7.0's hipGraphLaunch of an exec with parallel branches walks off the exec's internal stream list when two of
+    those streams share the launch stream's hardware queue (hip::Graph::UpdateStreams; met as a SIGSEGV at the 306th test of
+    this suite, reproduced by tools/lab/hipgraph_queue_collision.py).  With VG_LAUNCH_STREAM = prio / mask the trainer
+    launches its graphs from a stream whose queue is outside the pool the internal streams come from.  Here: a process whose
+    stream population is made uneven on purpose -- the next streams created all land on one light hardware queue, the calling
+    thread's stream among them -- then captures and replays a training micro-step.  (With VG_LAUNCH_STREAM=normal, the product
+    default for fresh processes, this very script dies of SIGSEGV: profiles/r06/labs/hipgraph_launch_stream.txt.)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _UNEVEN_STREAMS.format(root=root) + "sys.path.insert(0, %r)\n" % root + _GRAPH_STEP.format(root=root)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, VG_LAUNCH_STREAM=kind))
     assert r.returncode == 0 and "graph step ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])

@@ -12,8 +12,9 @@ streams can land where the launch stream sits.
 This script makes that population on purpose: 4 k raw streams, then all of one residue class destroyed (one hardware queue
 k lighter than the others), a launch stream created next (lands on the light queue), then a 3-branch graph instantiated
 (its internal streams land there too) and launched.  MODE=normal: launch stream of normal priority (expected: SIGSEGV);
-MODE=high: launch stream of high priority (other queue pool: expected to run).
-    MODE=normal|high [K=8] python tools/lab/hipgraph_queue_collision.py"""
+MODE=high: launch stream of high priority (other queue pool: expected to run); MODE=mask: launch stream created with
+a full CU mask (a queue of its own: expected to run).
+    MODE=normal|high|mask [K=8] python tools/lab/hipgraph_queue_collision.py"""
 import ctypes
 import os
 import sys
@@ -41,7 +42,11 @@ for i, s in enumerate(raw):
     if i % 4 == RES:
         assert hip.hipStreamDestroy(s) == 0
 launch = ctypes.c_void_p()
-if mode == "high":
+if mode == "mask":      # every CU, normal priority, a hardware queue of its own
+    words = 8
+    full = (ctypes.c_uint32 * words)(*([0xFFFFFFFF] * words))
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(launch), ctypes.c_uint32(words), full) == 0
+elif mode == "high":
     lo, hi = ctypes.c_int(), ctypes.c_int()
     hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi))
     assert hip.hipStreamCreateWithPriority(ctypes.byref(launch), 1, hi.value) == 0

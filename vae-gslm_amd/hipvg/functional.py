@@ -157,27 +157,56 @@ def on_side_stream() -> bool:
 
 _MAIN_OF_SIDE = {}
 
-# ---- the stream a hipGraph with parallel branches is launched on.  ROCm 7.0's hip::Graph::UpdateStreams (first hipGraphLaunch
-# of an exec) hands branch i the next of the exec's max_streams internal streams whose virtual device differs from the launch
-# stream's, and walks past the end of that vector when two of them sit where the launch stream sits: SIGSEGV inside
-# hipGraphLaunch.  Streams share the device's few hardware queues (least-loaded first), so it takes a long-lived process with an
-# uneven stream population -- the GPU test suite hit it at its 306th test, deterministically for a given tree, and
-# tools/lab/hipgraph_queue_collision.py reproduces it in 40 lines.  The internal streams are of normal priority and the queue
-# pools are per priority: a HIGH-priority launch stream can never match one, so the walk takes the first max_streams - 1
-# streams and stops.  Every graph of this package is launched from such a stream.
+# ---- the stream a hipGraph with parallel branches is launched on.  ROCm 7.0's hip::Graph::UpdateStreams (every hipGraphLaunch
+# of an exec with more than one branch) hands branch i the next of the exec's max_streams internal streams whose virtual device
+# differs from the launch stream's, and walks past the end of that vector when two of them sit where the launch stream sits:
+# SIGSEGV inside hipGraphLaunch.  Streams share the device's few pooled hardware queues (least-loaded first), so it takes a
+# long-lived process with an uneven stream population -- the GPU test suite hit it at its 306th test, deterministically for a
+# given tree, and tools/lab/hipgraph_queue_collision.py reproduces it in 40 lines; a fresh process (bench.py, a training run:
+# torch's 32 pooled streams spread evenly, then the graph's) was never seen to.  The internal streams are ordinary streams on
+# the pooled normal-priority queues; a launch stream on a queue OUTSIDE that pool can never match one, so the walk takes the
+# first max_streams - 1 streams and stops.  Two kinds of stream have such a queue: a high-priority stream (its own pool) and a
+# stream created with a full CU mask (a queue of its own).  Both are safe and both have a price: every cross-stream wait that
+# involves them blocks the HOST until the awaited work is done (the traces under rocprofv3 show the same GPU time; the host no
+# longer runs ahead).  A step that is one graph launch does not notice (27.71 - 27.89 ms either way); steps with eager launches
+# and stream traffic between graph pieces do: two micro-steps per optimizer step 34.2 -> 43.6 ms, one-rank RCCL 28.8 -> 40.3 ms
+# (profiles/r06/labs/hipgraph_launch_stream.txt).  VG_LAUNCH_STREAM = normal (default: an ordinary created stream, what every
+# bench line of this repository was measured on) | prio | mask.  tests/conftest.py selects `prio` for the long-lived pytest
+# process, which is exactly the population the hazard needs.
 _LAUNCH_STREAMS = {}
+_SAFE_LAUNCH_IDS = set()
+
+
+def launch_stream_kind() -> str:
+    kind = os.environ.get("VG_LAUNCH_STREAM", "normal").lower()
+    if kind not in ("mask", "prio", "normal"):
+        raise ValueError(f"VG_LAUNCH_STREAM={kind!r}: expected mask, prio or normal")
+    return kind
+
+
+def is_safe_launch_stream(st) -> bool:
+    """Is ``st`` one of this process's launch streams (of whatever kind VG_LAUNCH_STREAM selected)?"""
+    return st.cuda_stream in _SAFE_LAUNCH_IDS
 
 
 def graph_launch_stream(device) -> "torch.cuda.Stream":
-    """The calling thread's current stream if it is a created high-priority stream, else this process's high-priority
-    launch stream of ``device`` (created once)."""
+    """The calling thread's current stream if it is one of this process's launch streams, else the launch stream of ``device``
+    (created once per process)."""
     dev = torch.device(device)
     cur = torch.cuda.current_stream(dev)
-    if cur != torch.cuda.default_stream(dev) and getattr(cur, "priority", 0) < 0:
+    if cur.cuda_stream in _SAFE_LAUNCH_IDS:
         return cur
     st = _LAUNCH_STREAMS.get(dev)
     if st is None:
-        st = _LAUNCH_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
+        kind = launch_stream_kind()
+        if kind == "mask":
+            from hipvg.comm import masked_stream
+            total = torch.cuda.get_device_properties(dev).multi_processor_count
+            st = masked_stream(dev, total, total)
+        else:
+            st = torch.cuda.Stream(device=dev, priority=-1 if kind == "prio" else 0)
+        _LAUNCH_STREAMS[dev] = st
+        _SAFE_LAUNCH_IDS.add(st.cuda_stream)
     return st
 
 

@@ -399,14 +399,15 @@ class LVTRTrainer(BaseTrainer):
         same sequence is clean.  The calling thread is moved onto a stream the trainer owns, once (switching per
         step costs 1 ms of cross-stream waits per step), so the caller's later work is ordered after the step as
         before."""
+        from hipvg import functional as HF
         cur = torch.cuda.current_stream(dev)
-        prio = int(os.environ.get("VG_MAIN_PRIO", "-1"))      # (0: lab -- a normal-priority compute stream, the hazard below open)
-        # The stream must also be of HIGH priority: the first launch of a graph with parallel branches from a normal-priority
-        # stream can walk off the exec's internal stream list inside hipGraphLaunch (hipvg.functional.graph_launch_stream).
-        if cur != torch.cuda.default_stream(dev) and (prio >= 0 or getattr(cur, "priority", 0) < 0):
+        # The stream is hipvg.functional.graph_launch_stream's: one per process and device, shared by every trainer, of the
+        # kind VG_LAUNCH_STREAM names (ROCm 7.0's hipGraphLaunch can walk off the exec's internal stream list when the
+        # launch stream shares a pooled hardware queue with two of them -- the hazard, the safe kinds and their price are
+        # described there).
+        if HF.is_safe_launch_stream(cur):
             return
-        if self._compute_stream is None:
-            self._compute_stream = torch.cuda.Stream(device=dev, priority=prio)
+        self._compute_stream = HF.graph_launch_stream(dev)
         self._compute_stream.wait_stream(cur)
         torch.cuda.set_stream(self._compute_stream)
 
