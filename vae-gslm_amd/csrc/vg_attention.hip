@@ -42,6 +42,9 @@ constexpr float SCALE = 0.125f;   // 1 / sqrt(64)
 #ifndef VG_ATTN_HEADMIX
 #define VG_ATTN_HEADMIX 1   // heads x and 15 - x share an XCD (0: x and x + 8, lab)
 #endif
+#ifndef VG_ATTN_PRIO
+#define VG_ATTN_PRIO 0      // lab: static wave priority by block parity (bit 0: forward, blockIdx & 1; bit 1: backward, blockIdx % 3)
+#endif
 #ifndef VG_ATTN_BSW
 #define VG_ATTN_BSW 1       // swizzle of the bf16 backward kernels' row images (see row_swz): 1 = the dual-use one (round 6), 0 = RowTile's (lab)
 #endif
@@ -602,6 +605,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16_t* __restr
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((VG_ATTN_PRIO & 1) && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(1);
   // 1-D grid, longest sweeps first over the whole launch (LPT order); the tiles of one (b, h) are H*B apart
   const int nqt = (Tn + QB2 - 1) / QB2, HB = gridDim.x / nqt;
   int hb, rank;
@@ -1020,6 +1024,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   char* v_row = smem + LdsPlan<T>::ROW_BYTES;
   char* k_tr = smem + 2 * LdsPlan<T>::ROW_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (VG_ATTN_PRIO & 2) { const int pr = blockIdx.x % 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); }
   // 1-D grid, longest sweeps first over the whole launch (LPT order); the tiles of one (b, h)
   // are H*B apart, i.e. on the same XCD whenever H*B is a multiple of 8, and share K/V in its L2
   const int nqt = (Tn + QB - 1) / QB, HB = gridDim.x / nqt;
@@ -1224,6 +1229,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? VG_ATTN_OCC : 1) void attn_bw
   char* do_tr = q_tr + LdsPlan<T>::TR_BYTES;
   float* st = reinterpret_cast<float*>(do_tr + LdsPlan<T>::TR_BYTES);   // [2][64]: S init, dP init
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (VG_ATTN_PRIO & 2) { const int pr = blockIdx.x % 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); }
   const int nkb = (Tn + QB - 1) / QB, HB = gridDim.x / nkb;   // low key tiles sweep the most query tiles: first
   int hb, ktile;
   pair_and_rank(blockIdx.x, nkb, HB, sched, hb, ktile);
