@@ -758,6 +758,9 @@ constexpr int FD = FT + 6;          // du frames in LDS
 constexpr int FX = FT + 12;         // x rows in LDS
 constexpr int FUSED_LDS = (FX + FD) * 1024;
 constexpr int FRUN = 7;             // frames per wave in phase 2 (4 x 7 >= FT)
+#ifndef VG_DW_ONE_RUN
+#define VG_DW_ONE_RUN 1             // phase 2 as one run of 7 frames (13-row windows read once); 0: sub-runs of 4 + 3 (lab)
+#endif
 
 template <int TAPS>
 __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
@@ -924,8 +927,8 @@ __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* 
       radd[f] = *reinterpret_cast<const uint4*>(dx_add + (rbase + min(T0 + FRUN * wave + f, Tn - 1)) * a.C + lane * 8);
   }
   __syncthreads();
-  // ---- phase 2: own frames T0 + 7 wave .. + 6, in sub-runs of 4 + 3 (seven at once: 56 + 56 registers of frames next to the
-  // 56 of the weights -- the compiler then parks the gamma / beta sums in scratch)
+  // ---- phase 2: own frames T0 + 7 wave .. + 6 (the sub-run form dates from the hunt for the spills that turned out to be the
+  // compiler sinking the gamma / beta sums: with those pinned, seven frames at once fit)
   const int f0 = FRUN * wave;
   float gw[8][TAPS];
 #pragma unroll
@@ -988,9 +991,13 @@ __global__ __launch_bounds__(256, 2) void dwnorm_bwd_fused_kernel(const bf16_t* 
       }
     }
   };
+#if VG_DW_ONE_RUN
+  sub_run(std::integral_constant<int, 0>{}, std::integral_constant<int, FRUN>{});
+#else       // (lab: sub-runs of 4 + 3 re-read six window rows of each image: 31.8 against 31.35 us per launch; same bits)
   sub_run(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
   __builtin_amdgcn_sched_barrier(0);
   sub_run(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+#endif
   // ---- the four waves' partial sums
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);
