@@ -174,7 +174,7 @@ _MAIN_OF_SIDE = {}
 # bench line of this repository was measured on) | prio | mask.  tests/conftest.py selects `prio` for the long-lived pytest
 # process, which is exactly the population the hazard needs.
 _LAUNCH_STREAMS = {}
-_SAFE_LAUNCH_IDS = set()
+_LAUNCH_IDS = set()
 
 
 def launch_stream_kind() -> str:
@@ -184,9 +184,9 @@ def launch_stream_kind() -> str:
     return kind
 
 
-def is_safe_launch_stream(st) -> bool:
+def is_launch_stream(st) -> bool:
     """Is ``st`` one of this process's launch streams (of whatever kind VG_LAUNCH_STREAM selected)?"""
-    return st.cuda_stream in _SAFE_LAUNCH_IDS
+    return st.cuda_stream in _LAUNCH_IDS
 
 
 def graph_launch_stream(device) -> "torch.cuda.Stream":
@@ -194,7 +194,7 @@ def graph_launch_stream(device) -> "torch.cuda.Stream":
     (created once per process)."""
     dev = torch.device(device)
     cur = torch.cuda.current_stream(dev)
-    if cur.cuda_stream in _SAFE_LAUNCH_IDS:
+    if cur.cuda_stream in _LAUNCH_IDS:
         return cur
     st = _LAUNCH_STREAMS.get(dev)
     if st is None:
@@ -206,7 +206,7 @@ def graph_launch_stream(device) -> "torch.cuda.Stream":
         else:
             st = torch.cuda.Stream(device=dev, priority=-1 if kind == "prio" else 0)
         _LAUNCH_STREAMS[dev] = st
-        _SAFE_LAUNCH_IDS.add(st.cuda_stream)
+        _LAUNCH_IDS.add(st.cuda_stream)
     return st
 
 

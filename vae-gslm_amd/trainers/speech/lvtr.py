@@ -405,7 +405,7 @@ class LVTRTrainer(BaseTrainer):
         # kind VG_LAUNCH_STREAM names (ROCm 7.0's hipGraphLaunch can walk off the exec's internal stream list when the
         # launch stream shares a pooled hardware queue with two of them -- the hazard, the safe kinds and their price are
         # described there).
-        if HF.is_safe_launch_stream(cur):
+        if HF.is_launch_stream(cur):
             return
         self._compute_stream = HF.graph_launch_stream(dev)
         self._compute_stream.wait_stream(cur)
