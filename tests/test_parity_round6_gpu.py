@@ -587,10 +587,15 @@ def test_dwnorm_backward_in_one_launch_on_packed_rows(F, monkeypatch):
     du1, dx1, pg1, pb1, pw1 = F.dwnorm_bwd_raw(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift)
     assert pg1.shape[0] == plan.nseq * -(-T // 26)
     assert torch.equal(du0, du1) and torch.equal(dx0, dx1)
-    dx2, dte, _, _, _ = F.dwnorm_bwd_block(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift)
+    dx2, dte, _, _, _, rows = F.dwnorm_bwd_block(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift)
     want = F.segment_colsum(du1, plan)[:Bq].double()
     assert torch.equal(dx2, dx1) and dte.shape == (Bq, C)
     assert float((dte.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+    # the conv-bias gradient is the column sum of the returned rows (per-block partials here), with or without the fold
+    total = du1.double().sum(0)
+    assert float((rows.double().sum(0) - total).abs().max()) <= 2e-5 * float(total.abs().max()) + 1e-6
+    _, none, _, _, _, rows2 = F.dwnorm_bwd_block(dy, xp, w, cb, te, gamma, mean, rstd, dxa, plan, 7, shift, need_dte=False)
+    assert none is None and torch.equal(rows2, rows)
     for name, a, b in (("gamma", pg0, pg1), ("beta", pb0, pb1), ("taps", pw0, pw1)):
         want, got = a.double().sum(0), b.double().sum(0)
         assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6, name

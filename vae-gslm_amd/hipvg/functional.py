@@ -1776,25 +1776,29 @@ def _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shif
                                     ptr(dx_add), ptr(du), ptr(dx), ptr(npart), ptr(wpart), ptr(dupart), M, Cc, 0 if plan else int(T),
                                     ptr(plan.cu) if plan else None, plan.nseq if plan else 0, plan.B if plan else 0, max_len,
                                     int(taps), int(shift), dtype_id(x.dtype), stream()), "vg_dwnorm_bwd_fused")
+    if du_sums == "partials":      # fp32 [nseq * bps, C]: blocks [s * bps, (s + 1) * bps) are sequence s
+        return du, dx, npart[:, :Cc], npart[:, Cc:], wpart, dupart
     if du_sums:
-        # blocks [s * bps, (s + 1) * bps) are sequence s: nseq segments of bps rows each
         return du, dx, npart[:, :Cc], npart[:, Cc:], wpart, segment_colsum(dupart, nseq)
     return du, dx, npart[:, :Cc], npart[:, Cc:], wpart
 
 
-def dwnorm_bwd_block(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift):
-    """The (depthwise conv -> norm) backward as a conv block needs it: (dx, per-sequence column sums of du [B, C], gamma /
-    beta / tap partial sums).  One launch without a du tensor where vg_dwnorm_bwd_fused runs; else the two run kernels, du
-    through HBM and a pass over it for the sums."""
+def dwnorm_bwd_block(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift, need_dte=True):
+    """The (depthwise conv -> norm) backward as a conv block needs it: (dx, per-sequence column sums of du [B, C] or None,
+    gamma / beta / tap partial sums, rows whose column sum over ALL rows is the conv-bias gradient).  One launch without a du
+    tensor where vg_dwnorm_bwd_fused runs -- the per-sequence sums are then segments of its per-block partial rows, folded
+    only for a block that has a time embedding; else the two run kernels, du through HBM and a pass over it."""
     nb_seq = T.B if isinstance(T, PackPlan) else x.shape[0] // int(T)
     if _dw_fused_ok(dy, x, T, taps, shift):
-        _, dx, pg, pb, pw, dte = _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift, want_du=False,
-                                                   du_sums=True)
-        return dx, dte[:nb_seq], pg, pb, pw
+        _, dx, pg, pb, pw, dupart = _dwnorm_bwd_fused(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift, want_du=False,
+                                                      du_sums="partials")
+        nseq = T.nseq if isinstance(T, PackPlan) else nb_seq
+        dte = segment_colsum(dupart, nseq)[:nb_seq] if need_dte else None
+        return dx, dte, pg, pb, pw, dupart
     wide = dy.stride(0) != x.shape[1]
     dv, dx, pg, pb, pw = (dwnorm_bwd_ld_raw if wide else dwnorm_bwd_raw)(dy, x, w, cb, te, gamma, mean, rstd, dx_add, T, taps, shift)
     dte = segment_colsum(dv, T)[:nb_seq] if isinstance(T, PackPlan) else segment_colsum(dv, nb_seq)
-    return dx, dte, pg, pb, pw
+    return dx, dte, pg, pb, pw, dte
 
 
 def _dw_fused_ok(dy, x, T, taps, shift) -> bool:
@@ -2034,11 +2038,12 @@ class ConvBlockFn(torch.autograd.Function):
         elif g_c3 is not None:
             g_c3 = g_c3.view_as(c3w)
         # dte: per-sequence column sums of d loss / d v (the pseudo sequences' rows of a packed layout carry no gradient)
-        dx, dte, pg, pb, pw = dwnorm_bwd_block(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift)
+        dx, dte, pg, pb, pw, du_rows = dwnorm_bwd_block(du, x, w1, cb, te32, gamma, mean, rstd, dy, T, taps, shift,
+                                                         need_dte=has_te)
         # the five small reductions of this block (conv weight / bias, norm weight / bias, c2's bias) in one launch
         g_c2b, g_c1w, g_c1b, g_nw, g_nb = vec_grads([
             (None if id(c2b) in fused_bias else c2b, parts[0] if parts and parts[0] is not None else dpre),
-            (c1w, pw), (c1b, dte), (nw, pg), (nb_, pb)])
+            (c1w, pw), (c1b, du_rows), (nw, pg), (nb_, pb)])
         return (dx, dte if has_te else None, dcond, g_c1w, g_c1b, g_nw, g_nb, g_c2, g_c2b, g_c3, g_c3b,
                 None, None, None, None, None)
 
