@@ -241,6 +241,7 @@ def main():
     rank = dist.get_rank() if world > 1 else 0
 
     import hipvg
+    import hipvg.functional
     from hparams.hp import Hparams
     from trainers.speech.lvtr import LVTRTrainer
     from training_lib.synthetic import make_batch
@@ -459,7 +460,9 @@ def main():
                                   if args.ragged else "full",
                        "inputs": ("pinned host batches, asynchronous H2D two steps ahead (PCIe inside the timed region)"
                                   if args.host_batches else "resident in HBM before the timed region"),
-                       "accumulation": "one launch sequence over B x accum sequences" if args.coalesce else "per micro-batch"},
+                       "accumulation": "one launch sequence over B x accum sequences" if args.coalesce else "per micro-batch",
+                       # kind of the stream the hipGraphs are launched from (VG_LAUNCH_STREAM)
+                       "launch_stream": hipvg.functional.launch_stream_kind() if args.graph else "none"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT fwd, NN dgrad, TN wgrad)",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_static": traffic is not None,
